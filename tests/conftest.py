@@ -1,0 +1,34 @@
+"""pytest configuration: registers the ``gpu`` marker and puts the package on sys.path."""
+
+import pathlib
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+for p in (ROOT, ROOT / "transformer-recommenders_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are skipped (not failed) when no device is visible and -m gpu was not asked for."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

@@ -1,0 +1,164 @@
+"""The CPU oracle against the golden vectors produced by the reference itself.
+
+Fixtures come from ``oracle/make_golden.py`` (reference ``xfmr_rec/losses.py``
+imported unmodified + the HF ``BertModel`` the reference instantiates at
+``xfmr_rec/models.py:93-102``). Tolerances: the oracle runs the same fp32 ATen
+ops, so agreement is at rounding level (1e-6 abs/rel); masks must be equal.
+"""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as enc
+from oracle import losses as OL
+from oracle import model as OM
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def g1(golden_dir):
+    return np.load(golden_dir / "g1_losses.npz")
+
+
+def test_g1_losses_match_reference(g1):
+    index = json.loads(str(g1["index"]))
+    assert len(index) >= 100
+    kinds = set()
+    for c in index:
+        n = c["shape"][0]
+        q = _t(g1[f"in/s{c['seed']}_n{n}/q"]).clone().requires_grad_(True)
+        cand = _t(g1[f"in/s{c['seed']}_n{n}/cand"])
+        target = _t(g1[f"in/s{c['seed']}_n{n}/target"]) if c["has_target"] else None
+        parts = OL.embed_loss_parts(c["kind"], q, cand, target, **c["cfg"])
+        k = c["key"]
+        np.testing.assert_array_equal(parts["negative_mask"].numpy(), g1[f"{k}/mask"])
+        np.testing.assert_allclose(parts["logits"].detach().numpy(), g1[f"{k}/logits"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(parts["loss"].item(), g1[f"{k}/loss"], rtol=1e-6, atol=1e-6)
+        parts["loss"].backward()
+        np.testing.assert_allclose(q.grad.numpy(), g1[f"{k}/dq"], rtol=1e-5, atol=1e-6)
+        kinds.add(c["kind"])
+    assert kinds == set(OL.LOSS_KINDS)
+
+
+def test_g1_logits_statistics_match_reference(g1):
+    index = json.loads(str(g1["index"]))
+    seen = set()
+    for c in index:
+        n = c["shape"][0]
+        key = f"stats/s{c['seed']}_n{n}_v{c['variant']}"
+        if key in seen:
+            continue
+        seen.add(key)
+        q = _t(g1[f"in/s{c['seed']}_n{n}/q"])
+        cand = _t(g1[f"in/s{c['seed']}_n{n}/cand"])
+        target = _t(g1[f"in/s{c['seed']}_n{n}/target"]) if c["has_target"] else None
+        want = json.loads(str(g1[key]))
+        got = OL.logits_statistics(q, cand, target, **c["cfg"])
+        assert got.keys() == want.keys()
+        for name in want:
+            assert got[name] == pytest.approx(want[name], rel=1e-6, abs=1e-7), name
+
+
+@pytest.fixture(scope="module")
+def g2(golden_dir):
+    return np.load(golden_dir / "g2_encoder.npz")
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_g2_encoder_matches_hf_bert(g2, case):
+    cfg = json.loads(str(g2[f"{case}/cfg"]))
+    prefix = f"{case}/param/"
+    params = {k[len(prefix):]: _t(g2[k]).clone().requires_grad_(True) for k in g2.files if k.startswith(prefix)}
+    x = _t(g2[f"{case}/x"]).clone().requires_grad_(True)
+    mask = _t(g2[f"{case}/mask"])
+    out = enc.encoder_forward(params, x, mask, cfg["A"])
+    valid = mask.bool().numpy()
+    for impl, tol in (("eager", 2e-6), ("sdpa", 2e-5)):
+        want = g2[f"{case}/{impl}/last_hidden_state"]
+        # padded query rows are garbage-by-construction in HF (fully masked or not); compare valid rows
+        np.testing.assert_allclose(out.detach().numpy()[valid], want[valid], rtol=tol, atol=tol)
+    w = torch.linspace(0.5, 1.5, cfg["H"])
+    loss = ((out * w) ** 2 * mask[..., None]).sum()
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g2[f"{case}/eager/loss"], rtol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g2[f"{case}/eager/dx"], rtol=1e-4, atol=2e-5)
+    gp = f"{case}/eager/grad/"
+    checked = 0
+    for k in g2.files:
+        if k.startswith(gp):
+            name = k[len(gp):]
+            np.testing.assert_allclose(params[name].grad.numpy(), g2[k], rtol=1e-4, atol=3e-5, err_msg=name)
+            checked += 1
+    assert checked == len(params)  # every oracle parameter receives a gradient
+
+
+@pytest.fixture(scope="module")
+def g3(golden_dir):
+    return np.load(golden_dir / "g3_step.npz")
+
+
+def _g3_setup(g3):
+    cfg = json.loads(str(g3["cfg"]))
+    params = {k[len("param0/"):]: _t(g3[k]).clone() for k in g3.files if k.startswith("param0/")}
+    batch = {
+        "history_item_idx": _t(g3["hist"]),
+        "pos_item_idx": _t(g3["pos"]),
+        "neg_item_idx": _t(g3["neg"]),
+    }
+    return cfg, params, _t(g3["table"]), batch
+
+
+def test_g3_compute_losses_match_reference(g3):
+    cfg, params, table, batch = _g3_setup(g3)
+    out = OM.compute_losses(
+        params, table, batch, num_heads=cfg["A"], max_seq_length=cfg["L"], loss_cfg={},
+    )
+    for kind in OL.LOSS_KINDS:
+        np.testing.assert_allclose(float(out[f"loss/{kind}"]), g3[f"loss/{kind}"], rtol=2e-5, atol=1e-5, err_msg=kind)
+    want = json.loads(str(g3["stats"]))
+    for k, v in want.items():
+        assert out[k] == pytest.approx(v, rel=2e-5, abs=1e-6), k
+    e = OM.compute_embeds(
+        params, table, batch["history_item_idx"], batch["pos_item_idx"], batch["neg_item_idx"],
+        num_heads=cfg["A"], max_seq_length=cfg["L"],
+    )
+    np.testing.assert_array_equal(e["attention_mask"].numpy(), g3["attention_mask"])
+    np.testing.assert_array_equal(e["positive_mask"].numpy(), g3["positive_mask"])
+    np.testing.assert_allclose(e["query_embed"].numpy(), g3["query_embed"], rtol=1e-5, atol=1e-5)
+    assert int(e["positive_mask"].sum()) == e["query_embed"].shape[0] < int(e["attention_mask"].sum())
+
+
+@pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"])
+def test_g3_three_adamw_steps_match_reference(g3, train_loss):
+    cfg, params, table, batch = _g3_setup(g3)
+    tr = OM.OracleTrainer(
+        params, table, num_heads=cfg["A"], max_seq_length=cfg["L"], train_loss=train_loss, faithful=False,
+    )
+    for step in range(3):
+        loss, _ = tr.step(batch)
+        np.testing.assert_allclose(float(loss), g3[f"{train_loss}/loss_step{step}"], rtol=5e-5)
+        if step == 0:
+            for k, p in tr.params.items():
+                np.testing.assert_allclose(
+                    p.grad.numpy(), g3[f"{train_loss}/grad0/{k}"], rtol=2e-4, atol=2e-5, err_msg=k
+                )
+    for k, p in tr.params.items():
+        np.testing.assert_allclose(
+            p.detach().numpy(), g3[f"{train_loss}/param_after3/{k}"], rtol=1e-4, atol=2e-5, err_msg=k
+        )
+
+
+def test_lean_form_equals_materialised_form(g3):
+    """logits == [rowdot(q, e_pos) | Q E_neg^T]."""
+    cfg, params, table, batch = _g3_setup(g3)
+    for kind in OL.LOSS_KINDS:
+        lean = OM.lean_loss(
+            params, table, batch, num_heads=cfg["A"], max_seq_length=cfg["L"], kind=kind, loss_cfg={},
+        )
+        np.testing.assert_allclose(float(lean), g3[f"loss/{kind}"], rtol=1e-4, atol=1e-5, err_msg=kind)
