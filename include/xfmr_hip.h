@@ -1,0 +1,281 @@
+/*
+ * xfmr_hip.h -- C ABI of libxfmr_hip.so: the MI355X (gfx950 / CDNA4) training hot path of the
+ * sequential transformer recommender.
+ *
+ * Boundary: the reference has no FFI layer; its "operator API" for this path is
+ * PyTorch nn.Module + autograd. Each entry point below therefore replaces one ATen-level compute site
+ * that the reference reaches through torch / transformers, and cites it. Paths are relative to the
+ * reference checkout (xfmr_rec/...) or, prefixed TF:, to the `transformers` package the reference
+ * instantiates its encoder from (xfmr_rec/models.py:93-102).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer (inputs, outputs, workspace) is owned by the caller
+ *     and lives in device memory of the current HIP device; nothing is allocated, freed or retained.
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *     no entry point synchronises, so all of them may be captured into a hipGraph.
+ *   - all floating-point tensors in HBM are fp32, row-major, contiguous unless a stride is given.
+ *     `precision` selects the matrix-core arithmetic of every contraction:
+ *         XFMR_PREC_F32  : v_mfma_f32_32x32x2_f32  (exact fp32 fma chain; parity mode)
+ *         XFMR_PREC_BF16 : v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 on the way into LDS,
+ *                          fp32 accumulate; the analogue of the reference's `bf16-mixed`,
+ *                          xfmr_rec/trainer.py:450)
+ *     LayerNorm, softmax, loss reductions, AdamW always run in fp32.
+ *   - item indices are int64 as the reference's batches carry them (xfmr_rec/data.py:534-540).
+ *   - return value: 0 on success, a negative XFMR_E* code otherwise (never throws, never aborts).
+ *     Asynchronous HIP errors surface at the caller's next synchronisation.
+ *   - stateless and re-entrant: safe for one process per GPU and for several host threads on
+ *     different streams.
+ */
+#ifndef XFMR_HIP_H
+#define XFMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XFMR_ABI_VERSION 1
+
+enum {
+  XFMR_OK = 0,
+  XFMR_EINVAL = -1,      /* bad argument (null pointer, non-positive size)            */
+  XFMR_EUNSUPPORTED = -2, /* shape outside what the kernels are built for              */
+  XFMR_EWORKSPACE = -3,  /* workspace too small                                        */
+  XFMR_EHIP = -4,        /* a HIP launch failed (hipGetLastError)                      */
+  XFMR_EALIGN = -5       /* pointer / leading dimension not 16-byte aligned            */
+};
+
+enum { XFMR_PREC_F32 = 0, XFMR_PREC_BF16 = 1 };
+
+/* Loss heads, in the order of the reference's LOSS_CLASSES (xfmr_rec/losses.py:546-554). */
+enum {
+  XFMR_LOSS_ALIGNMENT = 0,
+  XFMR_LOSS_ALIGNMENT_CONTRASTIVE = 1,
+  XFMR_LOSS_CONTRASTIVE = 2,
+  XFMR_LOSS_INFONCE = 3,
+  XFMR_LOSS_NCE = 4,
+  XFMR_LOSS_PAIRWISE_HINGE = 5,
+  XFMR_LOSS_PAIRWISE_LOGISTIC = 6,
+  XFMR_NUM_LOSSES = 7
+};
+
+const char* xfmr_strerror(int code);
+int xfmr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder configuration and the flat parameter layout.
+ *
+ * All trainable tensors of the causal BERT encoder live in ONE flat fp32 buffer (and their gradients
+ * and AdamW moments in buffers of the same layout), so the data-parallel gradient exchange is a single
+ * all-reduce and the optimizer a single launch. Tensor order (HF state_dict names, the reference's
+ * checkpoint keys under `model.model.0.auto_model.`):
+ *   embeddings.position_embeddings.weight (max_pos,H) | embeddings.token_type_embeddings.weight (2,H)
+ *   | embeddings.LayerNorm.{weight,bias} (H) | per layer: attention.self.{query,key,value}.weight
+ *   stored as one (3H,H) block followed by the (3H) bias block | attention.output.dense.{weight,bias}
+ *   | attention.output.LayerNorm.{weight,bias} | intermediate.dense.{weight (I,H),bias (I)}
+ *   | output.dense.{weight (H,I),bias (H)} | output.LayerNorm.{weight,bias}.
+ * `word_embeddings` and `pooler.*` never receive a gradient on this path and are not
+ * part of the buffer.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct xfmr_encoder_cfg {
+  int32_t batch;      /* B: sequences in this call                                  */
+  int32_t seq_len;    /* L: padded length of every sequence (<= max_pos)            */
+  int32_t hidden;     /* H: d_model == item-embedding width (xfmr_rec/models.py:336-345) */
+  int32_t heads;      /* A: attention heads; H/A must be 32                          */
+  int32_t inter;      /* I: FFN width                                                */
+  int32_t layers;     /* number of BertLayers                                        */
+  int32_t max_pos;    /* rows of the position-embedding table (ModelConfig.max_seq_length) */
+  int32_t precision;  /* XFMR_PREC_*                                                 */
+  float ln_eps;       /* 1e-12 (TF:models/bert/configuration_bert.py:44-63)          */
+  float hidden_dropout;  /* 0.1 in training (same file), 0 for eval / parity         */
+  float attn_dropout;    /* 0.1 in training, 0 for eval / parity                     */
+  uint32_t reserved;
+  uint64_t seed;      /* dropout stream of this step; fwd and bwd must pass the same */
+} xfmr_encoder_cfg;
+
+/* Number of fp32 elements of the flat parameter buffer. */
+int64_t xfmr_param_count(const xfmr_encoder_cfg* cfg);
+/* Offsets (in elements) of the tensors in the order listed above: 4 + 16*layers entries
+ * (q,k,v weights are 3 consecutive (H,H) entries, then 3 (H) biases). Returns the entry count. */
+int32_t xfmr_param_offsets(const xfmr_encoder_cfg* cfg, int64_t* offsets, int32_t capacity);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1-K3: item-embedding gather + attention-mask derivation + BertEmbeddings.
+ * Replaces xfmr_rec/models.py:336-338 (torch.nn.Embedding gather), :343 (mask = (emb != 0).any(-1))
+ * and TF:models/bert/modeling_bert.py:68-108 (x + type_emb[0] + pos_emb[t] -> LayerNorm -> dropout).
+ *   item_idx (B*L) int64, table (n_rows,H) frozen, pos_emb (>=L,H), type_emb (2,H), gamma/beta (H)
+ *   out (B*L,H) post-LN(+dropout), pre (B*L,H) LN input (saved for backward), mean/rstd (B*L),
+ *   key_mask (B*L) uint8 = 1 where the gathered row has a non-zero element.
+ * An index outside [0,n_rows) is a caller error; it is clamped to row 0 (padding) rather than faulting.
+ * ---------------------------------------------------------------------------------------------- */
+int xfmr_embed_ln_fwd(const int64_t* item_idx, const float* table, int64_t n_rows, const float* pos_emb,
+                      const float* type_emb, const float* gamma, const float* beta, float* out, float* pre,
+                      float* mean, float* rstd, uint8_t* key_mask, int32_t B, int32_t L, int32_t H, float eps,
+                      float dropout_p, uint64_t seed, uint32_t site, void* stream);
+
+/* Gradients of the embedding stage w.r.t. position / token-type embeddings (the item table is frozen,
+ * xfmr_rec/models.py:251-253): d_pos[t] = sum_b d_pre[b,t], d_type[0] = sum_t d_pos[t], d_type[1] = 0,
+ * rows >= L of d_pos are zeroed. d_pre is the output of xfmr_layernorm_bwd on the embedding LayerNorm. */
+int xfmr_embed_param_grads(const float* d_pre, float* d_pos, float* d_type, int32_t B, int32_t L, int32_t H,
+                           int32_t max_pos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (TF:models/bert/modeling_bert.py:292, :349 -- torch.nn.LayerNorm over the last dim).
+ * fwd: y = (x-mean)*rstd*gamma+beta; saves mean, rstd.
+ * bwd: dx (rows,H); per-column sums d_gamma, d_beta, and d_bias = colsum(d_lin) where
+ *      d_lin = dx * dropout_keep/(1-p) is the gradient of the Linear output that was dropped out and
+ *      added to the residual before this LayerNorm (d_lin may be NULL when dropout_p == 0: d_lin == dx).
+ *      `partials` is workspace of xfmr_layernorm_bwd_workspace(rows,H) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+int xfmr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int64_t rows, int32_t H, float eps, void* stream);
+size_t xfmr_layernorm_bwd_workspace(int64_t rows, int32_t H);
+int xfmr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       float* dx, float* d_lin, float* d_gamma, float* d_beta, float* d_bias, int64_t rows,
+                       int32_t H, float dropout_p, uint64_t seed, uint32_t site, void* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Linear layers (torch.nn.Linear at TF:models/bert/modeling_bert.py:175-177, :289, :337, :347) as MFMA
+ * GEMMs with fused epilogues. x (M,K), w (N,K) [torch layout: out_features x in_features], y (M,N).
+ *   XFMR_EPI_BIAS          y = x w^T + b
+ *   XFMR_EPI_BIAS_GELU     pre = x w^T + b -> aux_out (M,N); y = gelu_erf(pre)        (:337-338)
+ *   XFMR_EPI_BIAS_DROP_RES y = dropout(x w^T + b) + residual                          (:289-291, :347-349)
+ * ---------------------------------------------------------------------------------------------- */
+enum { XFMR_EPI_BIAS = 0, XFMR_EPI_BIAS_GELU = 1, XFMR_EPI_BIAS_DROP_RES = 2 };
+int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
+                    int32_t epilogue, const float* residual, float* aux_out, float dropout_p, uint64_t seed,
+                    uint32_t site, int32_t precision, void* stream);
+/* dx = dy w (+ residual_grad) or, with gelu_pre != NULL, dx = (dy w) * gelu'(gelu_pre).   dy (M,N), w (N,K), dx (M,K) */
+int xfmr_linear_bwd_dx(const float* dy, const float* w, float* dx, int64_t M, int32_t N, int32_t K,
+                       const float* residual_grad, const float* gelu_pre, int32_t precision, void* stream);
+/* dw = dy^T x  (N,K), reduced over M with deterministic split-K slabs in `workspace`. */
+size_t xfmr_linear_bwd_dw_workspace(int64_t M, int32_t N, int32_t K);
+int xfmr_linear_bwd_dw(const float* dy, const float* x, float* dw, int64_t M, int32_t N, int32_t K,
+                       int32_t precision, void* workspace, size_t workspace_bytes, void* stream);
+/* out[n] = sum_m a[m,n] (bias gradients). workspace: xfmr_colsum_workspace(M,N) bytes. */
+size_t xfmr_colsum_workspace(int64_t M, int32_t N);
+int xfmr_colsum(const float* a, float* out, int64_t M, int32_t N, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5: causal self-attention with key-padding mask, flash-style (no (L,L) score tensor in HBM).
+ * Replaces TF:models/bert/modeling_bert.py:111-136 (eager_attention_forward) / SDPA and the mask built
+ * at TF:masking_utils.py:76-80,168-179: key k is visible to query q iff k <= q and key_mask[b,k].
+ *   qkv (B*L,3H): [q | k | v] per token, heads along H; ctx (B*L,H); lse (B,A,L) log-sum-exp of the
+ *   scaled scores (saved for backward). head size H/A must be 32. A query with no visible key gets ctx = 0.
+ * bwd: d_qkv (B*L,3H) from d_ctx, recomputing probabilities from qkv and lse.
+ * ---------------------------------------------------------------------------------------------- */
+int xfmr_attn_fwd(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,
+                  int32_t A, int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision,
+                  void* stream);
+int xfmr_attn_bwd(const float* qkv, const uint8_t* key_mask, const float* ctx, const float* lse,
+                  const float* d_ctx, float* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p,
+                  uint64_t seed, uint32_t site, int32_t precision, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole encoder (BertEmbeddings + `layers` x BertLayer), forward and backward, as one call each.
+ * Replaces BertModel.forward as driven by xfmr_rec/models.py:343-345 (forward) and autograd (backward).
+ * `params`/`grads`: flat buffers described above. `acts`: activation workspace of
+ * xfmr_encoder_workspace_bytes(cfg) bytes, written by fwd and read by bwd (the caller keeps it alive
+ * in between). tok (B*L,H) = last_hidden_state; key_mask (B*L) uint8.
+ * bwd overwrites `grads` (it does not accumulate) from d_tok (B*L,H); d_tok is clobbered.
+ * ---------------------------------------------------------------------------------------------- */
+size_t xfmr_encoder_workspace_bytes(const xfmr_encoder_cfg* cfg);
+int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int64_t* item_idx,
+                     const float* table, int64_t n_rows, float* tok, uint8_t* key_mask, void* acts,
+                     size_t acts_bytes, void* stream);
+int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* grads, float* d_tok,
+                     const uint8_t* key_mask, void* acts, size_t acts_bytes, void* stream);
+
+/* masked mean pooling: sentence_embedding[b] = sum_t tok[b,t]*m[b,t] / max(sum_t m[b,t], 1e-9)
+ * (sentence-transformers Pooling(mean) as wired at xfmr_rec/models.py:143-145). */
+int xfmr_mean_pool(const float* tok, const uint8_t* key_mask, float* out, int32_t B, int32_t L, int32_t H,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8-K17: fused in-batch sampled loss (all seven heads + LogitsStatistics + dL/dquery in ONE pass over
+ * the logits, which are never materialised).
+ * Replaces xfmr_rec/models.py:390-416 (valid-token compaction, pos/neg gathers, the (Np,1+N,H)
+ * candidate tensor), xfmr_rec/losses.py:128-155 (EmbedLoss.forward: logits, target, false-negative
+ * mask), :338-372, :408-543 (the seven heads), :375-405 (LogitsStatistics) and their autograd.
+ *
+ * Mathematically logits = [ rowdot(q, E[pos]) | Q E[neg]^T ]. Rows: positions with
+ * key_mask != 0 and pos_idx != 0 (Np). Columns: the positive, then one negative per position with
+ * key_mask != 0 (N), every row scoring against all of them (shared in-batch negatives).
+ *
+ * `mode`:
+ *   XFMR_NEG_SHARED  in-batch negatives as above (reference training path).
+ *   XFMR_NEG_CATALOG columns = every row of `table` (full-catalogue softmax: EmbedLoss.forward(q,
+ *                    table[None].expand, target=pos_idx) with target_position=None);
+ *                    neg_idx is ignored; the positive's own column is not a negative.
+ * Ties: a negative that is the row's positive item has, in the reference, a logit bit-identical to the
+ * positive's (same vectors through the same bmm) -- the kernel reproduces that by item id.
+ * num_hard_negatives (losses.py:295-330) is not fused: pass 0.
+ *
+ * Outputs (all device memory):
+ *   losses[7]        summed loss per head (fp64 -> written as fp32), order XFMR_LOSS_*
+ *   stats[16]        see XFMR_STAT_*; fp32
+ *   d_tok (B*L,H)    dL(train_head)/d tok, rows that are not queries are zero; may be NULL (eval)
+ * workspace: xfmr_sampled_loss_workspace(B*L, H, n_rows) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+enum { XFMR_NEG_SHARED = 0, XFMR_NEG_CATALOG = 1 };
+enum {
+  XFMR_STAT_N_VALID = 0,     /* N : positions with key_mask != 0  (batch/attention_non_zero)  */
+  XFMR_STAT_N_QUERY = 1,     /* Np: rows with a non-padding positive (batch/positive_non_zero) */
+  XFMR_STAT_NEG_DENSITY = 2, /* logits/neg/density */
+  XFMR_STAT_POS_MEAN = 3, XFMR_STAT_POS_STD = 4, XFMR_STAT_POS_MIN = 5, XFMR_STAT_POS_MAX = 6,
+  XFMR_STAT_NEG_MEAN = 7, XFMR_STAT_NEG_STD = 8, XFMR_STAT_NEG_MIN = 9, XFMR_STAT_NEG_MAX = 10,
+  XFMR_STAT_NEG_COUNT = 11,  /* number of (row, column) pairs counted as negatives */
+  XFMR_NUM_STATS = 16
+};
+typedef struct xfmr_loss_cfg {
+  int32_t train_head;           /* XFMR_LOSS_*: the head whose gradient is produced               */
+  int32_t all_heads;            /* 1: evaluate all seven heads + statistics (trainer.py:250-264);
+                                   0: only train_head (others are returned as 0)                   */
+  int32_t mask_false_negatives; /* LossConfig.mask_false_negatives (losses.py:27)                   */
+  int32_t mode;                 /* XFMR_NEG_*                                                       */
+  int32_t precision;            /* XFMR_PREC_*                                                      */
+  float scale;                  /* LossConfig.scale  (losses.py:29)                                 */
+  float margin;                 /* LossConfig.margin (losses.py:30)                                 */
+  int32_t reserved;
+} xfmr_loss_cfg;
+size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows);
+int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
+                      const int64_t* neg_idx, const float* table, const float* table_rnorm, int64_t n_rows,
+                      int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* List form of the same computation, for queries that are already compacted -- the calling convention of
+ * EmbedLoss.forward(query_embed (Np,H), candidate_embed) (xfmr_rec/losses.py:128-155) when the candidates are
+ * the structured [positive | shared negatives] set that compute_embeds builds (xfmr_rec/models.py:398-416):
+ *   query (Np,H); pos_items (Np) item id of each row's positive; neg_items (N) item ids of the shared negative
+ *   columns (ignored in XFMR_NEG_CATALOG mode); d_query (Np,H) or NULL. Every row of d_query is written. */
+size_t xfmr_sampled_loss_lists_workspace(int64_t n_query, int64_t n_neg, int32_t H, int64_t n_rows);
+int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const int64_t* pos_items,
+                            const int64_t* neg_items, int64_t n_query, int64_t n_neg, const float* table,
+                            const float* table_rnorm, int64_t n_rows, int32_t H, float* losses, float* stats,
+                            float* d_query, void* workspace, size_t workspace_bytes, void* stream);
+/* table_rnorm[r] = 1 / max(||table[r]||, 1e-8): per-item inverse norms for the cosine heads
+ * (torch cosine_similarity, losses.py:206-208); computed once because the table is frozen. */
+int xfmr_table_rnorm(const float* table, float* table_rnorm, int64_t n_rows, int32_t H, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K18: AdamW over the flat buffer (torch.optim.AdamW as configured at xfmr_rec/trainer.py:327-332:
+ * decoupled weight decay, bias-corrected moments, eps outside the sqrt). `step` is 1-based.
+ * grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce).
+ * ---------------------------------------------------------------------------------------------- */
+int xfmr_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+               float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+               void* stream);
+
+/* Elementwise helpers used by the autograd wrappers. */
+int xfmr_scale_by_device_scalar(float* x, int64_t n, const float* scalar, void* stream);
+
+/* Self-test of the MFMA operand / accumulator lane maps this library relies on (A = I against an
+ * asymmetric B, both precisions). out[0] = mismatching elements in total, out[1] = bf16 maps, out[2] = f32 maps. */
+int xfmr_selftest_mfma(int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFMR_HIP_H */

@@ -139,9 +139,10 @@ def _ragged_inputs(B, L, H, seed, lengths):
 def gen_encoder():
     store: dict[str, np.ndarray] = {"versions": np.array(VERSIONS)}
     cases = {
-        "a": dict(B=3, L=12, H=16, nL=2, A=2, I=32, lengths=[12, 7, 1]),
+        # head size 32 throughout (the reference's 384/12; the HIP attention kernels are built for it)
+        "a": dict(B=3, L=12, H=32, nL=2, A=1, I=64, lengths=[12, 7, 1]),
         "b": dict(B=2, L=20, H=64, nL=1, A=2, I=64, lengths=[20, 13]),
-        "c": dict(B=2, L=40, H=32, nL=2, A=1, I=64, lengths=[33, 40]),
+        "c": dict(B=2, L=40, H=32, nL=2, A=1, I=32, lengths=[33, 40]),
     }
     for name, c in cases.items():
         x = _ragged_inputs(c["B"], c["L"], c["H"], 7, c["lengths"])
@@ -197,7 +198,7 @@ def _ref_compute_embeds(bert, table, hist, pos, neg, max_seq_length, is_normaliz
 
 def gen_step():
     store: dict[str, np.ndarray] = {"versions": np.array(VERSIONS)}
-    V, H, nL, A, I, L, B = 50, 16, 2, 1, 32, 10, 4
+    V, H, nL, A, I, L, B = 50, 64, 1, 2, 32, 10, 4
     g = torch.Generator().manual_seed(3)
     items = torch.randn(V, H, generator=g)
     items = items / items.norm(dim=-1, keepdim=True)
@@ -238,7 +239,7 @@ def gen_step():
             q, cand, *_ = _ref_compute_embeds(bert, table, hist, pos, neg, L)
             loss = loss_fn(q, cand)
             loss.backward()
-            if step == 0:
+            if step == 0 and train_loss != "AlignmentContrastiveLoss":
                 for k, p in bert.named_parameters():
                     if p.grad is not None:
                         store[f"{train_loss}/grad0/{k}"] = _np(p.grad)
@@ -257,11 +258,65 @@ def gen_step():
     print("g3_step done")
 
 
+# --------------------------------------------------------------------------- G4
+def gen_shared_negatives():
+    """The training-path candidate structure (models.py:398-416) through the reference loss classes:
+    cand = cat([E[pos][:, None], E[neg][None].expand(Np, -1, -1)], 1), positive at column 0."""
+    store: dict[str, np.ndarray] = {"versions": np.array(VERSIONS)}
+    V, H, Np, Nn = 30, 64, 21, 33
+    g = torch.Generator().manual_seed(5)
+    items = torch.randn(V, H, generator=g)
+    items = items / items.norm(dim=-1, keepdim=True)
+    table = torch.cat([torch.zeros(1, H), items])
+    q0 = torch.randn(Np, H, generator=g) * 1.5
+    pos = torch.randint(1, V + 1, (Np,), generator=g)
+    neg = torch.randint(0, V + 1, (Nn,), generator=g)  # includes some padding-row (0) negatives
+    neg[3] = pos[0]  # sampled negatives that ARE some row's positive (false negatives, exact ties)
+    neg[7] = pos[5]
+    variants = [
+        dict(),
+        dict(mask_false_negatives=False),
+        dict(scale=20.0),
+        dict(margin=0.0),
+        dict(mask_false_negatives=False, scale=5.0, margin=0.25),
+    ]
+    index = []
+    for vi, var in enumerate(variants):
+        cfg = ref_losses.LossConfig(**var)
+        for cls in ref_losses.LOSS_CLASSES:
+            q = q0.clone().requires_grad_(True)
+            cand = torch.cat([table[pos][:, None, :], table[neg][None, :, :].expand(Np, -1, -1)], dim=1)
+            loss = cls(cfg)(q, cand)
+            loss.backward()
+            key = f"v{vi}/{cls.__name__}"
+            store[f"{key}/loss"] = _np(loss)
+            store[f"{key}/dq"] = _np(q.grad)
+            index.append(dict(key=key, kind=cls.__name__, cfg=cfg.model_dump()))
+        cand = torch.cat([table[pos][:, None, :], table[neg][None, :, :].expand(Np, -1, -1)], dim=1)
+        store[f"v{vi}/stats"] = np.array(json.dumps(ref_losses.LogitsStatistics(cfg)(q0, cand)))
+    # full-catalogue form (SURVEY F9): every table row is a column, target = the positive's row
+    cfg = ref_losses.LossConfig(target_position=None, mask_false_negatives=False)
+    for cls in ref_losses.LOSS_CLASSES:
+        q = q0.clone().requires_grad_(True)
+        loss = cls(cfg)(q, table[None].expand(Np, -1, -1), pos)
+        loss.backward()
+        store[f"catalog/{cls.__name__}/loss"] = _np(loss)
+        store[f"catalog/{cls.__name__}/dq"] = _np(q.grad)
+    store["table"] = _np(table)
+    store["q"] = _np(q0)
+    store["pos"] = _np(pos)
+    store["neg"] = _np(neg)
+    store["index"] = np.array(json.dumps(index))
+    np.savez_compressed(OUT / "g4_shared_negatives.npz", **store)
+    print("g4_shared_negatives:", len(index), "cases + catalogue")
+
+
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(4)
     gen_losses()
     gen_encoder()
     gen_step()
+    gen_shared_negatives()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")

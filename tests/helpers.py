@@ -1,0 +1,75 @@
+"""Shared helpers of the GPU parity tests (inputs, oracle calls, tolerance reporting)."""
+
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import torch
+
+# Tolerances (BASELINE.md section 3 / SURVEY.md section 8d):
+#   fp32 MFMA path vs fp32 oracle: values |d| <= 1e-4 * max(1,|x|); gradients rel-L2 <= 1e-4
+#   bf16 MFMA path vs fp32 oracle: loss rel <= 1e-2; gradients rel-L2 <= 3e-2
+TOL = {
+    "fp32": dict(val=1e-4, grad_l2=2e-4, loss_rel=1e-4),
+    "bf16": dict(val=3e-2, grad_l2=3e-2, loss_rel=1e-2),
+}
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu().flatten()
+    b = b.detach().double().cpu().flatten()
+    den = b.norm().item()
+    return (a - b).norm().item() / (den if den > 0 else 1.0)
+
+
+def max_scaled_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs() / b.abs().clamp(min=1.0)).max().item()
+
+
+def assert_close(name, got, want, prec, kind="val"):
+    if kind == "grad":
+        e = rel_l2(got, want)
+        lim = TOL[prec]["grad_l2"]
+    else:
+        e = max_scaled_err(got, want)
+        lim = TOL[prec]["val"]
+    assert np.isfinite(e) and e <= lim, f"{name} [{prec}]: error {e:.3e} > {lim:.1e}"
+    return e
+
+
+def unit_table(V, H, seed=1234, device="cpu"):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(V + 1, H, generator=g)
+    t = t / t.norm(dim=-1, keepdim=True)
+    t[0] = 0.0
+    return t.to(device)
+
+
+def ragged_batch(B, L, V, lengths=None, seed=0, pad_some_pos=True):
+    """hist/pos/neg (B,L) int64 right-padded with 0 like the reference collate (data.py:799-805)."""
+    g = torch.Generator().manual_seed(seed)
+    if lengths is None:
+        lengths = torch.randint(1, L + 1, (B,), generator=g).tolist()
+        lengths[0] = L
+    hist = torch.zeros(B, L, dtype=torch.int64)
+    pos = torch.zeros(B, L, dtype=torch.int64)
+    neg = torch.zeros(B, L, dtype=torch.int64)
+    for b, n in enumerate(lengths):
+        hist[b, :n] = torch.randint(1, V + 1, (n,), generator=g)
+        pos[b, :n] = torch.randint(1, V + 1, (n,), generator=g)
+        neg[b, :n] = torch.randint(1, V + 1, (n,), generator=g)
+    if pad_some_pos and B > 1 and lengths[1] > 1:
+        pos[1, lengths[1] - 1] = 0  # a valid position whose positive is padding (models.py:413)
+    neg[0, 0] = pos[0, 0]  # an exact false negative
+    return {"history_item_idx": hist, "pos_item_idx": pos, "neg_item_idx": neg}, lengths
+
+
+def load_json(npz, key):
+    return json.loads(str(npz[key]))
+
+
+def flat_from_state(model, state):
+    model.load_encoder_state_dict({k: torch.as_tensor(v) for k, v in state.items()})

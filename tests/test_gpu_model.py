@@ -1,0 +1,322 @@
+"""GPU parity of the composed path (encoder, fused loss, training step) against the golden vectors produced
+by the reference (tests/golden, see oracle/make_golden.py) and against the CPU oracle on larger seeded
+inputs. Everything goes through the product API (xfmr_rec_amd) and therefore through libxfmr_hip.so."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL, assert_close, ragged_batch, rel_l2, unit_table
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def X():
+    import xfmr_rec_amd as x
+
+    return x
+
+
+def _model(X, *, H, A, I, nL, Lmax, prec, state=None, table=None):
+    cfg = X.ModelConfig(hidden_size=H, num_attention_heads=A, intermediate_size=I, num_hidden_layers=nL,
+                        max_seq_length=Lmax)
+    m = X.RecommenderModel(cfg, device=DEV, precision=prec)
+    if state is not None:
+        m.load_encoder_state_dict(state)
+    if table is not None:
+        m.set_table(table.to(DEV))
+    return m.eval()
+
+
+# ------------------------------------------------------------------------------------------ encoder (G2)
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_encoder_matches_hf_bert_golden(X, golden_dir, case, prec):
+    g2 = np.load(golden_dir / "g2_encoder.npz")
+    cfg = json.loads(str(g2[f"{case}/cfg"]))
+    pre = f"{case}/param/"
+    state = {k[len(pre):]: _t(g2[k]) for k in g2.files if k.startswith(pre)}
+    m = _model(X, H=cfg["H"], A=cfg["A"], I=cfg["I"], nL=cfg["nL"], Lmax=cfg["L"], prec=prec, state=state,
+               table=torch.zeros(2, cfg["H"]))
+    x = _t(g2[f"{case}/x"]).to(DEV)
+    mask = _t(g2[f"{case}/mask"]).bool()
+    out = m(item_embeds=x)
+    assert torch.equal(out["attention_mask"].cpu().bool(), mask)
+    tok = out["token_embeddings"]
+    assert_close("last_hidden_state", tok.cpu()[mask], _t(g2[f"{case}/eager/last_hidden_state"])[mask], prec)
+    from oracle import encoder as enc
+
+    assert_close("sentence_embedding", out["sentence_embedding"],
+                 enc.mean_pool(_t(g2[f"{case}/eager/last_hidden_state"]), mask), prec)
+    w = torch.linspace(0.5, 1.5, cfg["H"], device=DEV)
+    loss = ((tok * w) ** 2 * mask.to(DEV)[..., None]).sum()
+    loss.backward()
+    grads = m.grad_state_dict()
+    gp = f"{case}/eager/grad/"
+    worst = 0.0
+    for k in g2.files:
+        if k.startswith(gp):
+            name = k[len(gp):]
+            if name.endswith("key.bias"):  # exactly zero in exact arithmetic: pure rounding noise
+                assert grads[name].abs().max().item() < 1e-2
+                continue
+            worst = max(worst, assert_close(name, grads[name], _t(g2[k]), prec, "grad"))
+    assert worst > 0.0
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_encoder_config2_shape_vs_oracle(X, prec):
+    """One real-size layer stack (L=200, H=128, 4 heads, I=512) on ragged rows against the CPU oracle."""
+    from oracle import encoder as enc
+    from oracle import model as OM
+
+    B, L, H, A, I, nL, V = 3, 200, 128, 4, 512, 2, 300
+    table = unit_table(V, H)
+    batch, lengths = ragged_batch(B, L, V, lengths=[200, 131, 17], seed=2)
+    m = _model(X, H=H, A=A, I=I, nL=nL, Lmax=L, prec=prec, table=table)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.encoder_state_dict().items()}
+    ref = OM.forward(params, table, batch["history_item_idx"], num_heads=A, max_seq_length=L)
+    out = m(batch["history_item_idx"].to(DEV))
+    valid = ref["attention_mask"].bool()
+    assert torch.equal(out["attention_mask"].cpu().bool(), valid)
+    assert_close("tok", out["token_embeddings"].cpu()[valid], ref["token_embeddings"].detach()[valid], prec)
+    w = torch.linspace(-1, 1, H)
+    (ref["token_embeddings"] * w * valid[..., None]).sum().backward()
+    (out["token_embeddings"] * w.to(DEV) * valid.to(DEV)[..., None]).sum().backward()
+    got = m.grad_state_dict()
+    for k, p in params.items():
+        if k.endswith("key.bias"):
+            continue
+        assert_close(k, got[k], p.grad, prec, "grad")
+    assert enc.num_layers_of(params) == nL
+
+
+def test_truncation_to_max_seq_length(X):
+    """models.py:334-337: only the last max_seq_length items are encoded."""
+    H, V = 64, 40
+    table = unit_table(V, H)
+    m = _model(X, H=H, A=2, I=64, nL=1, Lmax=8, prec="fp32", table=table)
+    idx = torch.randint(1, V + 1, (2, 13), generator=torch.Generator().manual_seed(0))
+    a = m(idx.to(DEV))["token_embeddings"]
+    b = m(idx[:, -8:].to(DEV))["token_embeddings"]
+    assert a.shape == (2, 8, H) and torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ loss heads (G4)
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_loss_heads_match_reference_golden(X, golden_dir, prec):
+    from xfmr_rec_amd import losses as XL
+    from xfmr_rec_amd import ops
+
+    g4 = np.load(golden_dir / "g4_shared_negatives.npz")
+    table = _t(g4["table"]).to(DEV)
+    rnorm = ops.table_rnorm(table)
+    q0, pos, neg = _t(g4["q"]).to(DEV), _t(g4["pos"]).to(DEV), _t(g4["neg"]).to(DEV)
+    classes = {c.__name__: c for c in XL.LOSS_CLASSES}
+    for case in json.loads(str(g4["index"])):
+        cfg = XL.LossConfig(**case["cfg"])
+        q = q0.clone().requires_grad_(True)
+        cand = XL.SharedNegatives(table, rnorm, pos, neg)
+        assert tuple(cand.shape) == (q.shape[0], 1 + neg.numel(), q.shape[1])
+        loss = classes[case["kind"]](cfg, precision=prec)(q, cand)
+        loss.backward()
+        want = float(g4[f"{case['key']}/loss"])
+        # bf16 logits flip a few false-negative mask bits: 1e-2 relative (+ small abs floor)
+        tol = TOL[prec]["loss_rel"] * max(1.0, abs(want)) * (3 if prec == "bf16" else 1)
+        assert abs(loss.item() - want) <= tol, (case["key"], loss.item(), want)
+        e = rel_l2(q.grad, _t(g4[f"{case['key']}/dq"]))
+        assert e <= TOL[prec]["grad_l2"] * (3 if prec == "bf16" else 1), (case["key"], e)
+    for vi in range(5):
+        want = json.loads(str(g4[f"v{vi}/stats"]))
+        cfgd = [c["cfg"] for c in json.loads(str(g4["index"])) if c["key"].startswith(f"v{vi}/")][0]
+        got = XL.LogitsStatistics(XL.LossConfig(**cfgd), precision=prec)(q0, XL.SharedNegatives(table, rnorm, pos, neg))
+        assert got.keys() == want.keys()
+        for k, v in want.items():
+            assert got[k] == pytest.approx(v, rel=3e-2 if prec == "bf16" else 2e-4, abs=2e-2 if prec == "bf16" else 1e-5), k
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_full_catalogue_softmax_matches_reference_golden(X, golden_dir, prec):
+    """EmbedLoss.forward(q, table[None].expand, target=pos) == CE(Q E^T) (BASELINE config 4 mode)."""
+    from xfmr_rec_amd import losses as XL
+    from xfmr_rec_amd import ops
+
+    g4 = np.load(golden_dir / "g4_shared_negatives.npz")
+    table = _t(g4["table"]).to(DEV)
+    rnorm = ops.table_rnorm(table)
+    q0, pos = _t(g4["q"]).to(DEV), _t(g4["pos"]).to(DEV)
+    cfg = XL.LossConfig(target_position=None, mask_false_negatives=False)
+    for cls in XL.LOSS_CLASSES:
+        q = q0.clone().requires_grad_(True)
+        loss = cls(cfg, precision=prec)(q, XL.CatalogCandidates(table, rnorm, q.shape[0]), pos)
+        loss.backward()
+        want = float(g4[f"catalog/{cls.__name__}/loss"])
+        assert abs(loss.item() - want) <= TOL[prec]["loss_rel"] * max(1.0, abs(want)), (cls.__name__, loss.item(), want)
+        assert rel_l2(q.grad, _t(g4[f"catalog/{cls.__name__}/dq"])) <= TOL[prec]["grad_l2"], cls.__name__
+
+
+def test_loss_api_errors_mirror_reference(X):
+    from xfmr_rec_amd import losses as XL
+
+    table = unit_table(10, 64).to(DEV)
+    from xfmr_rec_amd import ops
+
+    rn = ops.table_rnorm(table)
+    cand = XL.SharedNegatives(table, rn, torch.ones(4, dtype=torch.int64, device=DEV), torch.ones(6, dtype=torch.int64, device=DEV))
+    fn = XL.InfoNCELoss(XL.LossConfig())
+    with pytest.raises(AssertionError):
+        fn(torch.zeros(4, 1, 64, device=DEV), cand)  # query must be 2-D (losses.py:166)
+    with pytest.raises(AssertionError):
+        fn(torch.zeros(5, 64, device=DEV), cand)  # batch mismatch (losses.py:172)
+    with pytest.raises(AssertionError):
+        fn(torch.zeros(4, 64, device=DEV), cand, torch.zeros(4, dtype=torch.int64, device=DEV))  # both target and position
+    with pytest.raises(NotImplementedError):
+        XL.InfoNCELoss(XL.LossConfig(num_hard_negatives=3))(torch.zeros(4, 64, device=DEV), cand)
+
+
+# ------------------------------------------------------------------------------------------ fused loss, positions form
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("T_shape,H,V", [((4, 50), 64, 60), ((5, 200), 128, 500), ((2, 96), 256, 100)])
+def test_fused_loss_positions_form_vs_oracle(X, prec, T_shape, H, V):
+    """All seven heads + statistics + d_tok from ONE launch sequence, on ragged positions, vs the oracle that
+    materialises the (Np, 1+N, H) candidates like models.py:408-416. Several tiles and splits are exercised."""
+    from oracle import losses as OL
+    from xfmr_rec_amd import _native as N
+    from xfmr_rec_amd import ops
+
+    B, L = T_shape
+    table = unit_table(V, H)
+    batch, lengths = ragged_batch(B, L, V, seed=3)
+    g = torch.Generator().manual_seed(9)
+    tok = torch.randn(B, L, H, generator=g) * 1.2
+    key_mask = (batch["history_item_idx"] != 0)
+    am = key_mask
+    pos_i = batch["pos_item_idx"][am]
+    keep = pos_i != 0
+    tdev, rn = table.to(DEV), None
+    rn = ops.table_rnorm(tdev)
+    for head in OL.LOSS_KINDS:
+        tq = tok.clone().requires_grad_(True)
+        q = tq[am][keep]
+        cand = torch.cat([table[pos_i[keep]][:, None], table[batch["neg_item_idx"][am]][None].expand(int(keep.sum()), -1, -1)], 1)
+        want = {k: OL.embed_loss(k, q, cand) for k in OL.LOSS_KINDS}
+        want[head].backward()
+        losses, stats, d_tok = ops.sampled_loss(
+            tok.to(DEV), key_mask.to(torch.uint8).to(DEV), batch["pos_item_idx"].to(DEV), batch["neg_item_idx"].to(DEV),
+            tdev, rn, train_head=head, all_heads=True, precision=prec,
+        )
+        s = stats.tolist()
+        assert int(s[N.STAT["n_valid"]]) == int(am.sum()) and int(s[N.STAT["n_query"]]) == int(keep.sum())
+        for i, k in enumerate(OL.LOSS_KINDS):
+            w = float(want[k])
+            lim = TOL[prec]["loss_rel"] * max(1.0, abs(w)) * (3 if prec == "bf16" else 1)
+            assert abs(losses[i].item() - w) <= lim, (head, k, losses[i].item(), w)
+        e = rel_l2(d_tok, tq.grad)
+        assert e <= TOL[prec]["grad_l2"] * (3 if prec == "bf16" else 1), (head, e)
+        # lean mode (only the train head) must give the same loss and the same gradient
+        l2, _s2, d2 = ops.sampled_loss(
+            tok.to(DEV), key_mask.to(torch.uint8).to(DEV), batch["pos_item_idx"].to(DEV), batch["neg_item_idx"].to(DEV),
+            tdev, rn, train_head=head, all_heads=False, precision=prec,
+        )
+        i = OL.LOSS_KINDS.index(head)
+        assert abs(l2[i].item() - losses[i].item()) <= 1e-5 * max(1.0, abs(losses[i].item()))
+        assert rel_l2(d2, d_tok) <= 1e-5
+    ref_stats = OL.logits_statistics(tok[am][keep], cand.detach())
+    got = X.losses.stats_to_dict(s)
+    for k, v in ref_stats.items():
+        assert got[k] == pytest.approx(v, rel=3e-2 if prec == "bf16" else 2e-4, abs=2e-2 if prec == "bf16" else 1e-5), k
+
+
+# ------------------------------------------------------------------------------------------ training step (G3)
+def _g3_module(X, golden_dir, prec, train_loss):
+    g3 = np.load(golden_dir / "g3_step.npz")
+    cfg = json.loads(str(g3["cfg"]))
+    conf = X.LightningConfig(hidden_size=cfg["H"], num_attention_heads=cfg["A"], intermediate_size=cfg["I"],
+                             num_hidden_layers=cfg["nL"], max_seq_length=cfg["L"], train_loss=train_loss,
+                             precision=prec)
+    mod = X.RecommenderLightningModule(conf)
+    mod.configure_model()
+    mod.model.load_encoder_state_dict({k[len("param0/"):]: _t(g3[k]) for k in g3.files if k.startswith("param0/")})
+    mod.model.set_table(_t(g3["table"]).to(DEV))
+    batch = {"history_item_idx": _t(g3["hist"]), "pos_item_idx": _t(g3["pos"]), "neg_item_idx": _t(g3["neg"])}
+    return g3, mod.to(DEV), batch
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_compute_losses_matches_reference_golden(X, golden_dir, prec):
+    g3, mod, batch = _g3_module(X, golden_dir, prec, "InfoNCELoss")
+    mod.eval()
+    out = mod.compute_losses(batch)
+    for cls in X.LOSS_CLASSES:
+        k = f"loss/{cls.__name__}"
+        want = float(g3[k])
+        lim = TOL[prec]["loss_rel"] * max(1.0, abs(want)) * (3 if prec == "bf16" else 1)
+        assert abs(float(out[k]) - want) <= lim, (k, float(out[k]), want)
+        assert float(out[k + "Mean"]) == pytest.approx(float(out[k]) / (out["batch/positive_non_zero"] + 1e-9), rel=1e-5)
+    assert out["batch/attention_non_zero"] == int(g3["attention_mask"].sum())
+    assert out["batch/positive_non_zero"] == int(g3["positive_mask"].sum())
+    for k, v in json.loads(str(g3["stats"])).items():
+        assert out[k] == pytest.approx(v, rel=3e-2 if prec == "bf16" else 2e-4, abs=2e-2 if prec == "bf16" else 1e-5), k
+    # the drop-in compute_embeds: same valid/positive masks and query rows as the reference
+    e = mod.model.compute_embeds(batch["history_item_idx"], batch["pos_item_idx"], batch["neg_item_idx"])
+    assert torch.equal(e["attention_mask"].cpu(), _t(g3["attention_mask"]))
+    assert torch.equal(e["positive_mask"].cpu(), _t(g3["positive_mask"]))
+    assert_close("query_embed", e["query_embed"], _t(g3["query_embed"]), prec)
+
+
+@pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"])
+def test_three_adamw_steps_match_reference_golden(X, golden_dir, train_loss):
+    """zero_grad -> training_step -> backward -> AdamW, three times, fp32 MFMA path, dropout off (eval):
+    gradients after step 1 and parameters after step 3 against the reference's own run."""
+    g3, mod, batch = _g3_module(X, golden_dir, "fp32", train_loss)
+    mod.eval()
+    opt = mod.configure_optimizers()
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss = mod.training_step(batch)
+        assert float(loss) == pytest.approx(float(g3[f"{train_loss}/loss_step{step}"]), rel=2e-4)
+        loss.backward()
+        if step == 0 and f"{train_loss}/grad0/embeddings.LayerNorm.weight" in g3.files:
+            for k, v in mod.model.grad_state_dict().items():
+                if not k.endswith("key.bias"):
+                    assert_close(k, v, _t(g3[f"{train_loss}/grad0/{k}"]), "fp32", "grad")
+        opt.step()
+    for k, v in mod.model.encoder_state_dict().items():
+        atol = 3.5e-3 if k.endswith("key.bias") else 3e-5
+        torch.testing.assert_close(v.cpu(), _t(g3[f"{train_loss}/param_after3/{k}"]), rtol=2e-4, atol=atol, msg=k)
+    sd = mod.state_dict()
+    assert "model.embeddings.weight" not in sd and any(k.startswith("model.model.0.auto_model.") for k in sd)
+
+
+def test_training_mode_dropout_and_trainer_loop(X, golden_dir):
+    """Training mode (dropout 0.1 as TF:configuration_bert.py): loss differs from eval, is finite, decreases."""
+    g3, mod, batch = _g3_module(X, golden_dir, "bf16", "InfoNCELoss")
+    tr = X.Trainer(mod)
+    losses = tr.fit([batch] * 12)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    mod.eval()
+    e1 = float(mod.compute_losses(batch)["loss/InfoNCELoss"])
+    e2 = float(mod.compute_losses(batch)["loss/InfoNCELoss"])
+    assert e1 == e2  # eval is deterministic
+    mod.train()
+    t1 = float(mod.compute_losses(batch)["loss/InfoNCELoss"])
+    assert t1 != e1
+
+
+def test_save_load_roundtrip(X, golden_dir, tmp_path):
+    g3, mod, batch = _g3_module(X, golden_dir, "fp32", "InfoNCELoss")
+    mod.eval()
+    mod.save(tmp_path / "m")
+    m2 = X.RecommenderModel.load(str(tmp_path / "m"), device=DEV, precision="fp32").eval()
+    m2.set_table(mod.model.embeddings)
+    a = mod.model(batch["history_item_idx"].to(DEV))["sentence_embedding"]
+    b = m2(batch["history_item_idx"].to(DEV))["sentence_embedding"]
+    assert torch.equal(a, b)

@@ -1,0 +1,240 @@
+"""GPU parity of the individual HIP kernels, called through the C ABI (ctypes), against plain fp32/fp64
+PyTorch on the CPU. Sizes are small enough for the CPU side to take seconds; they cover ragged / partial
+tiles (M, N, K not multiples of the tile), both MFMA precisions, and the encoder's real shapes."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from xfmr_rec_amd import ops as _ops
+
+    return _ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_mfma_lane_maps(ops):
+    out = ops.selftest_mfma(DEV)
+    assert out[:3] == [0, 0, 0], f"MFMA fragment/accumulator maps wrong: total/bf16/f32 mismatches = {out[:3]}"
+
+
+@pytest.mark.parametrize("H", [32, 64, 128, 256, 320])
+def test_layernorm_fwd_bwd(ops, H):
+    rows = 77
+    x, gamma, beta, dy = _rand(rows, H, seed=1), 1 + 0.1 * _rand(H, seed=2), 0.1 * _rand(H, seed=3), _rand(rows, H, seed=4)
+    xr = x.clone().double().requires_grad_(True)
+    gr, br = gamma.clone().double().requires_grad_(True), beta.clone().double().requires_grad_(True)
+    yr = F.layer_norm(xr, (H,), gr, br, 1e-12)
+    yr.backward(dy.double())
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV))
+    assert_close("ln.y", y, yr, "fp32")
+    assert_close("ln.mean", mean, xr.mean(-1), "fp32")
+    dx, d_lin, dg, db, dbias = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV))
+    assert d_lin is None
+    assert_close("ln.dx", dx, xr.grad, "fp32", "grad")
+    assert_close("ln.dgamma", dg, gr.grad, "fp32", "grad")
+    assert_close("ln.dbeta", db, br.grad, "fp32", "grad")
+    assert_close("ln.dbias", dbias, xr.grad.sum(0), "fp32", "grad")
+
+
+def test_layernorm_bwd_dropout_consistency(ops):
+    """d_lin = dx * keep/(1-p) with the same mask the forward GEMM epilogue applied (same seed/site)."""
+    from xfmr_rec_amd import _native as N
+
+    M, H, p = 200, 128, 0.25
+    x, w, b = _rand(M, H, seed=1).to(DEV), _rand(H, H, seed=2, scale=0.1).to(DEV), _rand(H, seed=3).to(DEV)
+    res = torch.zeros(M, H, device=DEV)
+    y0 = ops.linear_fwd(x, w, b, epilogue=N.EPI_BIAS_DROP_RES, residual=res, dropout_p=0.0, precision="fp32")
+    y1 = ops.linear_fwd(x, w, b, epilogue=N.EPI_BIAS_DROP_RES, residual=res, dropout_p=p, seed=7, site=3, precision="fp32")
+    keep = (y1 != 0)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.02, frac
+    torch.testing.assert_close(y1[keep], (y0 / (1 - p))[keep], rtol=1e-5, atol=1e-6)
+    y2 = ops.linear_fwd(x, w, b, epilogue=N.EPI_BIAS_DROP_RES, residual=res, dropout_p=p, seed=7, site=3, precision="fp32")
+    assert torch.equal(y1, y2)  # same seed/site -> same mask
+    y3 = ops.linear_fwd(x, w, b, epilogue=N.EPI_BIAS_DROP_RES, residual=res, dropout_p=p, seed=8, site=3, precision="fp32")
+    assert not torch.equal(y1, y3)
+    gamma = torch.ones(H, device=DEV)
+    _, mean, rstd = ops.layernorm_fwd(y1, gamma, torch.zeros(H, device=DEV))
+    dy = _rand(M, H, seed=5).to(DEV)
+    dx, d_lin, *_ = ops.layernorm_bwd(dy, y1, mean, rstd, gamma, dropout_p=p, seed=7, site=3)
+    torch.testing.assert_close(d_lin, dx * keep / (1 - p), rtol=1e-5, atol=1e-7)
+
+
+SHAPES = [(100, 96, 32), (300, 128, 128), (513, 384, 128), (257, 128, 512), (64, 64, 64), (1000, 512, 128)]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_forward_epilogues(ops, prec, M, N, K):
+    from xfmr_rec_amd import _native as Nn
+
+    x, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K**-0.5), _rand(N, seed=3), _rand(M, N, seed=4)
+    ref = x.double() @ w.double().T + b.double()
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), precision=prec)
+    assert_close("linear.bias", y, ref, prec)
+    y, pre = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=Nn.EPI_BIAS_GELU, precision=prec)
+    assert_close("linear.gelu.pre", pre, ref, prec)
+    assert_close("linear.gelu", y, F.gelu(ref), prec)
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=Nn.EPI_BIAS_DROP_RES, residual=r.to(DEV), precision=prec)
+    assert_close("linear.residual", y, ref + r.double(), prec)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_backward(ops, prec, M, N, K):
+    dy, w, x = _rand(M, N, seed=1), _rand(N, K, seed=2, scale=N**-0.5), _rand(M, K, seed=3)
+    rg, pre = _rand(M, K, seed=4), _rand(M, K, seed=5)
+    ref_dx = dy.double() @ w.double()
+    dx = ops.linear_bwd_dx(dy.to(DEV), w.to(DEV), precision=prec)
+    assert_close("dx", dx, ref_dx, prec, "grad")
+    dx = ops.linear_bwd_dx(dy.to(DEV), w.to(DEV), residual_grad=rg.to(DEV), precision=prec)
+    assert_close("dx+res", dx, ref_dx + rg.double(), prec, "grad")
+    pr = pre.clone().double().requires_grad_(True)
+    F.gelu(pr).backward(ref_dx)
+    dx = ops.linear_bwd_dx(dy.to(DEV), w.to(DEV), gelu_pre=pre.to(DEV), precision=prec)
+    assert_close("dx*gelu'", dx, pr.grad, prec, "grad")
+    dw = ops.linear_bwd_dw(dy.to(DEV), x.to(DEV), precision=prec)
+    assert_close("dw", dw, dy.double().T @ x.double(), prec, "grad")
+    assert_close("colsum", ops.colsum(dy.to(DEV)), dy.double().sum(0), "fp32", "grad")
+
+
+def test_linear_bwd_dw_is_deterministic(ops):
+    dy, x = _rand(5000, 128, seed=1).to(DEV), _rand(5000, 128, seed=2).to(DEV)
+    a = ops.linear_bwd_dw(dy, x, precision="bf16")
+    b = ops.linear_bwd_dw(dy, x, precision="bf16")
+    assert torch.equal(a, b)  # split-K slabs are reduced in a fixed order (no float atomics)
+
+
+def test_embed_gather_layernorm_and_param_grads(ops):
+    B, L, H, V, Lmax = 3, 10, 64, 20, 12
+    table = _rand(V + 1, H, seed=1)
+    table[0] = 0
+    table[7] = 0  # a non-padding id whose embedding is all zero: the mask follows the VALUES (models.py:343)
+    idx = torch.randint(0, V + 1, (B, L), generator=torch.Generator().manual_seed(2))
+    idx[0, 3] = 7
+    pos, typ = _rand(Lmax, H, seed=3, scale=0.02), _rand(2, H, seed=4, scale=0.02)
+    gamma, beta = 1 + 0.1 * _rand(H, seed=5), 0.1 * _rand(H, seed=6)
+    out, pre, mean, rstd, mask = ops.embed_ln_fwd(idx.to(DEV), table.to(DEV), pos.to(DEV), typ.to(DEV), gamma.to(DEV), beta.to(DEV))
+    e = F.embedding(idx, table)
+    ref_pre = e + typ[0] + pos[:L]
+    assert torch.equal(mask.cpu().bool(), (e != 0).any(-1))
+    assert not mask[0, 3]
+    torch.testing.assert_close(pre.cpu(), ref_pre, rtol=0, atol=0)
+    assert_close("embed.ln", out, F.layer_norm(ref_pre.double(), (H,), gamma.double(), beta.double(), 1e-12), "fp32")
+    d_pre = _rand(B, L, H, seed=7)
+    d_pos, d_type = ops.embed_param_grads(d_pre.to(DEV), Lmax)
+    ref_pos = torch.zeros(Lmax, H, dtype=torch.float64)
+    ref_pos[:L] = d_pre.double().sum(0)
+    assert_close("d_pos", d_pos, ref_pos, "fp32", "grad")
+    assert_close("d_type0", d_type[0], d_pre.double().sum((0, 1)), "fp32", "grad")
+    assert torch.count_nonzero(d_type[1]) == 0
+
+
+def _attention_reference(qkv, key_mask, A):
+    """fp64 restatement of eager attention (TF:modeling_bert.py:111-136) with the causal+padding mask."""
+    B, L, H3 = qkv.shape
+    H = H3 // 3
+    dh = H // A
+    q, k, v = (t.view(B, L, A, dh).transpose(1, 2) for t in qkv.split(H, dim=-1))
+    scores = q @ k.transpose(2, 3) * dh**-0.5
+    allowed = torch.ones(L, L, dtype=torch.bool).tril()[None] & key_mask.bool()[:, None, :]
+    scores = scores.masked_fill(~allowed[:, None], float("-inf"))
+    probs = torch.softmax(scores, dim=-1)
+    probs = torch.nan_to_num(probs, nan=0.0)  # rows without any visible key -> zeros (documented)
+    return (probs @ v).transpose(1, 2).reshape(B, L, H)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,L,A,lengths", [(3, 12, 1, [12, 7, 1]), (2, 40, 2, [33, 40]), (2, 130, 2, [130, 77]),
+                                           (2, 200, 4, [200, 150]), (1, 256, 1, [250])])
+def test_attention_fwd_bwd(ops, prec, B, L, A, lengths):
+    H = 32 * A
+    qkv = _rand(B, L, 3 * H, seed=3)
+    mask = torch.zeros(B, L, dtype=torch.uint8)
+    for b, n in enumerate(lengths):
+        mask[b, :n] = 1
+    if B > 1:
+        mask[1, 2] = 0  # a hole in the middle: the kernels take an arbitrary key mask
+    w = _rand(B, L, H, seed=4) * mask[..., None]  # the training path only back-propagates valid rows
+    ref_in = qkv.clone().double().requires_grad_(True)
+    ref = _attention_reference(ref_in, mask, A)
+    (ref * w.double()).sum().backward()
+    ctx, lse = ops.attn_fwd(qkv.to(DEV), mask.to(DEV), A, precision=prec)
+    valid = mask.bool()
+    assert_close("attn.ctx", ctx.cpu()[valid], ref.detach()[valid], prec)
+    d_qkv = ops.attn_bwd(qkv.to(DEV), mask.to(DEV), ctx, lse, w.to(DEV), A, precision=prec)
+    assert_close("attn.d_qkv", d_qkv, ref_in.grad, prec, "grad")
+
+
+def test_attention_causality_and_padding_invariance(ops):
+    """Changing a later key/value or a masked key never changes an earlier / any output."""
+    B, L, A = 1, 96, 2
+    H = 32 * A
+    qkv = _rand(B, L, 3 * H, seed=1).to(DEV)
+    mask = torch.ones(B, L, dtype=torch.uint8, device=DEV)
+    mask[0, 50] = 0
+    base, _ = ops.attn_fwd(qkv, mask, A, precision="fp32")
+    q2 = qkv.clone()
+    q2[0, 70:, H:] += 1.0  # keys and values of positions >= 70
+    out2, _ = ops.attn_fwd(q2, mask, A, precision="fp32")
+    assert torch.equal(base[0, :70], out2[0, :70])
+    q3 = qkv.clone()
+    q3[0, 50, H:] += 5.0  # the masked key
+    out3, _ = ops.attn_fwd(q3, mask, A, precision="fp32")
+    keep = torch.ones(L, dtype=torch.bool, device=DEV)
+    assert torch.equal(base[0, keep], out3[0, keep])
+
+
+def test_attention_dropout_forward_backward_agree(ops):
+    """With dropout on, backward must differentiate the SAME masked forward: check by finite differences."""
+    B, L, A = 1, 40, 1
+    H = 32
+    qkv = _rand(B, L, 3 * H, seed=1).to(DEV)
+    mask = torch.ones(B, L, dtype=torch.uint8, device=DEV)
+    w = _rand(B, L, H, seed=2).to(DEV)
+    kw = dict(dropout_p=0.3, seed=11, site=5, precision="fp32")
+    ctx, lse = ops.attn_fwd(qkv, mask, A, **kw)
+    d = ops.attn_bwd(qkv, mask, ctx, lse, w, A, **kw)
+    direction = _rand(B, L, 3 * H, seed=3).to(DEV)
+    eps = 1e-2
+    fp = (ops.attn_fwd(qkv + eps * direction, mask, A, **kw)[0] * w).sum().item()
+    fm = (ops.attn_fwd(qkv - eps * direction, mask, A, **kw)[0] * w).sum().item()
+    fd = (fp - fm) / (2 * eps)
+    an = (d * direction).sum().item()
+    assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (fd, an)
+    ctx0, _ = ops.attn_fwd(qkv, mask, A, precision="fp32")
+    assert not torch.allclose(ctx, ctx0)  # dropout really changed the output
+
+
+def test_adamw_matches_torch(ops):
+    n = 10007
+    p, g = _rand(n, seed=1), _rand(n, seed=2)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01)
+    pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gs = g * step
+        ref.grad = gs.clone()
+        opt.step()
+        ops.adamw_(pd, gs.to(DEV), m, v, lr=1e-3, weight_decay=0.01, step=step)
+    torch.testing.assert_close(pd.cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_errors_are_loud(ops):
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        ops.layernorm_fwd(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+    qkv = torch.zeros(1, 8, 3 * 48, device=DEV)
+    with pytest.raises(RuntimeError, match="not supported"):
+        ops.attn_fwd(qkv, torch.ones(1, 8, dtype=torch.uint8, device=DEV), 1)  # head size 48

@@ -1,0 +1,390 @@
+// Causal self-attention with key-padding mask, head size 32, flash-style (scores never reach HBM).
+//
+// Layout trick used by all three kernels (forward, dQ, dK/dV): every score tile is produced with the
+// softmax-reduction axis in the accumulator REGISTERS and the other axis on the LANE
+// (forward/dQ: S^T = K Q^T, key in registers, query on the lane; dK/dV: S = Q K^T, query in registers,
+// key on the lane). Row statistics are then lane-local, and the probability tile feeds the next MFMA as
+// its B operand straight from the accumulator registers (no LDS round trip, no lane shuffles):
+//   O^T  += V^T  P^T      dQ^T += K^T dS^T      dV^T += dO^T (P.D)      dK^T += Q^T dS
+// One workgroup = 4 waves = 128 consecutive rows (queries, or keys for dK/dV) of one (batch, head);
+// the whole K/V (or Q/dO) panel of that head that the causal mask can reach is staged once into LDS
+// (L <= 512 keeps it under 160 KiB), so there is a single barrier per kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 32;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct AttnArgs {
+  const float* qkv; const uint8_t* key_mask; float* ctx; float* lse;
+  const float* d_ctx; float* d_qkv;
+  int B, L, A, H;
+  XfDropout drop;
+};
+
+// img[r][0..32) = src[(row0 + r) * stride + 0..32) for r in [0, nrows); rows >= row_end read as zero.
+template <class P>
+__device__ __forceinline__ void stage_rows(typename P::elem* img, int ld, const float* src, int64_t stride, int row0,
+                                           int nrows, int row_end) {
+  for (int c = threadIdx.x; c < nrows * 8; c += blockDim.x) {
+    const int r = c >> 3, dd = (c & 7) * 4;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * stride + dd);
+    xf_store4<P>(img + r * ld + dd, v);
+  }
+}
+// imgT[d][r] = src[(row0 + r) * stride + d]
+template <class P>
+__device__ __forceinline__ void stage_rows_T(typename P::elem* imgT, int ldT, const float* src, int64_t stride,
+                                             int row0, int nrows, int row_end) {
+  for (int c = threadIdx.x; c < (nrows / 2) * 8; c += blockDim.x) {
+    const int rp = c >> 3, dd = (c & 7) * 4;
+    float4 v0 = make_float4(0, 0, 0, 0), v1 = v0;
+    const int r = 2 * rp;
+    if (row0 + r < row_end) v0 = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * stride + dd);
+    if (row0 + r + 1 < row_end) v1 = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r + 1) * stride + dd);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf_store2<P>(imgT + (dd + j) * ldT + r, xf_get(v0, j), xf_get(v1, j));
+  }
+}
+
+template <class P>
+struct AttnSmem {
+  using elem = typename P::elem;
+  static constexpr int LDR = xf_ld<P>(DH);  // row images [row][DH]
+  // transposed images [DH][rows]: rows + 4 keeps 8-byte row alignment and makes the b64 fragment reads
+  // of 32 consecutive image rows hit 32 distinct even bank pairs (conflict-free)
+  __host__ __device__ static int ldt(int rows) { return rows + 4; }
+  __host__ __device__ static size_t row_img(int rows) { return (size_t)rows * LDR * sizeof(elem); }
+  __host__ __device__ static size_t t_img(int rows) { return (size_t)DH * ldt(rows) * sizeof(elem); }
+  __host__ __device__ static size_t align(size_t x) { return (x + 15) & ~(size_t)15; }
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <class P>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  using elem = typename P::elem;
+  using SM = AttnSmem<P>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
+  const int qblk0 = blockIdx.x * 128;
+  const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);  // keys the causal mask can reach, padded to 32
+  elem* sK = reinterpret_cast<elem*>(smem_raw);
+  elem* sVT = reinterpret_cast<elem*>(smem_raw + SM::align(SM::row_img(nkeys)));
+  const int ldt = SM::ldt(nkeys);
+  float* scratch = reinterpret_cast<float*>(smem_raw + SM::align(SM::row_img(nkeys)) + SM::align(SM::t_img(nkeys)));
+  uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
+
+  const int64_t tok0 = (int64_t)b * L;
+  const float* kbase = a.qkv + tok0 * 3 * H + H + h * DH;
+  const float* vbase = a.qkv + tok0 * 3 * H + 2 * H + h * DH;
+  stage_rows<P>(sK, SM::LDR, kbase, 3 * H, 0, nkeys, L);
+  stage_rows_T<P>(sVT, ldt, vbase, 3 * H, 0, nkeys, L);
+  for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
+  __syncthreads();
+
+  const int lane = xf_lane(), wid = threadIdx.x >> 6;
+  const int q0 = qblk0 + wid * 32;
+  if (q0 >= L) return;
+  const int q = q0 + (lane & 31);
+  RegRows<P, DH> qreg;
+  qreg.load(a.qkv + (tok0 + q) * 3 * H + h * DH, q < L);
+
+  const float sc = 0.17677669529663687f * kLog2e;  // 1/sqrt(32) in base-2 exponent units
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
+
+  const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
+  for (int kb = 0; kb <= kb_end; ++kb) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    P::tile_nreg(s, sK, SM::LDR, kb * 32, qreg.regs(), DH);
+    float bmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + xf_acc_row(r, lane);
+      const bool vis = (key <= q) && sMask[key];
+      s[r] = vis ? s[r] * sc : -INFINITY;
+      bmax = fmaxf(bmax, s[r]);
+    }
+    bmax = fmaxf(bmax, xf_half_swap(bmax));
+    const float mnew = fmaxf(m, bmax);
+    if (__all(mnew == -INFINITY)) continue;  // nothing visible yet for any query of this wave
+    const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+    const float alpha = exp2f(m - msafe);  // m = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = exp2f(s[r] - msafe);  // masked: exp2(-inf) = 0
+      psum += p;
+      s[r] = a.drop.on ? p * xf_keep_scale(a.drop, ebase + (uint32_t)(kb * 32 + xf_acc_row(r, lane))) : p;
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    m = mnew;
+    P::tile_xb(o, sVT, ldt, 0, kb * 32, s);
+  }
+  const float ltot = lsum + xf_half_swap(lsum);
+  const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+  xf_store_tile_T(scratch + wid * 32 * 33, o, inv, a.ctx + tok0 * H + h * DH, H, q0, L);
+  if (lane < 32 && q < L)
+    a.lse[((int64_t)blockIdx.y) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <class P>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  using elem = typename P::elem;
+  using SM = AttnSmem<P>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
+  const int qblk0 = blockIdx.x * 128;
+  const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
+  elem* sK = reinterpret_cast<elem*>(smem_raw);
+  elem* sV = reinterpret_cast<elem*>(smem_raw + SM::align(SM::row_img(nkeys)));
+  elem* sKT = reinterpret_cast<elem*>(smem_raw + 2 * SM::align(SM::row_img(nkeys)));
+  const int ldt = SM::ldt(nkeys);
+  float* scratch = reinterpret_cast<float*>(smem_raw + 2 * SM::align(SM::row_img(nkeys)) + SM::align(SM::t_img(nkeys)));
+  uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
+
+  const int64_t tok0 = (int64_t)b * L;
+  const float* kbase = a.qkv + tok0 * 3 * H + H + h * DH;
+  const float* vbase = a.qkv + tok0 * 3 * H + 2 * H + h * DH;
+  stage_rows<P>(sK, SM::LDR, kbase, 3 * H, 0, nkeys, L);
+  stage_rows<P>(sV, SM::LDR, vbase, 3 * H, 0, nkeys, L);
+  stage_rows_T<P>(sKT, ldt, kbase, 3 * H, 0, nkeys, L);
+  for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
+  __syncthreads();
+
+  const int lane = xf_lane(), wid = threadIdx.x >> 6;
+  const int q0 = qblk0 + wid * 32;
+  if (q0 >= L) return;
+  const int q = q0 + (lane & 31);
+  const bool qv = q < L;
+  RegRows<P, DH> qreg, doreg;
+  qreg.load(a.qkv + (tok0 + q) * 3 * H + h * DH, qv);
+  doreg.load(a.d_ctx + (tok0 + q) * H + h * DH, qv);
+  // delta = rowsum(dO * O) in fp32 from the unrounded tensors; each lane half covers 16 of the 32 dims
+  float delta = 0.f;
+  if (qv) {
+    const float* po = a.ctx + (tok0 + q) * H + h * DH + 16 * (lane >> 5);
+    const float* pd = a.d_ctx + (tok0 + q) * H + h * DH + 16 * (lane >> 5);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 x = *reinterpret_cast<const float4*>(po + 4 * u);
+      const float4 y = *reinterpret_cast<const float4*>(pd + 4 * u);
+      delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+  }
+  delta += xf_half_swap(delta);
+  const float lse2 = qv ? a.lse[(int64_t)blockIdx.y * L + q] * kLog2e : INFINITY;
+  const float sc = 0.17677669529663687f * kLog2e;
+  const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
+
+  f32x16 dq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
+  for (int kb = 0; kb <= kb_end; ++kb) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    P::tile_nreg(s, sK, SM::LDR, kb * 32, qreg.regs(), DH);
+    P::tile_nreg(dp, sV, SM::LDR, kb * 32, doreg.regs(), DH);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + xf_acc_row(r, lane);
+      const bool vis = (key <= q) && sMask[key];
+      const float p = vis ? exp2f(s[r] * sc - lse2) : 0.f;
+      float dpv = dp[r];
+      if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)key);
+      s[r] = p * (dpv - delta);
+    }
+    P::tile_xb(dq, sKT, ldt, 0, kb * 32, s);
+  }
+  xf_store_tile_T(scratch + wid * 32 * 33, dq, 0.17677669529663687f, a.d_qkv + tok0 * 3 * H + h * DH, 3 * H, q0, L);
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <class P>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+  using elem = typename P::elem;
+  using SM = AttnSmem<P>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
+  const int kblk0 = blockIdx.x * 128;          // first key of this workgroup == first query it needs
+  const int Lp = ((L + 31) / 32) * 32;
+  const int nq = Lp - kblk0;                    // queries [kblk0, Lp) staged, image row = q - kblk0
+  elem* sQ = reinterpret_cast<elem*>(smem_raw);
+  elem* sDO = reinterpret_cast<elem*>(smem_raw + SM::align(SM::row_img(nq)));
+  elem* sQT = reinterpret_cast<elem*>(smem_raw + 2 * SM::align(SM::row_img(nq)));
+  elem* sDOT = reinterpret_cast<elem*>(smem_raw + 2 * SM::align(SM::row_img(nq)) + SM::align(SM::t_img(nq)));
+  const int ldt = SM::ldt(nq);
+  float* scratch = reinterpret_cast<float*>(smem_raw + 2 * SM::align(SM::row_img(nq)) + 2 * SM::align(SM::t_img(nq)));
+  float* sLse = scratch + 4 * 32 * 33;  // [nq] log2-scaled lse
+  float* sDelta = sLse + nq;            // [nq]
+
+  const int64_t tok0 = (int64_t)b * L;
+  const float* qbase = a.qkv + tok0 * 3 * H + h * DH;
+  const float* dobase = a.d_ctx + tok0 * H + h * DH;
+  const float* obase = a.ctx + tok0 * H + h * DH;
+  stage_rows<P>(sQ, SM::LDR, qbase, 3 * H, kblk0, nq, L);
+  stage_rows<P>(sDO, SM::LDR, dobase, H, kblk0, nq, L);
+  stage_rows_T<P>(sQT, ldt, qbase, 3 * H, kblk0, nq, L);
+  stage_rows_T<P>(sDOT, ldt, dobase, H, kblk0, nq, L);
+  for (int c = threadIdx.x; c < nq * 8; c += blockDim.x) {  // delta: 8 consecutive lanes share a row
+    const int r = c >> 3, dd = (c & 7) * 4;
+    float part = 0.f;
+    if (kblk0 + r < L) {
+      const float4 x = *reinterpret_cast<const float4*>(obase + (int64_t)(kblk0 + r) * H + dd);
+      const float4 y = *reinterpret_cast<const float4*>(dobase + (int64_t)(kblk0 + r) * H + dd);
+      part = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if ((c & 7) == 0) {
+      sDelta[r] = part;
+      sLse[r] = (kblk0 + r < L) ? a.lse[(int64_t)blockIdx.y * L + kblk0 + r] * kLog2e : INFINITY;
+    }
+  }
+  __syncthreads();
+
+  const int lane = xf_lane(), wid = threadIdx.x >> 6;
+  const int k0 = kblk0 + wid * 32;
+  if (k0 >= L) return;
+  const int key = k0 + (lane & 31);
+  const bool kvis = key < L && a.key_mask[tok0 + (key < L ? key : 0)];
+  RegRows<P, DH> kreg, vreg;
+  kreg.load(a.qkv + (tok0 + key) * 3 * H + H + h * DH, key < L);
+  vreg.load(a.qkv + (tok0 + key) * 3 * H + 2 * H + h * DH, key < L);
+  const float sc = 0.17677669529663687f * kLog2e;
+
+  f32x16 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+  for (int qb = k0 / 32; qb < Lp / 32; ++qb) {
+    const int row0 = qb * 32 - kblk0;
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    P::tile_nreg(s, sQ, SM::LDR, row0, kreg.regs(), DH);
+    P::tile_nreg(dp, sDO, SM::LDR, row0, vreg.regs(), DH);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = row0 + xf_acc_row(r, lane);
+      const int q = qi + kblk0;
+      const bool vis = kvis && (key <= q);
+      const float p = vis ? exp2f(s[r] * sc - sLse[qi]) : 0.f;  // q >= L: lse = +inf -> 0
+      float keep = 1.f;
+      if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blockIdx.y * L + q) * L) + (uint32_t)key);
+      s[r] = p * (dp[r] * keep - sDelta[qi]);  // dS
+      dp[r] = p * keep;                        // P.D
+    }
+    P::tile_xb(dv, sDOT, ldt, 0, row0, dp);
+    P::tile_xb(dk, sQT, ldt, 0, row0, s);
+  }
+  float* sc_w = scratch + wid * 32 * 33;
+  xf_store_tile_T(sc_w, dk, 0.17677669529663687f, a.d_qkv + tok0 * 3 * H + H + h * DH, 3 * H, k0, L);
+  xf_store_tile_T(sc_w, dv, 1.f, a.d_qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, k0, L);
+}
+
+template <class P>
+size_t fwd_smem(int L) {
+  using SM = AttnSmem<P>;
+  const int Lp = ((L + 31) / 32) * 32;
+  return SM::align(SM::row_img(Lp)) + SM::align(SM::t_img(Lp)) + 4 * 32 * 33 * sizeof(float) + Lp;
+}
+template <class P>
+size_t dq_smem(int L) {
+  using SM = AttnSmem<P>;
+  const int Lp = ((L + 31) / 32) * 32;
+  return 2 * SM::align(SM::row_img(Lp)) + SM::align(SM::t_img(Lp)) + 4 * 32 * 33 * sizeof(float) + Lp;
+}
+template <class P>
+size_t dkv_smem(int L) {
+  using SM = AttnSmem<P>;
+  const int Lp = ((L + 31) / 32) * 32;
+  return 2 * SM::align(SM::row_img(Lp)) + 2 * SM::align(SM::t_img(Lp)) + 4 * 32 * 33 * sizeof(float) +
+         2 * (size_t)Lp * sizeof(float);
+}
+constexpr size_t kLdsLimit = 160 * 1024;
+
+template <class P>
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+  const size_t sm = fwd_smem<P>(a.L);
+  if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)attn_fwd_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
+      hipSuccess)
+    return XFMR_EHIP;
+  hipLaunchKernelGGL((attn_fwd_kernel<P>), dim3((a.L + 127) / 128, a.B * a.A), dim3(256), sm, st, a);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+template <class P>
+int launch_bwd(const AttnArgs& a, hipStream_t st) {
+  const size_t s1 = dq_smem<P>(a.L), s2 = dkv_smem<P>(a.L);
+  if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s1) !=
+          hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2) !=
+          hipSuccess)
+    return XFMR_EHIP;
+  dim3 grid((a.L + 127) / 128, a.B * a.A);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<P>), grid, dim3(256), s1, st, a);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<P>), grid, dim3(256), s2, st, a);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int check_shape(int B, int L, int A, int H) {
+  if (B <= 0 || L <= 0 || A <= 0 || H <= 0) return XFMR_EINVAL;
+  if (H != A * DH) return XFMR_EUNSUPPORTED;  // head size must be 32
+  return XFMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xfmr_attn_fwd(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,
+                  int32_t A, int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision,
+                  void* stream) {
+  if (!qkv || !key_mask || !ctx || !lse) return XFMR_EINVAL;
+  if (int rc = check_shape(B, L, A, H)) return rc;
+  if (!xf_aligned16(qkv) || !xf_aligned16(ctx)) return XFMR_EALIGN;
+  AttnArgs a{};
+  a.qkv = qkv; a.key_mask = key_mask; a.ctx = ctx; a.lse = lse; a.B = B; a.L = L; a.A = A; a.H = H;
+  a.drop = xf_make_dropout(dropout_p, seed, site);
+  if (precision == XFMR_PREC_BF16) return launch_fwd<PrecBF16>(a, (hipStream_t)stream);
+  if (precision == XFMR_PREC_F32) return launch_fwd<PrecF32>(a, (hipStream_t)stream);
+  return XFMR_EINVAL;
+}
+
+int xfmr_attn_bwd(const float* qkv, const uint8_t* key_mask, const float* ctx, const float* lse,
+                  const float* d_ctx, float* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p,
+                  uint64_t seed, uint32_t site, int32_t precision, void* stream) {
+  if (!qkv || !key_mask || !ctx || !lse || !d_ctx || !d_qkv) return XFMR_EINVAL;
+  if (int rc = check_shape(B, L, A, H)) return rc;
+  if (!xf_aligned16(qkv) || !xf_aligned16(ctx) || !xf_aligned16(d_ctx) || !xf_aligned16(d_qkv)) return XFMR_EALIGN;
+  AttnArgs a{};
+  a.qkv = qkv; a.key_mask = key_mask; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
+  a.d_ctx = d_ctx; a.d_qkv = d_qkv; a.B = B; a.L = L; a.A = A; a.H = H;
+  a.drop = xf_make_dropout(dropout_p, seed, site);
+  if (precision == XFMR_PREC_BF16) return launch_bwd<PrecBF16>(a, (hipStream_t)stream);
+  if (precision == XFMR_PREC_F32) return launch_bwd<PrecF32>(a, (hipStream_t)stream);
+  return XFMR_EINVAL;
+}
+
+}  // extern "C"

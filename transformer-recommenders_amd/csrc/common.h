@@ -1,0 +1,276 @@
+// Shared device helpers for libxfmr_hip (gfx950 / CDNA4 only: wave64, MFMA 32x32, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xfmr_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define XF_WAVE 64
+
+#define XF_LAUNCH_CHECK()                                   \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return XFMR_EHIP;  \
+  } while (0)
+
+static inline bool xf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ int xf_lane() { return threadIdx.x & 63; }
+
+// 32x32 MFMA accumulator map (dtype independent on gfx950): element r of lane l is
+// C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ int xf_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------------------------------------------
+// Precision policies. A policy names the LDS element type and implements, for one wave,
+//   tile_nt : acc(32x32) += A[arow0..+32][0..K) * B[brow0..+32][0..K)^T   (both images K-contiguous)
+//   tile_xb : acc(32x32) += A[arow0..+32][kbase + k] * X[k][col]  for k = 0..31, where X is a 32x32
+//             accumulator tile still in registers (its ROW index is the contraction index: no lane
+//             movement, cdna_hip_programming.md section 3 "An accumulator tile as the next MFMA's
+//             operand"); A is an image whose K runs over X's rows.
+// Images are row-major [row][ld]; ld is in elements and keeps 16-byte row alignment.
+// ---------------------------------------------------------------------------------------------------
+struct PrecBF16 {
+  using elem = __bf16;
+  static constexpr int kPad = 8;  // elements of row padding (16 B = one ds_read_b128)
+  static constexpr int kId = XFMR_PREC_BF16;
+  __device__ static __forceinline__ elem cvt(float x) { return (__bf16)x; }
+  __device__ static __forceinline__ float round(float x) { return (float)((__bf16)x); }
+
+  __device__ static __forceinline__ void tile_nt(f32x16& acc, const elem* A, int lda, int arow0, const elem* B,
+                                                 int ldb, int brow0, int K) {
+    const int l = xf_lane();
+    const elem* pa = A + (arow0 + (l & 31)) * lda + 8 * (l >> 5);
+    const elem* pb = B + (brow0 + (l & 31)) * ldb + 8 * (l >> 5);
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(pa + k0);
+      bf16x8 b = *reinterpret_cast<const bf16x8*>(pb + k0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+  }
+  // B operand held in registers (8 bf16 per 16-deep k-step), e.g. a wave's query rows.
+  __device__ static __forceinline__ void tile_nreg(f32x16& acc, const elem* A, int lda, int arow0,
+                                                   const bf16x8* breg, int K) {
+    const int l = xf_lane();
+    const elem* pa = A + (arow0 + (l & 31)) * lda + 8 * (l >> 5);
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(pa + 16 * s);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, breg[s], acc, 0, 0, 0);
+    }
+  }
+  __device__ static __forceinline__ void tile_xb(f32x16& acc, const elem* A, int lda, int arow0, int kbase,
+                                                 const f32x16& x) {
+    const int l = xf_lane();
+    const elem* pa = A + (arow0 + (l & 31)) * lda + kbase + 4 * (l >> 5);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = (__bf16)x[8 * s + j];
+      // element j of lane half h pairs with X row 16s + 8(j>>2) + 4h + (j&3)
+      bf16x4 a0 = *reinterpret_cast<const bf16x4*>(pa + 16 * s);
+      bf16x4 a1 = *reinterpret_cast<const bf16x4*>(pa + 16 * s + 8);
+      bf16x8 a;
+      a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
+      a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+  }
+};
+
+struct PrecF32 {
+  using elem = float;
+  static constexpr int kPad = 4;
+  static constexpr int kId = XFMR_PREC_F32;
+  __device__ static __forceinline__ elem cvt(float x) { return x; }
+  __device__ static __forceinline__ float round(float x) { return x; }
+
+  __device__ static __forceinline__ void tile_nt(f32x16& acc, const elem* A, int lda, int arow0, const elem* B,
+                                                 int ldb, int brow0, int K) {
+    const int l = xf_lane();
+    const elem* pa = A + (arow0 + (l & 31)) * lda + (l >> 5);
+    const elem* pb = B + (brow0 + (l & 31)) * ldb + (l >> 5);
+#pragma unroll 8
+    for (int k0 = 0; k0 < K; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k0], pb[k0], acc, 0, 0, 0);
+  }
+  // breg[s] holds B[k = 2s + (lane>>5)][col = lane&31]
+  __device__ static __forceinline__ void tile_nreg(f32x16& acc, const elem* A, int lda, int arow0, const float* breg,
+                                                   int K) {
+    const int l = xf_lane();
+    const elem* pa = A + (arow0 + (l & 31)) * lda + (l >> 5);
+#pragma unroll
+    for (int s = 0; s < K / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s], breg[s], acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ void tile_xb(f32x16& acc, const elem* A, int lda, int arow0, int kbase,
+                                                 const f32x16& x) {
+    const int l = xf_lane();
+    const elem* pa = A + (arow0 + (l & 31)) * lda + kbase + 4 * (l >> 5);
+    // k-step r contracts X rows (r&3)+8(r>>2) [lane half 0] and +4 [lane half 1]: exactly register r.
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(r & 3) + 8 * (r >> 2)], x[r], acc, 0, 0, 0);
+  }
+};
+
+template <class P>
+__host__ __device__ constexpr int xf_ld(int k) {  // padded leading dimension of a [rows][k] image
+  return k + P::kPad;
+}
+
+// Register-resident "N" operand of one wave (its 32 rows, K deep), loaded straight from global fp32.
+template <class P, int K>
+struct RegRows;
+template <int K>
+struct RegRows<PrecBF16, K> {
+  bf16x8 v[K / 16];
+  // row pointer of THIS lane's row (lane&31); valid==false loads zeros
+  __device__ __forceinline__ void load(const float* row, bool valid) {
+    const int h = xf_lane() >> 5;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      float4 a = make_float4(0, 0, 0, 0), b = a;
+      if (valid) {
+        a = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h);
+        b = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h + 4);
+      }
+      v[s][0] = (__bf16)a.x; v[s][1] = (__bf16)a.y; v[s][2] = (__bf16)a.z; v[s][3] = (__bf16)a.w;
+      v[s][4] = (__bf16)b.x; v[s][5] = (__bf16)b.y; v[s][6] = (__bf16)b.z; v[s][7] = (__bf16)b.w;
+    }
+  }
+  __device__ __forceinline__ float dot_partial(const RegRows& o) const {  // over this lane's half of K
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf((float)v[s][j], (float)o.v[s][j], acc);
+    return acc;
+  }
+  __device__ __forceinline__ const bf16x8* regs() const { return v; }
+};
+template <int K>
+struct RegRows<PrecF32, K> {
+  float v[K / 2];
+  __device__ __forceinline__ void load(const float* row, bool valid) {
+    const int h = xf_lane() >> 5;
+#pragma unroll
+    for (int s = 0; s < K / 2; ++s) v[s] = valid ? row[2 * s + h] : 0.f;
+  }
+  __device__ __forceinline__ float dot_partial(const RegRows& o) const {
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < K / 2; ++s) acc = fmaf(v[s], o.v[s], acc);
+    return acc;
+  }
+  __device__ __forceinline__ const float* regs() const { return v; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// LDS staging from fp32 global memory, converting to the policy's element type.
+// ---------------------------------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ void xf_store4(typename P::elem* dst, float4 v);
+template <>
+__device__ __forceinline__ void xf_store4<PrecBF16>(__bf16* dst, float4 v) {
+  bf16x4 o;
+  o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+  *reinterpret_cast<bf16x4*>(dst) = o;
+}
+template <>
+__device__ __forceinline__ void xf_store4<PrecF32>(float* dst, float4 v) {
+  *reinterpret_cast<float4*>(dst) = v;
+}
+template <class P>
+__device__ __forceinline__ void xf_store2(typename P::elem* dst, float a, float b);
+template <>
+__device__ __forceinline__ void xf_store2<PrecBF16>(__bf16* dst, float a, float b) {
+  bf16x2 o;
+  o[0] = (__bf16)a; o[1] = (__bf16)b;
+  *reinterpret_cast<bf16x2*>(dst) = o;
+}
+template <>
+__device__ __forceinline__ void xf_store2<PrecF32>(float* dst, float a, float b) {
+  *reinterpret_cast<float2*>(dst) = make_float2(a, b);
+}
+
+__device__ __forceinline__ float xf_get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+// ---------------------------------------------------------------------------------------------------
+// Dropout: stateless per-element hash so that forward and backward kernels with different thread
+// mappings regenerate the same mask. keep  <=>  hash32(element ^ key) >= threshold(p).
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t xf_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct XfDropout {
+  uint32_t key;
+  uint32_t thresh;  // drop when hash < thresh
+  float scale;      // 1/(1-p); 1 when disabled
+  bool on;
+};
+static inline XfDropout xf_make_dropout(float p, uint64_t seed, uint32_t site) {
+  XfDropout d;
+  d.on = p > 0.f;
+  d.key = xf_hash32((uint32_t)seed ^ xf_hash32((uint32_t)(seed >> 32) + 0x9E3779B9U * (site + 1)));
+  double t = (double)p * 4294967296.0;
+  d.thresh = p >= 1.f ? 0xFFFFFFFFu : (uint32_t)t;
+  d.scale = d.on ? 1.f / (1.f - p) : 1.f;
+  return d;
+}
+__device__ __forceinline__ float xf_keep_scale(const XfDropout& d, uint32_t element) {
+  return (xf_hash32(element ^ d.key) >= d.thresh) ? d.scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wave reductions (wave64)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float xf_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float xf_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float xf_half_swap(float v) { return __shfl_xor(v, 32, 64); }  // lane <-> lane^32
+
+__device__ __forceinline__ float xf_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float xf_gelu_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float xf_softplus(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
+__device__ __forceinline__ float xf_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// Write a wave's 32(d) x 32(row) accumulator tile, transposed, as 32 rows of 32 contiguous floats.
+// scratch: per-wave [32][33] floats. dst row pointer for lane-row j: base + (row0 + j) * stride.
+__device__ __forceinline__ void xf_store_tile_T(float* scratch, const f32x16& acc, float mul, float* base, int64_t stride,
+                                             int row0, int row_end) {
+  const int lane = xf_lane();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scratch[(lane & 31) * 33 + xf_acc_row(r, lane)] = acc[r] * mul;
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave re-reads its own writes
+  __builtin_amdgcn_wave_barrier();
+  const int j = lane >> 1, half = lane & 1;
+  if (row0 + j < row_end) {
+    float* dst = base + (int64_t)(row0 + j) * stride + 16 * half;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float4 v;
+      v.x = scratch[j * 33 + 16 * half + 4 * u + 0];
+      v.y = scratch[j * 33 + 16 * half + 4 * u + 1];
+      v.z = scratch[j * 33 + 16 * half + 4 * u + 2];
+      v.w = scratch[j * 33 + 16 * half + 4 * u + 3];
+      *reinterpret_cast<float4*>(dst + 4 * u) = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+

@@ -1,0 +1,274 @@
+// Whole-encoder forward / backward: the launch sequence of BertEmbeddings + N x BertLayer over the
+// kernels of this library, with a deterministic carve of the caller's activation workspace.
+// Host code only (no kernels here): everything is enqueued on the caller's stream, nothing synchronises,
+// so one training step can be captured into a hipGraph.
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+
+// defined in norm.hip (internal, not part of the public header)
+extern "C" int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          float* dx, float* d_lin, float* d_gamma, float* d_beta, float* d_bias, int64_t rows,
+                          int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials, hipStream_t st);
+
+namespace {
+
+struct LayerParams {
+  int64_t wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+};
+struct ParamLayout {
+  int64_t pos, type, eg, eb;
+  int64_t total;
+};
+
+int64_t layer_base(const xfmr_encoder_cfg* c, int i, ParamLayout* pl) {
+  const int64_t H = c->hidden, I = c->inter;
+  pl->pos = 0;
+  pl->type = pl->pos + (int64_t)c->max_pos * H;
+  pl->eg = pl->type + 2 * H;
+  pl->eb = pl->eg + H;
+  const int64_t first = pl->eb + H;
+  const int64_t per = 3 * H * H + 3 * H + H * H + H + 2 * H + I * H + I + H * I + H + 2 * H;
+  pl->total = first + per * c->layers;
+  return first + per * i;
+}
+LayerParams layer_params(const xfmr_encoder_cfg* c, int i) {
+  ParamLayout pl;
+  const int64_t H = c->hidden, I = c->inter;
+  int64_t o = layer_base(c, i, &pl);
+  LayerParams p;
+  p.wqkv = o; o += 3 * H * H;
+  p.bqkv = o; o += 3 * H;
+  p.wo = o; o += H * H;
+  p.bo = o; o += H;
+  p.ln1g = o; o += H;
+  p.ln1b = o; o += H;
+  p.w1 = o; o += I * H;
+  p.b1 = o; o += I;
+  p.w2 = o; o += H * I;
+  p.b2 = o; o += H;
+  p.ln2g = o; o += H;
+  p.ln2b = o; o += H;
+  return p;
+}
+
+struct LayerActs {
+  float *qkv, *lse, *ctx, *pre1, *mean1, *rstd1, *x1, *f1, *g, *pre2, *mean2, *rstd2, *x2;
+};
+struct Acts {
+  float *emb_pre, *emb_mean, *emb_rstd, *x0;
+  float *dA, *dB, *dI, *dQKV;
+  void* scratch;  // ln-bwd partials / dW slabs / colsum partials (used one at a time)
+  size_t scratch_bytes;
+  size_t total;
+};
+
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Carves `base` (may be null: size query). Layer i's activations are returned in *la when i >= 0.
+Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs* la) {
+  const size_t T = (size_t)c->batch * c->seq_len, H = c->hidden, I = c->inter, A = c->heads;
+  size_t o = 0;
+  auto take = [&](size_t nfloats) -> float* {
+    float* p = base ? reinterpret_cast<float*>(base + o) : nullptr;
+    o += up256(nfloats * sizeof(float));
+    return p;
+  };
+  Acts a{};
+  a.emb_pre = take(T * H); a.emb_mean = take(T); a.emb_rstd = take(T); a.x0 = take(T * H);
+  a.dA = take(T * H); a.dB = take(T * H); a.dI = take(T * I); a.dQKV = take(T * 3 * H);
+  size_t sc = xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H);
+  size_t s2 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)(3 * H), (int32_t)H);
+  size_t s3 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)I, (int32_t)H);
+  size_t s4 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)H, (int32_t)I);
+  size_t s5 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)H, (int32_t)H);
+  size_t s6 = xfmr_colsum_workspace((int64_t)T, (int32_t)(3 * H));
+  size_t s7 = xfmr_colsum_workspace((int64_t)T, (int32_t)I);
+  if (s2 > sc) sc = s2; if (s3 > sc) sc = s3; if (s4 > sc) sc = s4; if (s5 > sc) sc = s5;
+  if (s6 > sc) sc = s6; if (s7 > sc) sc = s7;
+  a.scratch = base ? base + o : nullptr;
+  a.scratch_bytes = sc;
+  o += up256(sc);
+  for (int i = 0; i < c->layers; ++i) {
+    LayerActs l;
+    l.qkv = take(T * 3 * H); l.lse = take((size_t)c->batch * A * c->seq_len); l.ctx = take(T * H);
+    l.pre1 = take(T * H); l.mean1 = take(T); l.rstd1 = take(T); l.x1 = take(T * H);
+    l.f1 = take(T * I); l.g = take(T * I);
+    l.pre2 = take(T * H); l.mean2 = take(T); l.rstd2 = take(T); l.x2 = take(T * H);
+    if (i == layer && la) *la = l;
+  }
+  a.total = o;
+  return a;
+}
+
+int check_cfg(const xfmr_encoder_cfg* c) {
+  if (!c) return XFMR_EINVAL;
+  if (c->batch <= 0 || c->seq_len <= 0 || c->hidden <= 0 || c->heads <= 0 || c->inter <= 0 || c->layers <= 0)
+    return XFMR_EINVAL;
+  if (c->seq_len > c->max_pos) return XFMR_EINVAL;
+  if (c->hidden != c->heads * 32 || (c->inter & 3)) return XFMR_EUNSUPPORTED;
+  if (c->precision != XFMR_PREC_F32 && c->precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  return XFMR_OK;
+}
+
+enum { SITE_EMB = 0 };
+inline uint32_t site_attn(int i) { return 1 + 4 * (uint32_t)i; }
+inline uint32_t site_out(int i) { return 2 + 4 * (uint32_t)i; }
+inline uint32_t site_ffn(int i) { return 3 + 4 * (uint32_t)i; }
+
+#define XF_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != XFMR_OK) return _rc; \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* xfmr_strerror(int code) {
+  switch (code) {
+    case XFMR_OK: return "ok";
+    case XFMR_EINVAL: return "invalid argument";
+    case XFMR_EUNSUPPORTED: return "shape not supported by the gfx950 kernels (head size must be 32, H in {64,128,256} for the loss)";
+    case XFMR_EWORKSPACE: return "workspace too small";
+    case XFMR_EHIP: return "HIP launch failed";
+    case XFMR_EALIGN: return "pointer or leading dimension not 16-byte aligned";
+    default: return "unknown error";
+  }
+}
+int xfmr_abi_version(void) { return XFMR_ABI_VERSION; }
+
+int64_t xfmr_param_count(const xfmr_encoder_cfg* cfg) {
+  if (!cfg || cfg->layers <= 0) return XFMR_EINVAL;
+  ParamLayout pl;
+  layer_base(cfg, 0, &pl);
+  return pl.total;
+}
+
+int32_t xfmr_param_offsets(const xfmr_encoder_cfg* cfg, int64_t* offsets, int32_t capacity) {
+  if (!cfg || !offsets) return XFMR_EINVAL;
+  const int32_t n = 4 + 16 * cfg->layers;
+  if (capacity < n) return XFMR_EINVAL;
+  ParamLayout pl;
+  layer_base(cfg, 0, &pl);
+  const int64_t H = cfg->hidden;
+  int k = 0;
+  offsets[k++] = pl.pos; offsets[k++] = pl.type; offsets[k++] = pl.eg; offsets[k++] = pl.eb;
+  for (int i = 0; i < cfg->layers; ++i) {
+    const LayerParams p = layer_params(cfg, i);
+    offsets[k++] = p.wqkv; offsets[k++] = p.wqkv + H * H; offsets[k++] = p.wqkv + 2 * H * H;
+    offsets[k++] = p.bqkv; offsets[k++] = p.bqkv + H; offsets[k++] = p.bqkv + 2 * H;
+    offsets[k++] = p.wo; offsets[k++] = p.bo; offsets[k++] = p.ln1g; offsets[k++] = p.ln1b;
+    offsets[k++] = p.w1; offsets[k++] = p.b1; offsets[k++] = p.w2; offsets[k++] = p.b2;
+    offsets[k++] = p.ln2g; offsets[k++] = p.ln2b;
+  }
+  return n;
+}
+
+size_t xfmr_encoder_workspace_bytes(const xfmr_encoder_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  return carve(cfg, nullptr, -1, nullptr).total;
+}
+
+int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int64_t* item_idx,
+                     const float* table, int64_t n_rows, float* tok, uint8_t* key_mask, void* acts,
+                     size_t acts_bytes, void* stream) {
+  XF_TRY(check_cfg(cfg));
+  if (!params || !item_idx || !table || !tok || !key_mask || !acts) return XFMR_EINVAL;
+  if (!xf_aligned16(params) || !xf_aligned16(acts) || !xf_aligned16(tok) || !xf_aligned16(table)) return XFMR_EALIGN;
+  unsigned char* base = (unsigned char*)acts;
+  const Acts a = carve(cfg, base, -1, nullptr);
+  if (acts_bytes < a.total) return XFMR_EWORKSPACE;
+  const int B = cfg->batch, L = cfg->seq_len, H = cfg->hidden, I = cfg->inter, A = cfg->heads;
+  const int64_t T = (int64_t)B * L;
+  const int prec = cfg->precision;
+  ParamLayout pl;
+  layer_base(cfg, 0, &pl);
+  XF_TRY(xfmr_embed_ln_fwd(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
+                           params + pl.eb, a.x0, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask, B, L, H, cfg->ln_eps,
+                           cfg->hidden_dropout, cfg->seed, SITE_EMB, stream));
+  const float* x = a.x0;
+  for (int i = 0; i < cfg->layers; ++i) {
+    LayerActs l;
+    carve(cfg, base, i, &l);
+    const LayerParams p = layer_params(cfg, i);
+    float* out = (i == cfg->layers - 1) ? tok : l.x2;
+    XF_TRY(xfmr_linear_fwd(x, params + p.wqkv, params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
+                           0.f, 0, 0, prec, stream));
+    XF_TRY(xfmr_attn_fwd(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, cfg->seed, site_attn(i), prec,
+                         stream));
+    XF_TRY(xfmr_linear_fwd(l.ctx, params + p.wo, params + p.bo, l.pre1, T, H, H, XFMR_EPI_BIAS_DROP_RES, x, nullptr,
+                           cfg->hidden_dropout, cfg->seed, site_out(i), prec, stream));
+    XF_TRY(xfmr_layernorm_fwd(l.pre1, params + p.ln1g, params + p.ln1b, l.x1, l.mean1, l.rstd1, T, H, cfg->ln_eps,
+                              stream));
+    XF_TRY(xfmr_linear_fwd(l.x1, params + p.w1, params + p.b1, l.g, T, I, H, XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f,
+                           0, 0, prec, stream));
+    XF_TRY(xfmr_linear_fwd(l.g, params + p.w2, params + p.b2, l.pre2, T, H, I, XFMR_EPI_BIAS_DROP_RES, l.x1, nullptr,
+                           cfg->hidden_dropout, cfg->seed, site_ffn(i), prec, stream));
+    XF_TRY(xfmr_layernorm_fwd(l.pre2, params + p.ln2g, params + p.ln2b, out, l.mean2, l.rstd2, T, H, cfg->ln_eps,
+                              stream));
+    x = out;
+  }
+  return XFMR_OK;
+}
+
+int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* grads, float* d_tok,
+                     const uint8_t* key_mask, void* acts, size_t acts_bytes, void* stream) {
+  XF_TRY(check_cfg(cfg));
+  if (!params || !grads || !d_tok || !key_mask || !acts) return XFMR_EINVAL;
+  if (!xf_aligned16(params) || !xf_aligned16(grads) || !xf_aligned16(acts) || !xf_aligned16(d_tok)) return XFMR_EALIGN;
+  unsigned char* base = (unsigned char*)acts;
+  const Acts a = carve(cfg, base, -1, nullptr);
+  if (acts_bytes < a.total) return XFMR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = cfg->batch, L = cfg->seq_len, H = cfg->hidden, I = cfg->inter, A = cfg->heads;
+  const int64_t T = (int64_t)B * L;
+  const int prec = cfg->precision;
+  const bool hdrop = cfg->hidden_dropout > 0.f;
+  const XfDropout off = xf_make_dropout(0.f, 0, 0);
+  float* dX = d_tok;  // gradient w.r.t. the current layer's output
+  for (int i = cfg->layers - 1; i >= 0; --i) {
+    LayerActs l;
+    carve(cfg, base, i, &l);
+    const LayerParams p = layer_params(cfg, i);
+    LayerActs prev;
+    const float* x_in = a.x0;
+    if (i > 0) {
+      carve(cfg, base, i - 1, &prev);
+      x_in = prev.x2;
+    }
+    // LayerNorm 2 -> dA = d(pre2); dlin = gradient of the FFN output Linear
+    XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, hdrop ? a.dB : nullptr,
+                                 grads + p.ln2g, grads + p.ln2b, grads + p.b2, T, H, off,
+                                 xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_ffn(i)), a.scratch, st));
+    const float* dlin = hdrop ? a.dB : a.dA;
+    XF_TRY(xfmr_linear_bwd_dw(dlin, l.g, grads + p.w2, T, H, I, prec, a.scratch, a.scratch_bytes, stream));
+    XF_TRY(xfmr_linear_bwd_dx(dlin, params + p.w2, a.dI, T, H, I, nullptr, l.f1, prec, stream));
+    XF_TRY(xfmr_colsum(a.dI, grads + p.b1, T, I, a.scratch, stream));
+    XF_TRY(xfmr_linear_bwd_dw(a.dI, l.x1, grads + p.w1, T, I, H, prec, a.scratch, a.scratch_bytes, stream));
+    XF_TRY(xfmr_linear_bwd_dx(a.dI, params + p.w1, a.dA, T, I, H, a.dA, nullptr, prec, stream));  // += d(pre2)
+    // LayerNorm 1 -> dX = d(pre1)
+    XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, hdrop ? a.dB : nullptr,
+                                 grads + p.ln1g, grads + p.ln1b, grads + p.bo, T, H, off,
+                                 xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_out(i)), a.scratch, st));
+    dlin = hdrop ? a.dB : dX;
+    XF_TRY(xfmr_linear_bwd_dw(dlin, l.ctx, grads + p.wo, T, H, H, prec, a.scratch, a.scratch_bytes, stream));
+    XF_TRY(xfmr_linear_bwd_dx(dlin, params + p.wo, a.dA, T, H, H, nullptr, nullptr, prec, stream));  // d(ctx)
+    XF_TRY(xfmr_attn_bwd(l.qkv, key_mask, l.ctx, l.lse, a.dA, a.dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
+                         site_attn(i), prec, stream));
+    XF_TRY(xfmr_colsum(a.dQKV, grads + p.bqkv, T, 3 * H, a.scratch, stream));
+    XF_TRY(xfmr_linear_bwd_dw(a.dQKV, x_in, grads + p.wqkv, T, 3 * H, H, prec, a.scratch, a.scratch_bytes, stream));
+    XF_TRY(xfmr_linear_bwd_dx(a.dQKV, params + p.wqkv, dX, T, 3 * H, H, dX, nullptr, prec, stream));  // += d(pre1)
+  }
+  ParamLayout pl;
+  layer_base(cfg, 0, &pl);
+  XF_TRY(xf_layernorm_bwd_impl(dX, a.emb_pre, a.emb_mean, a.emb_rstd, params + pl.eg, a.dA, nullptr, grads + pl.eg,
+                               grads + pl.eb, nullptr, T, H,
+                               xf_make_dropout(cfg->hidden_dropout, cfg->seed, SITE_EMB), off, a.scratch, st));
+  XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
+  return XFMR_OK;
+}
+
+}  // extern "C"

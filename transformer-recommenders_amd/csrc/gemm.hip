@@ -1,0 +1,346 @@
+// MFMA GEMMs for the encoder's Linear layers (forward, dX, dW) with fused epilogues.
+//
+//   C[M,N] = A'[M,K] * B'[N,K]^T,  A' = A or A^T, B' = B or B^T as stored (fp32, row-major)
+//
+// One workgroup = 4 waves (2x2) computes a BM x BN tile; each wave owns (BM/2)x(BN/2) as 32x32 MFMA
+// accumulators. K is walked in BK=32 slices: global fp32 -> registers (prefetch of slice k+1 is in
+// flight while slice k is multiplied) -> converted to the MFMA element type on the way into LDS.
+// These GEMMs are skinny (K = H or I <= 1024, except dW where K = tokens and the split-K grid supplies
+// the parallelism); the operands are L2 / Infinity-Cache resident between the kernels of one step.
+#include "common.h"
+
+namespace {
+
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DROP_RES = 2, EPI_GELU_GRAD = 3, EPI_SPLITK = 4 };
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int64_t lda, ldb, ldc;
+  int64_t M; int N; int K;
+  int k_chunk;            // split-K: blockIdx.z handles [z*k_chunk, min(K,(z+1)*k_chunk)); 0 = whole K
+  const float* bias;      // [N] or null
+  const float* R;         // residual / residual-grad [M,ldc] or null
+  const float* P;         // pre-activation for gelu' [M,ldc]
+  float* C2;              // pre-activation output for EPI_GELU
+  XfDropout drop;
+};
+
+constexpr int BK = 32;
+
+template <class P, int BM, int BN, bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  using elem = typename P::elem;
+  constexpr int LD = xf_ld<P>(BK);
+  __shared__ __attribute__((aligned(16))) elem sA[BM * LD];
+  __shared__ __attribute__((aligned(16))) elem sB[BN * LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  int kbeg = 0, kend = g.K;
+  if (g.k_chunk > 0) {
+    kbeg = blockIdx.z * g.k_chunk;
+    kend = min(g.K, kbeg + g.k_chunk);
+  }
+
+  constexpr int NA = BM * BK / 4 / 256;  // float4 per thread per slice
+  constexpr int NB = BN * BK / 4 / 256;
+  float4 ra[NA], rb[NB];
+
+  // ---- global -> register loaders ------------------------------------------------------------
+  auto load_operand = [&](const float* src, int64_t ld, int64_t row0, int64_t rows_total, bool transposed,
+                          int k0, float4* reg, int count, int tile_rows) {
+    if (!transposed) {
+      // memory [rows][K]: chunk c -> row c/8, k-offset (c%8)*4
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < count) {
+          int c = tid + i * 256;
+          int r = c >> 3, kk = (c & 7) * 4;
+          int64_t gr = row0 + r;
+          int gk = k0 + kk;
+          float4 v = make_float4(0, 0, 0, 0);
+          if (gr < rows_total && gk < kend) {
+            const float* p = src + gr * ld + gk;
+            if (gk + 3 < kend) v = *reinterpret_cast<const float4*>(p);
+            else { v.x = p[0]; if (gk + 1 < kend) v.y = p[1]; if (gk + 2 < kend) v.z = p[2]; }
+          }
+          reg[i] = v;
+        }
+      }
+    } else {
+      // memory [K][rows]: item -> k-pair kp, 4 consecutive rows; two float4 (k, k+1) per item
+      const int rows4 = tile_rows / 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (2 * i < count) {
+          int item = tid + i * 256;
+          int kp = item / rows4, rc = (item % rows4) * 4;
+          int64_t gr = row0 + rc;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            int gk = k0 + 2 * kp + u;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (gk < kend && gr < rows_total) {
+              const float* p = src + (int64_t)gk * ld + gr;
+              if (gr + 3 < rows_total) v = *reinterpret_cast<const float4*>(p);
+              else { v.x = p[0]; if (gr + 1 < rows_total) v.y = p[1]; if (gr + 2 < rows_total) v.z = p[2]; }
+            }
+            reg[2 * i + u] = v;
+          }
+        }
+      }
+    }
+  };
+  auto store_operand = [&](elem* dst, bool transposed, const float4* reg, int count, int tile_rows) {
+    if (!transposed) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < count) {
+          int c = tid + i * 256;
+          int r = c >> 3, kk = (c & 7) * 4;
+          xf_store4<P>(dst + r * LD + kk, reg[i]);
+        }
+      }
+    } else {
+      const int rows4 = tile_rows / 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (2 * i < count) {
+          int item = tid + i * 256;
+          int kp = item / rows4, rc = (item % rows4) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            xf_store2<P>(dst + (rc + j) * LD + 2 * kp, xf_get(reg[2 * i], j), xf_get(reg[2 * i + 1], j));
+        }
+      }
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    load_operand(g.A, g.lda, m0, g.M, TA, kbeg, ra, NA, BM);
+    load_operand(g.B, g.ldb, n0, g.N, TB, kbeg, rb, NB, BN);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    store_operand(sA, TA, ra, NA, BM);
+    store_operand(sB, TB, rb, NB, BN);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      load_operand(g.A, g.lda, m0, g.M, TA, kbeg + (kt + 1) * BK, ra, NA, BM);
+      load_operand(g.B, g.ldb, n0, g.N, TB, kbeg + (kt + 1) * BK, rb, NB, BN);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        P::tile_nt(acc[i][j], sA, LD, wr * WM + i * 32, sB, LD, wc * WN + j * 32, BK);
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------
+  float* C = g.C;
+  if (EPI == EPI_SPLITK) C += (int64_t)blockIdx.z * g.M * g.ldc;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wc * WN + j * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bias = (EPI != EPI_SPLITK && EPI != EPI_GELU_GRAD && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wr * WM + i * 32 + xf_acc_row(r, lane);
+        if (m >= g.M) continue;
+        const int64_t o = m * g.ldc + n;
+        float v = acc[i][j][r] + bias;
+        if (EPI == EPI_STORE) {
+          if (g.R) v += g.R[o];
+          C[o] = v;
+        } else if (EPI == EPI_GELU) {
+          g.C2[o] = v;
+          C[o] = xf_gelu(v);
+        } else if (EPI == EPI_DROP_RES) {
+          if (g.drop.on) v *= xf_keep_scale(g.drop, (uint32_t)(m * g.N + n));
+          C[o] = v + g.R[o];
+        } else if (EPI == EPI_GELU_GRAD) {
+          C[o] = v * xf_gelu_grad(g.P[o]);
+        } else {
+          C[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// deterministic reduction of `count` slabs: dst[i] = sum_s src[s*n + i]
+__global__ void reduce_slabs_kernel(float* dst, const float* src, int count, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < count; ++c) s += src[(int64_t)c * n + i];
+  dst[i] = s;
+}
+
+// column sums, stage 1: block b sums rows [b*rows_per, ...) into partial[b][N]
+__global__ void colsum_partial_kernel(const float* a, float* partial, int64_t M, int N, int rows_per) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = min(M, r0 + rows_per);
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += a[r * N + n];
+  partial[(int64_t)blockIdx.y * N + n] = s;
+}
+
+template <class P, bool TA, bool TB, int EPI>
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
+  // tile choice: 128x128 when it still fills the chip, otherwise 64-wide tiles for more workgroups
+  const int64_t tiles128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
+  const bool bigN = g.N > 64, bigM = (g.M > 64) && (tiles128 >= 256 || g.M >= 4096);
+  dim3 block(256);
+  if (bigM && bigN) {
+    dim3 grid((g.N + 127) / 128, (unsigned)((g.M + 127) / 128), splits);
+    hipLaunchKernelGGL((gemm_kernel<P, 128, 128, TA, TB, EPI>), grid, block, 0, st, g);
+  } else if (bigN) {
+    dim3 grid((g.N + 127) / 128, (unsigned)((g.M + 63) / 64), splits);
+    hipLaunchKernelGGL((gemm_kernel<P, 64, 128, TA, TB, EPI>), grid, block, 0, st, g);
+  } else if (bigM) {
+    dim3 grid((g.N + 63) / 64, (unsigned)((g.M + 127) / 128), splits);
+    hipLaunchKernelGGL((gemm_kernel<P, 128, 64, TA, TB, EPI>), grid, block, 0, st, g);
+  } else {
+    dim3 grid((g.N + 63) / 64, (unsigned)((g.M + 63) / 64), splits);
+    hipLaunchKernelGGL((gemm_kernel<P, 64, 64, TA, TB, EPI>), grid, block, 0, st, g);
+  }
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+template <bool TA, bool TB, int EPI>
+int dispatch_gemm(const GemmArgs& g, int splits, int precision, hipStream_t st) {
+  if (precision == XFMR_PREC_BF16) return launch_gemm<PrecBF16, TA, TB, EPI>(g, splits, st);
+  if (precision == XFMR_PREC_F32) return launch_gemm<PrecF32, TA, TB, EPI>(g, splits, st);
+  return XFMR_EINVAL;
+}
+
+int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
+  // reduction dimension = M (tokens). Aim at ~512 workgroups in total.
+  int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int64_t want = (512 + tiles - 1) / tiles;
+  int64_t chunk = (M + want - 1) / want;
+  chunk = ((chunk + 31) / 32) * 32;
+  if (chunk < 64) chunk = 64;
+  *k_chunk = (int)chunk;
+  return (int)((M + chunk - 1) / chunk);
+}
+
+}  // namespace
+
+extern "C" {
+
+int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
+                    int32_t epilogue, const float* residual, float* aux_out, float dropout_p, uint64_t seed,
+                    uint32_t site, int32_t precision, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
+  if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
+  if (!xf_aligned16(x) || !xf_aligned16(w) || !xf_aligned16(y)) return XFMR_EALIGN;
+  GemmArgs g{};
+  g.A = x; g.B = w; g.C = y; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K; g.k_chunk = 0;
+  g.bias = bias; g.R = residual; g.C2 = aux_out; g.P = nullptr;
+  g.drop = xf_make_dropout(dropout_p, seed, site);
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case XFMR_EPI_BIAS:
+      g.R = nullptr;
+      return dispatch_gemm<false, false, EPI_STORE>(g, 1, precision, st);
+    case XFMR_EPI_BIAS_GELU:
+      if (!aux_out) return XFMR_EINVAL;
+      return dispatch_gemm<false, false, EPI_GELU>(g, 1, precision, st);
+    case XFMR_EPI_BIAS_DROP_RES:
+      if (!residual) return XFMR_EINVAL;
+      return dispatch_gemm<false, false, EPI_DROP_RES>(g, 1, precision, st);
+    default:
+      return XFMR_EINVAL;
+  }
+}
+
+int xfmr_linear_bwd_dx(const float* dy, const float* w, float* dx, int64_t M, int32_t N, int32_t K,
+                       const float* residual_grad, const float* gelu_pre, int32_t precision, void* stream) {
+  if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
+  if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
+  if (!xf_aligned16(dy) || !xf_aligned16(w) || !xf_aligned16(dx)) return XFMR_EALIGN;
+  // dx[M,K] = dy[M,N] * w[N,K]: contraction over N; B' [K rows][N] = w^T -> w is stored [N][K] = K-major
+  GemmArgs g{};
+  g.A = dy; g.B = w; g.C = dx; g.lda = N; g.ldb = K; g.ldc = K; g.M = M; g.N = K; g.K = N; g.k_chunk = 0;
+  g.bias = nullptr; g.R = residual_grad; g.P = gelu_pre; g.C2 = nullptr;
+  g.drop = xf_make_dropout(0.f, 0, 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (gelu_pre) return dispatch_gemm<false, true, EPI_GELU_GRAD>(g, 1, precision, st);
+  return dispatch_gemm<false, true, EPI_STORE>(g, 1, precision, st);
+}
+
+size_t xfmr_linear_bwd_dw_workspace(int64_t M, int32_t N, int32_t K) {
+  int k_chunk;
+  int splits = dw_split_plan(M, N, K, &k_chunk);
+  return (size_t)splits * (size_t)N * (size_t)K * sizeof(float);
+}
+
+int xfmr_linear_bwd_dw(const float* dy, const float* x, float* dw, int64_t M, int32_t N, int32_t K,
+                       int32_t precision, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dy || !x || !dw || !workspace || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
+  if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
+  if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(workspace)) return XFMR_EALIGN;
+  if (workspace_bytes < xfmr_linear_bwd_dw_workspace(M, N, K)) return XFMR_EWORKSPACE;
+  // dw[N,K] = dy^T[N,M] * x[M,K]: contraction over M. A' = dy^T (dy stored [M][N]), B'[K rows][M] = x^T.
+  int k_chunk;
+  int splits = dw_split_plan(M, N, K, &k_chunk);
+  GemmArgs g{};
+  g.A = dy; g.B = x; g.C = (float*)workspace; g.lda = N; g.ldb = K; g.ldc = K;
+  g.M = N; g.N = K; g.K = (int)M; g.k_chunk = k_chunk;
+  g.bias = nullptr; g.R = nullptr; g.P = nullptr; g.C2 = nullptr;
+  g.drop = xf_make_dropout(0.f, 0, 0);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dispatch_gemm<true, true, EPI_SPLITK>(g, splits, precision, st);
+  if (rc) return rc;
+  const int64_t n = (int64_t)N * K;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dw,
+                     (const float*)workspace, splits, n);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+static int colsum_plan(int64_t M, int* rows_per) {
+  int64_t blocks = (M + 127) / 128;
+  if (blocks > 256) blocks = 256;
+  *rows_per = (int)((M + blocks - 1) / blocks);
+  return (int)((M + *rows_per - 1) / *rows_per);
+}
+size_t xfmr_colsum_workspace(int64_t M, int32_t N) {
+  int rows_per;
+  return (size_t)colsum_plan(M, &rows_per) * (size_t)N * sizeof(float);
+}
+int xfmr_colsum(const float* a, float* out, int64_t M, int32_t N, void* workspace, void* stream) {
+  if (!a || !out || !workspace || M <= 0 || N <= 0) return XFMR_EINVAL;
+  int rows_per;
+  int blocks = colsum_plan(M, &rows_per);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, blocks), dim3(64), 0, st, a, (float*)workspace, M,
+                     N, rows_per);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, st, out, (const float*)workspace,
+                     blocks, (int64_t)N);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,662 @@
+// Fused in-batch sampled loss: all seven heads + LogitsStatistics + dL/dquery in one pass over the
+// (never materialised) logits  [ rowdot(q, E[pos]) | Q E[neg]^T ].
+//
+// Structure (flash-attention shaped, with "V = K = E_neg"):
+//   * a workgroup = 4 waves owns 128 queries; each wave keeps its 32 query rows in registers as the B
+//     operand and walks tiles of 64 negatives whose table rows are GATHERED by item id straight into
+//     LDS (fp32 HBM/L2 rows -> registers -> MFMA element type), next tile's gather in flight during the
+//     current tile's math;
+//   * S^T = E_neg Q^T is produced with the negative in the accumulator registers and the query on the
+//     lane, so every per-query reduction (false-negative mask counts, online log-sum-exp, softplus /
+//     hinge / relu sums, statistics) is lane-local;
+//   * the per-element loss-gradient weights w (softmax numerators / sigmoids / indicators) go back into
+//     the matrix core as the B operand straight from the accumulator registers:
+//     dQ^T += E_neg^T w^T  (second image of the tile, [h][j], conflict-free for the b64 fragment reads);
+//   * the negatives axis is split across workgroups (grid.y) to fill 256 CUs; a combine kernel merges the
+//     split partials per query, finishes the seven row losses and the gradient row, and a final
+//     single-workgroup kernel reduces them deterministically.
+#include "common.h"
+
+namespace {
+
+constexpr int BN = 64;        // negatives per tile
+constexpr int QB = 128;       // queries per workgroup
+constexpr int REC = 16;       // floats per (split, query) partial record
+constexpr int LDT = BN + 4;   // transposed image [h][j] leading dimension (see attention.hip note)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+enum { R_CNTD = 0, R_M, R_L, R_NCE, R_HINGE, R_LOGI, R_CNTC, R_CONTR, R_SSUM, R_SSQ, R_SMIN, R_SMAX, R_SW,
+       R_POSDOT, R_RQ, R_QQ };
+constexpr int BP = 24;        // doubles per block-partial record
+
+struct LossArgs {
+  const float* tok; const float* table; const float* rnorm; int64_t n_rows;
+  const int* counts;      // [0] = N valid positions, [1] = Np queries
+  const int* neg_item;    // [N] (shared mode) or null (catalogue mode: item j)
+  const int* qrow; const int* qpos;
+  float* part; float* partO;
+  int T; int nsplit;
+  int train_head, mask_fn, mode, need_grad;
+  float scale, margin;
+};
+
+// ---- compaction of valid positions (replaces the boolean-mask indexing of models.py:390-404) ------
+__global__ __launch_bounds__(1024) void prepare_kernel(const uint8_t* key_mask, const int64_t* pos_idx,
+                                                       const int64_t* neg_idx, int T, int64_t n_rows, int* counts,
+                                                       int* neg_item, int* qrow, int* qpos) {
+  __shared__ int s_valid[1024], s_query[1024];
+  const int tid = threadIdx.x;
+  const int per = (T + 1023) / 1024;
+  const int beg = tid * per, end = min(T, beg + per);
+  int nv = 0, nq = 0;
+  for (int i = beg; i < end; ++i) {
+    const bool v = key_mask[i] != 0;
+    nv += v;
+    nq += v && (pos_idx[i] != 0);
+  }
+  s_valid[tid] = nv;
+  s_query[tid] = nq;
+  __syncthreads();
+  // inclusive Hillis-Steele scan over 1024 entries
+  for (int off = 1; off < 1024; off <<= 1) {
+    int a = 0, b = 0;
+    if (tid >= off) { a = s_valid[tid - off]; b = s_query[tid - off]; }
+    __syncthreads();
+    s_valid[tid] += a;
+    s_query[tid] += b;
+    __syncthreads();
+  }
+  int ov = s_valid[tid] - nv, oq = s_query[tid] - nq;
+  for (int i = beg; i < end; ++i) {
+    if (key_mask[i] != 0) {
+      int64_t ni = neg_idx ? neg_idx[i] : 0;
+      if (ni < 0 || ni >= n_rows) ni = 0;
+      neg_item[ov++] = (int)ni;
+      int64_t pi = pos_idx[i];
+      if (pi != 0) {
+        if (pi < 0 || pi >= n_rows) pi = 0;
+        qrow[oq] = i;
+        qpos[oq] = (int)pi;
+        ++oq;
+      }
+    }
+  }
+  if (tid == 1023) {
+    counts[0] = s_valid[1023];
+    counts[1] = s_query[1023];
+  }
+}
+
+// ---- list form: queries already compacted (EmbedLoss.forward(query_embed, candidates)) ------------
+__global__ void prepare_lists_kernel(const int64_t* pos_items, const int64_t* neg_items, int Np, int N,
+                                     int64_t n_rows, int* counts, int* neg_item, int* qrow, int* qpos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    counts[0] = N;
+    counts[1] = Np;
+  }
+  if (i < Np) {
+    int64_t p = pos_items[i];
+    if (p < 0 || p >= n_rows) p = 0;
+    qrow[i] = i;
+    qpos[i] = (int)p;
+  }
+  if (neg_items && i < N) {
+    int64_t n = neg_items[i];
+    if (n < 0 || n >= n_rows) n = 0;
+    neg_item[i] = (int)n;
+  }
+}
+
+// ---- main kernel -------------------------------------------------------------------------------------
+template <class P, int H, bool ALL>
+__global__ __launch_bounds__(256) void loss_main_kernel(LossArgs a) {
+  using elem = typename P::elem;
+  constexpr int LDE = xf_ld<P>(H);
+  constexpr int NPASS = 2 * (H / 64);  // staging passes: 32 rows x 64 columns per pass per workgroup
+  __shared__ __attribute__((aligned(16))) elem sE[BN * LDE];
+  __shared__ __attribute__((aligned(16))) elem sET[H * LDT];
+  __shared__ __attribute__((aligned(16))) float sScratch[4 * 32 * 33];
+  __shared__ int sNid[BN];
+  __shared__ float sRc[BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+  const int Nq = a.counts[1];
+  const int N = (a.mode == XFMR_NEG_CATALOG) ? (int)a.n_rows : a.counts[0];
+  const int qb0 = blockIdx.x * QB;
+  if (qb0 >= Nq) return;
+  const int ntiles = (N + BN - 1) / BN;
+  const int split = blockIdx.y;
+  const int t_beg = (int)((int64_t)ntiles * split / a.nsplit);
+  const int t_end = (int)((int64_t)ntiles * (split + 1) / a.nsplit);
+
+  // ---- per-query prologue -----------------------------------------------------------------------
+  const int qi = qb0 + wid * 32 + (lane & 31);
+  const bool qvalid = qi < Nq;
+  const int row = qvalid ? a.qrow[qi] : 0;
+  const int pos_item = qvalid ? a.qpos[qi] : -2;
+  RegRows<P, H> qreg;
+  qreg.load(a.tok + (int64_t)row * H, qvalid);
+  float pos_dot, qq = 0.f;
+  {
+    RegRows<P, H> preg;
+    preg.load(a.table + (int64_t)(qvalid ? pos_item : 0) * H, qvalid);
+    pos_dot = qreg.dot_partial(preg);
+    pos_dot += xf_half_swap(pos_dot);
+    if (qvalid) {
+      const float* pr = a.tok + (int64_t)row * H + hh * (H / 2);
+#pragma unroll 4
+      for (int c = 0; c < H / 2; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(pr + c);
+        qq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+    }
+    qq += xf_half_swap(qq);
+  }
+  const float rq = 1.f / fmaxf(sqrtf(qq), 1e-8f);
+  const float rcpos = qvalid ? a.rnorm[pos_item] : 1.f;
+  const float cpos = pos_dot * rq * rcpos;
+  const float chinge = pos_dot * (1.f - a.margin);
+  const float sc2 = a.scale * kLog2e;
+  const float z2pos = pos_dot * sc2;
+  const bool mask_fn = a.mask_fn != 0, catalog = (a.mode == XFMR_NEG_CATALOG);
+  const int head = a.train_head;
+  const bool cos_head = head <= XFMR_LOSS_CONTRASTIVE;
+  const bool do_grad = a.need_grad && head != XFMR_LOSS_ALIGNMENT;
+
+  float cnt_d = 0.f, m = z2pos, l = 0.f, nce = 0.f, hinge = 0.f, logi = 0.f, cnt_c = 0.f, contr = 0.f;
+  float ssum = 0.f, ssq = 0.f, smin = INFINITY, smax = -INFINITY, sw = 0.f;
+  f32x16 o[H / 32];
+#pragma unroll
+  for (int i = 0; i < H / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+
+  // ---- tile staging -----------------------------------------------------------------------------
+  // lane -> (row pair rho = lane&3, 16-byte chunk c = lane>>2); wave w -> rows 8w..8w+7 of a 32-row block;
+  // pass p -> row block p&1, column block p>>1. ET writes then land 2-way conflicted at worst.
+  float4 pre[NPASS][2];
+  int pre_nid = -1;
+  float pre_rc = 0.f;
+  const int st_rho = lane & 3, st_c = lane >> 2;
+  auto item_of = [&](int j) -> int {
+    if (j >= N) return -1;
+    return catalog ? j : a.neg_item[j];
+  };
+  auto prefetch = [&](int tile) {
+    const int j0 = tile * BN;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int cc = (p >> 1) * 64 + st_c * 4;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = (p & 1) * 32 + wid * 8 + 2 * st_rho + u;
+        const int it = item_of(j0 + r);
+        pre[p][u] = it >= 0 ? *reinterpret_cast<const float4*>(a.table + (int64_t)it * H + cc)
+                            : make_float4(0, 0, 0, 0);
+      }
+    }
+    if (tid < BN) {
+      pre_nid = item_of(j0 + tid);
+      pre_rc = pre_nid >= 0 ? a.rnorm[pre_nid] : 0.f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int cc = (p >> 1) * 64 + st_c * 4;
+      const int r0 = (p & 1) * 32 + wid * 8 + 2 * st_rho;
+      xf_store4<P>(sE + r0 * LDE + cc, pre[p][0]);
+      xf_store4<P>(sE + (r0 + 1) * LDE + cc, pre[p][1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf_store2<P>(sET + (cc + j) * LDT + r0, xf_get(pre[p][0], j), xf_get(pre[p][1], j));
+    }
+    if (tid < BN) {
+      sNid[tid] = pre_nid;
+      sRc[tid] = pre_rc;
+    }
+  };
+
+  if (t_beg < t_end) prefetch(t_beg);
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + 1 < t_end) prefetch(tile + 1);
+
+#pragma unroll 1
+    for (int sb = 0; sb < BN / 32; ++sb) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      P::tile_nreg(s, sE, LDE, sb * 32, qreg.regs(), H);
+
+      // pass 1: tie handling, dot-family mask, block max for the online log-sum-exp
+      unsigned mdbits = 0, samebits = 0;
+      float bmax = m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = sb * 32 + xf_acc_row(r, lane);
+        const int nid = sNid[jl];
+        const bool valid = nid >= 0;
+        const bool same = nid == pos_item;
+        const float sv = same ? pos_dot : s[r];
+        s[r] = sv;
+        const bool md = valid && (mask_fn ? (sv < pos_dot) : true) && !(catalog && same);
+        mdbits |= (md ? 1u : 0u) << r;
+        samebits |= (same ? 1u : 0u) << r;
+        if (md) bmax = fmaxf(bmax, sv * sc2);
+      }
+      const bool want_lse = ALL || head == XFMR_LOSS_INFONCE;
+      float mnew = m;
+      if (want_lse) {
+        bmax = fmaxf(bmax, xf_half_swap(bmax));
+        mnew = bmax;  // >= m by construction
+        if (__any(mnew > m)) {
+          const float alpha = exp2f(m - mnew);
+          l *= alpha;
+          if (head == XFMR_LOSS_INFONCE) {
+#pragma unroll
+            for (int i = 0; i < H / 32; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            sw *= alpha;
+          }
+          m = mnew;
+        }
+      }
+      // pass 2: every head's row reductions + the train head's gradient weight (left in s[r])
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = sb * 32 + xf_acc_row(r, lane);
+        const float sv = s[r];
+        const bool md = (mdbits >> r) & 1u;
+        const float mdf = md ? 1.f : 0.f;
+        float w = 0.f;
+        cnt_d += mdf;
+        if (want_lse) {
+          const float e = md ? exp2f(sv * sc2 - m) : 0.f;
+          l += e;
+          if (head == XFMR_LOSS_INFONCE) w = e;
+        }
+        if (ALL || head == XFMR_LOSS_NCE) {
+          nce += md ? xf_softplus(sv) : 0.f;
+          if (head == XFMR_LOSS_NCE) w = md ? xf_sigmoid(sv) : 0.f;
+        }
+        if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE) {
+          const float d = sv - chinge;
+          hinge += md ? fmaxf(d, 0.f) : 0.f;
+          if (head == XFMR_LOSS_PAIRWISE_HINGE) w = (md && d > 0.f) ? 1.f : 0.f;
+        }
+        if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
+          const float d = sv - chinge;
+          logi += md ? xf_softplus(d) : 0.f;
+          if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md ? xf_sigmoid(d) : 0.f;
+        }
+        if (ALL || cos_head) {
+          const float rc = sRc[jl];
+          const bool same = (samebits >> r) & 1u;
+          const float c = same ? cpos : sv * rq * rc;
+          const bool valid = sNid[jl] >= 0;
+          const bool mc = valid && (mask_fn ? (c < cpos) : true) && !(catalog && same);
+          cnt_c += mc ? 1.f : 0.f;
+          const float d = c - 1.f + a.margin;
+          contr += mc ? fmaxf(d, 0.f) : 0.f;
+          if (head == XFMR_LOSS_CONTRASTIVE || head == XFMR_LOSS_ALIGNMENT_CONTRASTIVE)
+            w = (mc && d > 0.f) ? rc : 0.f;
+        }
+        if (ALL) {
+          ssum += md ? sv : 0.f;
+          ssq += md ? sv * sv : 0.f;
+          smin = md ? fminf(smin, sv) : smin;
+          smax = md ? fmaxf(smax, sv) : smax;
+        }
+        sw += w;
+        s[r] = w;
+      }
+      if (do_grad) {
+#pragma unroll
+        for (int i = 0; i < H / 32; ++i) P::tile_xb(o[i], sET, LDT, i * 32, sb * 32, s);
+      }
+    }
+  }
+
+  // ---- write the (split, query) partial -----------------------------------------------------------
+  cnt_d += xf_half_swap(cnt_d); l += xf_half_swap(l); nce += xf_half_swap(nce); hinge += xf_half_swap(hinge);
+  logi += xf_half_swap(logi); cnt_c += xf_half_swap(cnt_c); contr += xf_half_swap(contr);
+  ssum += xf_half_swap(ssum); ssq += xf_half_swap(ssq); sw += xf_half_swap(sw);
+  smin = fminf(smin, xf_half_swap(smin)); smax = fmaxf(smax, xf_half_swap(smax));
+  if (lane < 32 && qvalid) {
+    float* rec = a.part + ((int64_t)split * a.T + qi) * REC;
+    rec[R_CNTD] = cnt_d; rec[R_M] = m; rec[R_L] = l; rec[R_NCE] = nce; rec[R_HINGE] = hinge; rec[R_LOGI] = logi;
+    rec[R_CNTC] = cnt_c; rec[R_CONTR] = contr; rec[R_SSUM] = ssum; rec[R_SSQ] = ssq; rec[R_SMIN] = smin;
+    rec[R_SMAX] = smax; rec[R_SW] = sw; rec[R_POSDOT] = pos_dot; rec[R_RQ] = rq; rec[R_QQ] = qq;
+  }
+  if (do_grad) {
+    float* base = a.partO + (int64_t)split * a.T * H;
+#pragma unroll
+    for (int i = 0; i < H / 32; ++i)
+      xf_store_tile_T(sScratch + wid * 32 * 33, o[i], 1.f, base + i * 32, H, qb0 + wid * 32, Nq);
+  }
+}
+
+// ---- combine: one wave per query -----------------------------------------------------------------------
+struct CombineArgs {
+  const float* tok; const float* table; const float* rnorm;
+  const int* counts; const int* qrow; const int* qpos;
+  const float* part; const float* partO;
+  float* d_tok; double* blockpart;
+  int T, H, nsplit, train_head, need_grad, mode; int64_t n_rows;
+  float scale, margin;
+};
+
+__global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
+  __shared__ double sAcc[4][BP];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int Nq = a.counts[1];
+  const int N = (a.mode == XFMR_NEG_CATALOG) ? (int)a.n_rows : a.counts[0];
+  const int qi = blockIdx.x * 4 + wid;
+  const int H = a.H;
+  double acc[BP];
+#pragma unroll
+  for (int k = 0; k < BP; ++k) acc[k] = 0.0;
+  acc[20] = INFINITY; acc[21] = -INFINITY; acc[22] = INFINITY; acc[23] = -INFINITY;
+  if (qi < Nq) {
+    // merge the split partials (every lane computes the same scalars)
+    const float* r0 = a.part + (int64_t)qi * REC;
+    const float pos_dot = r0[R_POSDOT], rq = r0[R_RQ], qq = r0[R_QQ];
+    float M = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part[((int64_t)s * a.T + qi) * REC + R_M]);
+    float cnt_d = 0, l = 0, nce = 0, hinge = 0, logi = 0, cnt_c = 0, contr = 0, ssum = 0, ssq = 0, sw = 0;
+    float smin = INFINITY, smax = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) {
+      const float* r = a.part + ((int64_t)s * a.T + qi) * REC;
+      const float f = exp2f(r[R_M] - M);
+      cnt_d += r[R_CNTD]; l += r[R_L] * f; nce += r[R_NCE]; hinge += r[R_HINGE]; logi += r[R_LOGI];
+      cnt_c += r[R_CNTC]; contr += r[R_CONTR]; ssum += r[R_SSUM]; ssq += r[R_SSQ];
+      smin = fminf(smin, r[R_SMIN]); smax = fmaxf(smax, r[R_SMAX]);
+      sw += (a.train_head == XFMR_LOSS_INFONCE) ? r[R_SW] * f : r[R_SW];
+    }
+    const int pit = a.qpos[qi];
+    const float rcpos = a.rnorm[pit];
+    const float cpos = pos_dot * rq * rcpos;
+    const float sc2 = a.scale * kLog2e;
+    const float z2pos = pos_dot * sc2;
+    const float epos = exp2f(z2pos - M);  // M >= z2pos
+    const float ltot = l + epos;
+    const float inv_d = 1.f / (cnt_d + 1e-9f), inv_c = 1.f / (cnt_c + 1e-9f);
+    const float loss_align = 1.f - cpos;
+    const float loss_contr = contr * inv_c;
+    const float loss_info = (M + log2f(ltot)) * kLn2 - a.scale * pos_dot;
+    const float loss_nce = xf_softplus(-pos_dot) + nce * inv_d;
+    const float loss_hinge = hinge * inv_d, loss_logi = logi * inv_d;
+    acc[XFMR_LOSS_ALIGNMENT] = loss_align;
+    acc[XFMR_LOSS_ALIGNMENT_CONTRASTIVE] = loss_align + loss_contr;
+    acc[XFMR_LOSS_CONTRASTIVE] = loss_contr;
+    acc[XFMR_LOSS_INFONCE] = loss_info;
+    acc[XFMR_LOSS_NCE] = loss_nce;
+    acc[XFMR_LOSS_PAIRWISE_HINGE] = loss_hinge;
+    acc[XFMR_LOSS_PAIRWISE_LOGISTIC] = loss_logi;
+    acc[8] = (double)cnt_d / ((double)N + 1e-9);  // density term
+    acc[9] = pos_dot; acc[10] = (double)pos_dot * pos_dot;
+    acc[11] = ssum; acc[12] = ssq; acc[13] = cnt_d; acc[14] = 1.0;
+    acc[20] = pos_dot; acc[21] = pos_dot; acc[22] = smin; acc[23] = smax;
+
+    if (a.need_grad) {
+      const int head = a.train_head;
+      const int64_t row = a.qrow[qi];
+      const float* ep = a.table + (int64_t)pit * H;
+      const float* qp = a.tok + row * H;
+      float* dst = a.d_tok + row * H;
+      const bool cosh = head <= XFMR_LOSS_CONTRASTIVE;
+      // first pass for cosine heads: q_hat . dq_hat
+      float dotp = 0.f;
+      for (int c0 = 0; c0 < H; c0 += 64) {
+        const int c = c0 + lane;
+        if (c >= H) break;
+        float O = 0.f;
+        if (head != XFMR_LOSS_ALIGNMENT) {
+          for (int s = 0; s < a.nsplit; ++s) {
+            float v = a.partO[((int64_t)s * a.T + qi) * H + c];
+            if (head == XFMR_LOSS_INFONCE) v *= exp2f(a.part[((int64_t)s * a.T + qi) * REC + R_M] - M);
+            O += v;
+          }
+        }
+        const float e = ep[c];
+        float g;
+        switch (head) {
+          case XFMR_LOSS_INFONCE: g = a.scale * (O / ltot - (1.f - epos / ltot) * e); break;
+          case XFMR_LOSS_NCE: g = -xf_sigmoid(-pos_dot) * e + O * inv_d; break;
+          case XFMR_LOSS_PAIRWISE_HINGE:
+          case XFMR_LOSS_PAIRWISE_LOGISTIC: g = (O - (1.f - a.margin) * sw * e) * inv_d; break;
+          case XFMR_LOSS_ALIGNMENT: g = -rcpos * e; break;
+          case XFMR_LOSS_CONTRASTIVE: g = O * inv_c; break;
+          default: g = -rcpos * e + O * inv_c; break;  // ALIGNMENT_CONTRASTIVE
+        }
+        if (cosh) dotp += g * qp[c] * rq;
+        dst[c] = g;  // for cosine heads this is dq_hat, fixed up below
+      }
+      if (cosh) {
+        dotp = xf_wave_sum(dotp);
+        const bool clamped = sqrtf(qq) < 1e-8f;  // norm clamped: q_hat = q/eps, no projection term
+        for (int c = lane; c < H; c += 64) {
+          const float g = dst[c];
+          dst[c] = clamped ? g * rq : rq * (g - qp[c] * rq * dotp);
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < BP; ++k) sAcc[wid][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < BP) {
+    const int k = threadIdx.x;
+    double v;
+    if (k == 20 || k == 22) v = fmin(fmin(sAcc[0][k], sAcc[1][k]), fmin(sAcc[2][k], sAcc[3][k]));
+    else if (k == 21 || k == 23) v = fmax(fmax(sAcc[0][k], sAcc[1][k]), fmax(sAcc[2][k], sAcc[3][k]));
+    else v = sAcc[0][k] + sAcc[1][k] + sAcc[2][k] + sAcc[3][k];
+    a.blockpart[(int64_t)blockIdx.x * BP + k] = v;
+  }
+}
+
+// ---- final: deterministic reduction of the block partials ------------------------------------------------
+__global__ __launch_bounds__(256) void loss_final_kernel(const double* blockpart, int nblocks, const int* counts,
+                                                         int mode, int64_t n_rows, float* losses, float* stats) {
+  __shared__ double sRed[256];
+  const int Nq = counts[1];
+  const int N = (mode == XFMR_NEG_CATALOG) ? (int)n_rows : counts[0];
+  const int used = (Nq + 3) / 4;  // blocks that carried queries
+  __shared__ double tot[BP];
+  for (int k = 0; k < BP; ++k) {
+    const bool is_min = (k == 20 || k == 22), is_max = (k == 21 || k == 23);
+    double v = is_min ? INFINITY : is_max ? -INFINITY : 0.0;
+    for (int b = threadIdx.x; b < used && b < nblocks; b += 256) {
+      const double x = blockpart[(int64_t)b * BP + k];
+      v = is_min ? fmin(v, x) : is_max ? fmax(v, x) : v + x;
+    }
+    sRed[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) {
+        const double x = sRed[threadIdx.x + off];
+        sRed[threadIdx.x] = is_min ? fmin(sRed[threadIdx.x], x) : is_max ? fmax(sRed[threadIdx.x], x) : sRed[threadIdx.x] + x;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[k] = sRed[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < XFMR_NUM_LOSSES; ++k) losses[k] = (float)tot[k];
+    for (int k = 0; k < XFMR_NUM_STATS; ++k) stats[k] = 0.f;
+    const double nq = (double)Nq;
+    stats[XFMR_STAT_N_VALID] = (float)counts[0];
+    stats[XFMR_STAT_N_QUERY] = (float)Nq;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    stats[XFMR_STAT_NEG_DENSITY] = (float)(Nq > 0 ? tot[8] / nq : nan);
+    stats[XFMR_STAT_POS_MEAN] = (float)(Nq > 0 ? tot[9] / nq : nan);
+    stats[XFMR_STAT_POS_STD] = (float)(Nq > 1 ? sqrt(fmax(0.0, (tot[10] - tot[9] * tot[9] / nq) / (nq - 1.0))) : nan);
+    stats[XFMR_STAT_POS_MIN] = (float)(Nq > 0 ? tot[20] : nan);
+    stats[XFMR_STAT_POS_MAX] = (float)(Nq > 0 ? tot[21] : nan);
+    const double nn = tot[13];
+    stats[XFMR_STAT_NEG_COUNT] = (float)nn;
+    stats[XFMR_STAT_NEG_MEAN] = (float)(nn > 0 ? tot[11] / nn : nan);
+    stats[XFMR_STAT_NEG_STD] = (float)(nn > 1 ? sqrt(fmax(0.0, (tot[12] - tot[11] * tot[11] / nn) / (nn - 1.0))) : nan);
+    stats[XFMR_STAT_NEG_MIN] = (float)(nn > 0 ? tot[22] : nan);
+    stats[XFMR_STAT_NEG_MAX] = (float)(nn > 0 ? tot[23] : nan);
+    (void)N;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+struct Plan {
+  int nsplit;
+  size_t off_counts, off_neg, off_qrow, off_qpos, off_part, off_partO, off_block, total;
+  int nblocks;
+};
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+Plan make_plan(int64_t T, int H, int64_t n_rows) {
+  Plan p;
+  const int64_t qblocks = (T + QB - 1) / QB;
+  const int64_t cols = T > n_rows ? T : n_rows;
+  const int64_t tiles = (cols + BN - 1) / BN;
+  int64_t ns = (768 + qblocks - 1) / qblocks;
+  if (ns > 16) ns = 16;
+  if (ns > tiles) ns = tiles;
+  if (ns < 1) ns = 1;
+  p.nsplit = (int)ns;
+  p.nblocks = (int)((T + 3) / 4);
+  size_t o = 0;
+  p.off_counts = o; o += 256;
+  p.off_neg = o; o += up256((size_t)T * 4);
+  p.off_qrow = o; o += up256((size_t)T * 4);
+  p.off_qpos = o; o += up256((size_t)T * 4);
+  p.off_part = o; o += up256((size_t)ns * T * REC * 4);
+  p.off_partO = o; o += up256((size_t)ns * T * H * 4);
+  p.off_block = o; o += up256((size_t)p.nblocks * BP * 8);
+  p.total = o;
+  return p;
+}
+
+template <class P, int H>
+void launch_main(const LossArgs& a, bool all, dim3 grid, hipStream_t st) {
+  if (all) hipLaunchKernelGGL((loss_main_kernel<P, H, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((loss_main_kernel<P, H, false>), grid, dim3(256), 0, st, a);
+}
+template <class P>
+int launch_main_h(const LossArgs& a, int H, bool all, dim3 grid, hipStream_t st) {
+  switch (H) {
+    case 64: launch_main<P, 64>(a, all, grid, st); break;
+    case 128: launch_main<P, 128>(a, all, grid, st); break;
+    case 256: launch_main<P, 256>(a, all, grid, st); break;
+    default: return XFMR_EUNSUPPORTED;
+  }
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows) {
+  if (positions <= 0 || H <= 0) return 0;
+  return make_plan(positions, H, n_rows).total;
+}
+
+static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* table, const float* table_rnorm,
+                    int64_t n_rows, int T, int32_t H, float* losses, float* stats, float* d_tok, unsigned char* ws,
+                    const Plan& p, hipStream_t st) {
+  int* counts = (int*)(ws + p.off_counts);
+  int* neg_item = (int*)(ws + p.off_neg);
+  int* qrow = (int*)(ws + p.off_qrow);
+  int* qpos = (int*)(ws + p.off_qpos);
+  LossArgs a{};
+  a.tok = tok; a.table = table; a.rnorm = table_rnorm; a.n_rows = n_rows; a.counts = counts;
+  a.neg_item = cfg->mode == XFMR_NEG_SHARED ? neg_item : nullptr;
+  a.qrow = qrow; a.qpos = qpos; a.part = (float*)(ws + p.off_part); a.partO = (float*)(ws + p.off_partO);
+  a.T = T; a.nsplit = p.nsplit; a.train_head = cfg->train_head; a.mask_fn = cfg->mask_false_negatives;
+  a.mode = cfg->mode; a.need_grad = d_tok != nullptr; a.scale = cfg->scale; a.margin = cfg->margin;
+  dim3 grid((unsigned)((T + QB - 1) / QB), p.nsplit);
+  int rc;
+  if (cfg->precision == XFMR_PREC_BF16) rc = launch_main_h<PrecBF16>(a, H, cfg->all_heads != 0, grid, st);
+  else if (cfg->precision == XFMR_PREC_F32) rc = launch_main_h<PrecF32>(a, H, cfg->all_heads != 0, grid, st);
+  else rc = XFMR_EINVAL;
+  if (rc) return rc;
+
+  CombineArgs c{};
+  c.tok = tok; c.table = table; c.rnorm = table_rnorm; c.counts = counts; c.qrow = qrow; c.qpos = qpos;
+  c.part = a.part; c.partO = a.partO; c.d_tok = d_tok; c.blockpart = (double*)(ws + p.off_block);
+  c.T = T; c.H = H; c.nsplit = p.nsplit; c.train_head = cfg->train_head; c.need_grad = d_tok != nullptr;
+  c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, (const double*)c.blockpart, p.nblocks,
+                     (const int*)counts, cfg->mode, n_rows, losses, stats);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+static int check_loss_args(const xfmr_loss_cfg* cfg, const float* tok, const float* table, const float* rnorm,
+                           float* losses, float* stats, void* workspace, float* d_tok, int64_t rows, int64_t n_rows) {
+  if (!cfg || !tok || !table || !rnorm || !losses || !stats || !workspace) return XFMR_EINVAL;
+  if (rows <= 0 || n_rows <= 0 || rows > (1 << 30) || n_rows > (1 << 30)) return XFMR_EINVAL;
+  if (cfg->train_head < 0 || cfg->train_head >= XFMR_NUM_LOSSES) return XFMR_EINVAL;
+  if (!xf_aligned16(tok) || !xf_aligned16(table) || !xf_aligned16(workspace) || (d_tok && !xf_aligned16(d_tok)))
+    return XFMR_EALIGN;
+  return XFMR_OK;
+}
+
+int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
+                      const int64_t* neg_idx, const float* table, const float* table_rnorm, int64_t n_rows,
+                      int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (int rc = check_loss_args(cfg, tok, table, table_rnorm, losses, stats, workspace, d_tok, positions, n_rows))
+    return rc;
+  if (!key_mask || !pos_idx) return XFMR_EINVAL;
+  if (cfg->mode == XFMR_NEG_SHARED && !neg_idx) return XFMR_EINVAL;
+  const Plan p = make_plan(positions, H, n_rows);
+  if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  const int T = (int)positions;
+  hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(1024), 0, st, key_mask, pos_idx,
+                     cfg->mode == XFMR_NEG_SHARED ? neg_idx : (const int64_t*)nullptr, T, n_rows,
+                     (int*)(ws + p.off_counts), (int*)(ws + p.off_neg), (int*)(ws + p.off_qrow),
+                     (int*)(ws + p.off_qpos));
+  XF_LAUNCH_CHECK();
+  if (d_tok && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
+  return run_loss(cfg, tok, table, table_rnorm, n_rows, T, H, losses, stats, d_tok, ws, p, st);
+}
+
+size_t xfmr_sampled_loss_lists_workspace(int64_t n_query, int64_t n_neg, int32_t H, int64_t n_rows) {
+  const int64_t rows = n_query > n_neg ? n_query : n_neg;
+  if (rows <= 0 || H <= 0) return 0;
+  return make_plan(rows, H, n_rows).total;
+}
+
+int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const int64_t* pos_items,
+                            const int64_t* neg_items, int64_t n_query, int64_t n_neg, const float* table,
+                            const float* table_rnorm, int64_t n_rows, int32_t H, float* losses, float* stats,
+                            float* d_query, void* workspace, size_t workspace_bytes, void* stream) {
+  const int64_t rows = n_query > n_neg ? n_query : n_neg;
+  if (int rc = check_loss_args(cfg, query, table, table_rnorm, losses, stats, workspace, d_query, rows, n_rows))
+    return rc;
+  if (!pos_items || n_query <= 0) return XFMR_EINVAL;
+  if (cfg->mode == XFMR_NEG_SHARED && (!neg_items || n_neg <= 0)) return XFMR_EINVAL;
+  const Plan p = make_plan(rows, H, n_rows);
+  if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  const int T = (int)rows;
+  hipLaunchKernelGGL(prepare_lists_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, pos_items,
+                     cfg->mode == XFMR_NEG_SHARED ? neg_items : (const int64_t*)nullptr, (int)n_query,
+                     (int)(cfg->mode == XFMR_NEG_SHARED ? n_neg : 0), n_rows, (int*)(ws + p.off_counts),
+                     (int*)(ws + p.off_neg), (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
+  XF_LAUNCH_CHECK();
+  return run_loss(cfg, query, table, table_rnorm, n_rows, T, H, losses, stats, d_query, ws, p, st);
+}
+
+}  // extern "C"

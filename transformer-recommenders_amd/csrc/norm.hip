@@ -1,0 +1,406 @@
+// HBM-bound row kernels: item-embedding gather + BertEmbeddings LayerNorm, LayerNorm fwd/bwd,
+// embedding-parameter gradients, masked mean pooling, AdamW, per-item inverse norms.
+// One wavefront owns one row (H <= 1024): lanes stride the row in 4-byte steps, so every wave
+// instruction touches 256 contiguous bytes; row statistics are wave reductions, never LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxPerLane = 16;  // H <= 1024
+
+// ---- LayerNorm forward (optionally fused with the embedding gather) ---------------------------
+struct LnFwdArgs {
+  const float* x;          // [rows,H] input (when !GATHER)
+  const int64_t* idx;      // GATHER: item index per row
+  const float* table; int64_t n_rows;
+  const float* pos_emb; const float* type_emb; int L;
+  const float* gamma; const float* beta;
+  float* y; float* pre; float* mean; float* rstd; uint8_t* key_mask;
+  int64_t rows; int H; float eps;
+  XfDropout drop;
+};
+
+template <int NPL, bool GATHER>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  float v[NPL];
+  const int H = a.H;
+  if (GATHER) {
+    int64_t item = a.idx[row];
+    if (item < 0 || item >= a.n_rows) item = 0;
+    const float* src = a.table + item * H;
+    const float* pe = a.pos_emb + (int64_t)(row % a.L) * H;
+    bool nz = false;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      float e = 0.f;
+      if (c < H) {
+        e = src[c];
+        nz |= (e != 0.f);
+        e = (e + a.type_emb[c]) + pe[c];  // same association as TF:modeling_bert.py:100-104
+        a.pre[row * H + c] = e;
+      }
+      v[i] = e;
+    }
+    const bool any_nz = __any(nz);
+    if (lane == 0) a.key_mask[row] = any_nz ? 1 : 0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < H) ? a.x[row * H + c] : 0.f;
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) s += v[i];
+  const float mean = xf_wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int c = lane + 64 * i;
+    const float d = (c < H) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float var = xf_wave_sum(q) / (float)H;
+  const float rstd = rsqrtf(var + a.eps);
+  if (lane == 0) {
+    a.mean[row] = mean;
+    a.rstd[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < H) {
+      float o = (v[i] - mean) * rstd * a.gamma[c] + a.beta[c];
+      if (a.drop.on) o *= xf_keep_scale(a.drop, (uint32_t)(row * H + c));
+      a.y[row * H + c] = o;
+    }
+  }
+}
+
+// ---- LayerNorm backward --------------------------------------------------------------------------
+// dy is the gradient of the (possibly dropped-out, embedding site only) LayerNorm output.
+struct LnBwdArgs {
+  const float* dy; const float* x; const float* mean; const float* rstd; const float* gamma;
+  float* dx; float* d_lin; float* partials;  // partials [blocks][3][H]
+  int64_t rows; int H; int rows_per_block;
+  XfDropout drop_out;  // dropout that was applied to y itself (embedding site); off otherwise
+  XfDropout drop_lin;  // dropout of the Linear output feeding this LayerNorm's input
+};
+
+template <int NPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4][3][H]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int H = a.H;
+  float gam[NPL], dgam[NPL], dbet[NPL], dbias[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int c = lane + 64 * i;
+    gam[i] = (c < H) ? a.gamma[c] : 0.f;
+    dgam[i] = dbet[i] = dbias[i] = 0.f;
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  const int64_t r1 = (r0 + a.rows_per_block < a.rows) ? r0 + a.rows_per_block : a.rows;
+  for (int64_t row = r0 + wid; row < r1; row += 4) {
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    float xh[NPL], g[NPL];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      float dyv = 0.f, xv = 0.f;
+      if (c < H) {
+        dyv = a.dy[row * H + c];
+        if (a.drop_out.on) dyv *= xf_keep_scale(a.drop_out, (uint32_t)(row * H + c));
+        xv = (a.x[row * H + c] - mean) * rstd;
+      }
+      xh[i] = xv;
+      g[i] = dyv * gam[i];
+      dgam[i] += dyv * xv;
+      dbet[i] += dyv;
+      sg += g[i];
+      sgx += g[i] * xv;
+    }
+    const float mg = xf_wave_sum(sg) / (float)H;
+    const float mgx = xf_wave_sum(sgx) / (float)H;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < H) {
+        const float d = rstd * (g[i] - mg - xh[i] * mgx);
+        a.dx[row * H + c] = d;
+        float dl = d;
+        if (a.drop_lin.on) {
+          dl = d * xf_keep_scale(a.drop_lin, (uint32_t)(row * H + c));
+          a.d_lin[row * H + c] = dl;
+        }
+        dbias[i] += dl;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < H) {
+      smem[(wid * 3 + 0) * H + c] = dgam[i];
+      smem[(wid * 3 + 1) * H + c] = dbet[i];
+      smem[(wid * 3 + 2) * H + c] = dbias[i];
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 3 * H; o += 256) {
+    const float s = smem[o] + smem[3 * H + o] + smem[6 * H + o] + smem[9 * H + o];
+    a.partials[(int64_t)blockIdx.x * 3 * H + o] = s;
+  }
+}
+
+// sums `blocks` partial records [blocks][3][H] into up to three destinations
+__global__ void ln_bwd_reduce_kernel(const float* partials, int blocks, int H, float* d_gamma, float* d_beta,
+                                     float* d_bias) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= 3 * H) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += partials[(int64_t)b * 3 * H + o];
+  const int which = o / H, c = o % H;
+  float* dst = which == 0 ? d_gamma : which == 1 ? d_beta : d_bias;
+  if (dst) dst[c] = s;
+}
+
+// d_pos[t,c] = sum_b d_pre[b,t,c]  (t < L), 0 for L <= t < max_pos
+__global__ void embed_pos_grad_kernel(const float* d_pre, float* d_pos, int B, int L, int H, int max_pos) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (c >= H) return;
+  float s = 0.f;
+  if (t < L)
+    for (int b = 0; b < B; ++b) s += d_pre[((int64_t)b * L + t) * H + c];
+  d_pos[(int64_t)t * H + c] = s;
+}
+__global__ void embed_type_grad_kernel(const float* d_pos, float* d_type, int L, int H) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float s = 0.f;
+  for (int t = 0; t < L; ++t) s += d_pos[(int64_t)t * H + c];
+  d_type[c] = s;
+  d_type[H + c] = 0.f;
+}
+
+__global__ void mean_pool_kernel(const float* tok, const uint8_t* mask, float* out, int L, int H) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float s = 0.f, n = 0.f;
+  for (int t = 0; t < L; ++t) {
+    const float m = mask[(int64_t)b * L + t] ? 1.f : 0.f;
+    s += tok[((int64_t)b * L + t) * H + c] * m;
+    n += m;
+  }
+  out[(int64_t)b * H + c] = s / fmaxf(n, 1e-9f);
+}
+
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    float4 pp = *reinterpret_cast<float4*>(p + i);
+    const float4 gg = *reinterpret_cast<const float4*>(g + i);
+    float4 mm = *reinterpret_cast<float4*>(m + i);
+    float4 vv = *reinterpret_cast<float4*>(v + i);
+    float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = ga[j] * gscale;
+      float pj = pa[j] * (1.f - lr * wd);
+      ma[j] = b1 * ma[j] + (1.f - b1) * gr;
+      va[j] = b2 * va[j] + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(va[j]) / bc2_sqrt + eps;
+      pa[j] = pj - (lr / bc1) * (ma[j] / denom);
+    }
+    *reinterpret_cast<float4*>(p + i) = pp;
+    *reinterpret_cast<float4*>(m + i) = mm;
+    *reinterpret_cast<float4*>(v + i) = vv;
+  } else {
+    for (int64_t k = i; k < n; ++k) {
+      const float gr = g[k] * gscale;
+      float pj = p[k] * (1.f - lr * wd);
+      m[k] = b1 * m[k] + (1.f - b1) * gr;
+      v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(v[k]) / bc2_sqrt + eps;
+      p[k] = pj - (lr / bc1) * (m[k] / denom);
+    }
+  }
+}
+
+__global__ void scale_kernel(float* x, int64_t n, const float* s) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= s[0];
+}
+
+__global__ void table_rnorm_kernel(const float* table, float* out, int64_t rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < H; c += 64) {
+    const float e = table[row * H + c];
+    s += e * e;
+  }
+  s = xf_wave_sum(s);
+  if (lane == 0) out[row] = 1.f / fmaxf(sqrtf(s), 1e-8f);
+}
+
+int npl_of(int H) { return (H + 63) / 64; }
+
+template <bool GATHER>
+int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
+  const int npl = npl_of(a.H);
+  if (npl <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, GATHER>), grid, block, 0, st, a);
+  else if (npl <= 2) hipLaunchKernelGGL((ln_fwd_kernel<2, GATHER>), grid, block, 0, st, a);
+  else if (npl <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, GATHER>), grid, block, 0, st, a);
+  else if (npl <= 8) hipLaunchKernelGGL((ln_fwd_kernel<8, GATHER>), grid, block, 0, st, a);
+  else if (npl <= kMaxPerLane) hipLaunchKernelGGL((ln_fwd_kernel<16, GATHER>), grid, block, 0, st, a);
+  else return XFMR_EUNSUPPORTED;
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int ln_bwd_blocks(int64_t rows, int* rows_per_block) {
+  int64_t blocks = (rows + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  int64_t rpb = (rows + blocks - 1) / blocks;
+  rpb = ((rpb + 3) / 4) * 4;
+  *rows_per_block = (int)rpb;
+  return (int)((rows + rpb - 1) / rpb);
+}
+
+}  // namespace
+
+extern "C" {
+
+int xfmr_embed_ln_fwd(const int64_t* item_idx, const float* table, int64_t n_rows, const float* pos_emb,
+                      const float* type_emb, const float* gamma, const float* beta, float* out, float* pre,
+                      float* mean, float* rstd, uint8_t* key_mask, int32_t B, int32_t L, int32_t H, float eps,
+                      float dropout_p, uint64_t seed, uint32_t site, void* stream) {
+  if (!item_idx || !table || !pos_emb || !type_emb || !gamma || !beta || !out || !pre || !mean || !rstd || !key_mask)
+    return XFMR_EINVAL;
+  if (B <= 0 || L <= 0 || H <= 0 || n_rows <= 0) return XFMR_EINVAL;
+  LnFwdArgs a{};
+  a.x = nullptr; a.idx = item_idx; a.table = table; a.n_rows = n_rows; a.pos_emb = pos_emb; a.type_emb = type_emb;
+  a.L = L; a.gamma = gamma; a.beta = beta; a.y = out; a.pre = pre; a.mean = mean; a.rstd = rstd;
+  a.key_mask = key_mask; a.rows = (int64_t)B * L; a.H = H; a.eps = eps;
+  a.drop = xf_make_dropout(dropout_p, seed, site);
+  return launch_ln_fwd<true>(a, (hipStream_t)stream);
+}
+
+int xfmr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int64_t rows, int32_t H, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || H <= 0) return XFMR_EINVAL;
+  LnFwdArgs a{};
+  a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.rows = rows; a.H = H;
+  a.eps = eps; a.L = 1;
+  a.drop = xf_make_dropout(0.f, 0, 0);
+  return launch_ln_fwd<false>(a, (hipStream_t)stream);
+}
+
+size_t xfmr_layernorm_bwd_workspace(int64_t rows, int32_t H) {
+  int rpb;
+  return (size_t)ln_bwd_blocks(rows, &rpb) * 3 * (size_t)H * sizeof(float);
+}
+
+// Internal variant that also takes the dropout applied to the LayerNorm OUTPUT (embedding site).
+int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          float* dx, float* d_lin, float* d_gamma, float* d_beta, float* d_bias, int64_t rows,
+                          int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials, hipStream_t st) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !partials || rows <= 0 || H <= 0) return XFMR_EINVAL;
+  if (drop_lin.on && !d_lin) return XFMR_EINVAL;
+  LnBwdArgs a{};
+  a.dy = dy; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.dx = dx; a.d_lin = d_lin;
+  a.partials = (float*)partials; a.rows = rows; a.H = H;
+  const int blocks = ln_bwd_blocks(rows, &a.rows_per_block);
+  a.drop_out = drop_out; a.drop_lin = drop_lin;
+  const size_t shmem = (size_t)12 * H * sizeof(float);
+  const int npl = npl_of(H);
+  dim3 grid(blocks), block(256);
+  if (npl <= 1) hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, block, shmem, st, a);
+  else if (npl <= 2) hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, block, shmem, st, a);
+  else if (npl <= 4) hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, shmem, st, a);
+  else if (npl <= 8) hipLaunchKernelGGL((ln_bwd_kernel<8>), grid, block, shmem, st, a);
+  else if (npl <= kMaxPerLane) hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, shmem, st, a);
+  else return XFMR_EUNSUPPORTED;
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * H + 255) / 256), dim3(256), 0, st, (const float*)partials,
+                     blocks, H, d_gamma, d_beta, d_bias);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int xfmr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       float* dx, float* d_lin, float* d_gamma, float* d_beta, float* d_bias, int64_t rows,
+                       int32_t H, float dropout_p, uint64_t seed, uint32_t site, void* partials, void* stream) {
+  return xf_layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, d_lin, d_gamma, d_beta, d_bias, rows, H,
+                               xf_make_dropout(0.f, 0, 0), xf_make_dropout(dropout_p, seed, site), partials,
+                               (hipStream_t)stream);
+}
+
+int xfmr_embed_param_grads(const float* d_pre, float* d_pos, float* d_type, int32_t B, int32_t L, int32_t H,
+                           int32_t max_pos, void* stream) {
+  if (!d_pre || !d_pos || !d_type || B <= 0 || L <= 0 || H <= 0 || max_pos < L) return XFMR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_pos_grad_kernel, dim3((H + 63) / 64, max_pos), dim3(64), 0, st, d_pre, d_pos, B, L, H,
+                     max_pos);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(embed_type_grad_kernel, dim3((H + 63) / 64), dim3(64), 0, st, (const float*)d_pos, d_type, L, H);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int xfmr_mean_pool(const float* tok, const uint8_t* key_mask, float* out, int32_t B, int32_t L, int32_t H,
+                   void* stream) {
+  if (!tok || !key_mask || !out || B <= 0 || L <= 0 || H <= 0) return XFMR_EINVAL;
+  hipLaunchKernelGGL(mean_pool_kernel, dim3((H + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, tok, key_mask, out,
+                     L, H);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int xfmr_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+               float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+               void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return XFMR_EINVAL;
+  if (!xf_aligned16(params) || !xf_aligned16(grads) || !xf_aligned16(exp_avg) || !xf_aligned16(exp_avg_sq))
+    return XFMR_EALIGN;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int64_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                     (float)sqrt(bc2), grad_scale);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int xfmr_scale_by_device_scalar(float* x, int64_t n, const float* scalar, void* stream) {
+  if (!x || !scalar || n <= 0) return XFMR_EINVAL;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+                     scalar);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int xfmr_table_rnorm(const float* table, float* table_rnorm, int64_t n_rows, int32_t H, void* stream) {
+  if (!table || !table_rnorm || n_rows <= 0 || H <= 0) return XFMR_EINVAL;
+  hipLaunchKernelGGL(table_rnorm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     table, table_rnorm, n_rows, H);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+"""ctypes binding of ``libxfmr_hip.so`` (C ABI declared in ``include/xfmr_hip.h``).
+
+There is no CPU fallback: every op in this package goes through this library. If the shared object is
+missing, cannot be loaded, or a tensor is not on a HIP device, the call raises -- it never silently
+computes with PyTorch instead.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+
+import torch
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libxfmr_hip.so"
+
+PREC_F32, PREC_BF16 = 0, 1
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES = 0, 1, 2
+NEG_SHARED, NEG_CATALOG = 0, 1
+NUM_LOSSES, NUM_STATS = 7, 16
+LOSS_IDS = {
+    "AlignmentLoss": 0,
+    "AlignmentContrastiveLoss": 1,
+    "ContrastiveLoss": 2,
+    "InfoNCELoss": 3,
+    "NCELoss": 4,
+    "PairwiseHingeLoss": 5,
+    "PairwiseLogisticLoss": 6,
+}
+STAT = dict(
+    n_valid=0, n_query=1, neg_density=2, pos_mean=3, pos_std=4, pos_min=5, pos_max=6,
+    neg_mean=7, neg_std=8, neg_min=9, neg_max=10, neg_count=11,
+)
+
+
+class EncoderCfg(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("seq_len", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
+        ("inter", C.c_int32), ("layers", C.c_int32), ("max_pos", C.c_int32), ("precision", C.c_int32),
+        ("ln_eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float),
+        ("reserved", C.c_uint32), ("seed", C.c_uint64),
+    ]
+
+
+class LossCfg(C.Structure):
+    _fields_ = [
+        ("train_head", C.c_int32), ("all_heads", C.c_int32), ("mask_false_negatives", C.c_int32),
+        ("mode", C.c_int32), ("precision", C.c_int32), ("scale", C.c_float), ("margin", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "xfmr_strerror": (C.c_char_p, [C.c_int]),
+    "xfmr_abi_version": (C.c_int, []),
+    "xfmr_param_count": (C.c_int64, [C.POINTER(EncoderCfg)]),
+    "xfmr_param_offsets": (C.c_int32, [C.POINTER(EncoderCfg), C.POINTER(C.c_int64), C.c_int32]),
+    "xfmr_embed_ln_fwd": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    "xfmr_embed_param_grads": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "xfmr_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "xfmr_layernorm_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "xfmr_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float,
+                                     C.c_uint64, C.c_uint32, _P, _P]),
+    "xfmr_linear_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_float,
+                                  C.c_uint64, C.c_uint32, C.c_int32, _P]),
+    "xfmr_linear_bwd_dx": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
+    "xfmr_linear_bwd_dw_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "xfmr_linear_bwd_dw": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
+    "xfmr_colsum_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "xfmr_colsum": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
+    "xfmr_attn_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
+                                C.c_uint32, C.c_int32, _P]),
+    "xfmr_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                C.c_uint64, C.c_uint32, C.c_int32, _P]),
+    "xfmr_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderCfg)]),
+    "xfmr_encoder_fwd": (C.c_int, [C.POINTER(EncoderCfg), _P, _P, _P, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
+    "xfmr_encoder_bwd": (C.c_int, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "xfmr_mean_pool": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "xfmr_sampled_loss_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int64]),
+    "xfmr_sampled_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32,
+                                    _P, _P, _P, _P, C.c_size_t, _P]),
+    "xfmr_sampled_loss_lists_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int64]),
+    "xfmr_sampled_loss_lists": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, C.c_int64, C.c_int64, _P, _P, C.c_int64,
+                                          C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "xfmr_table_rnorm": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "xfmr_adamw": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                             C.c_int64, C.c_float, _P]),
+    "xfmr_scale_by_device_scalar": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "xfmr_selftest_mfma": (C.c_int, [_P, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library once. ``torch`` is imported first so that its bundled HIP runtime
+    (same soname ``libamdhip64.so.7``) is the one the library binds to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C transformer-recommenders_amd/csrc`). There is no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.xfmr_abi_version() != 1:
+        raise NativeLibraryError("libxfmr_hip.so ABI version mismatch: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().xfmr_strerror(rc).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    """Device pointer of a contiguous HIP tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(
+            "xfmr_rec_amd ops run only on a HIP device (MI355X); got a CPU tensor. There is no CPU fallback."
+        )
+    if not t.is_contiguous():
+        raise RuntimeError("xfmr_rec_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def precision_id(p) -> int:
+    if isinstance(p, int):
+        return p
+    try:
+        return PRECISIONS[str(p).lower()]
+    except KeyError:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}; got {p!r}") from None

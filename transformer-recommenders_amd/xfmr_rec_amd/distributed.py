@@ -1,0 +1,44 @@
+"""Data-parallel glue: one process per GPU, sequences sharded by rank, ONE collective per step.
+
+The reference reaches data parallelism implicitly (Lightning ``strategy: auto`` -> torch DDP,
+``config.yaml:5-6,35``): bucketed gradient all-reduce (SUM, then / world) and a ``DistributedSampler``.
+Here every trainable tensor and its gradient live in one flat buffer, so the exchange is a single
+``all_reduce`` over RCCL/xGMI (3.1 MiB at the MovieLens-1M config: latency-bound, one message beats
+buckets) and the 1/world factor is folded into the fused AdamW launch. The item table is frozen and
+replicated; negatives stay rank-local exactly as under the reference's DDP.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """(rank, local_rank, world). RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from torchrun."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> range:
+    """Rows of the epoch owned by ``rank`` (DistributedSampler without shuffling: rank::world)."""
+    return range(rank, n_rows, world)
+
+
+def allreduce_flat_grad_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
+    """SUM all-reduce of the flat gradient in place (the only collective of a training step)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return flat_grad

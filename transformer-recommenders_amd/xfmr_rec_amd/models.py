@@ -1,0 +1,322 @@
+"""``RecommenderModel``: host-side mirror of the reference's ``xfmr_rec/models.py`` over the HIP encoder.
+
+Keeps the reference's surface -- ``ModelConfig`` fields/defaults (``models.py:22-48``),
+``configure_embeddings``, ``forward(item_idx=None, *, item_embeds=None)``, ``compute_embeds``, ``encode``,
+``save`` / ``load``, properties ``device`` / ``max_seq_length`` (``models.py:176-419``) -- while the compute
+(gather + mask + BERT stack, fwd and bwd) runs in ``libxfmr_hip.so``.
+
+Differences that are deliberate and visible:
+
+* The encoder is not a HuggingFace/sentence-transformers object. All trainable tensors live in one flat
+  fp32 ``nn.Parameter`` (``self.flat``); ``encoder_state_dict()`` exposes them under the HF BERT key names
+  the reference checkpoints use, and ``load_encoder_state_dict()`` takes the same.
+  ``word_embeddings`` / ``pooler`` never receive a gradient in the reference and are not created.
+* Nothing is fetched from the network: ``hidden_size`` etc. must be given (the reference resolves ``None``
+  from a pretrained model download, ``models.py:85-91``).
+* ``compute_embeds`` returns the candidates structured (:class:`~xfmr_rec_amd.losses.SharedNegatives`)
+  rather than as the materialised ``(Np, 1+N, H)`` tensor.
+"""
+
+from __future__ import annotations
+
+import json
+import pathlib
+from typing import Literal
+
+import pydantic
+import torch
+
+from . import _native as N
+from . import ops
+from .losses import SharedNegatives
+from .params import (
+    ATTENTION_PROBS_DROPOUT_PROB,
+    HIDDEN_DROPOUT_PROB,
+    INITIALIZER_RANGE,
+    LAYER_NORM_EPS,
+    PRETRAINED_MODEL_NAME,
+)
+
+
+class ModelConfig(pydantic.BaseModel):
+    """Same fields and defaults as the reference (``models.py:22-48``)."""
+
+    vocab_size: int | None = 1
+    hidden_size: int | None = None
+    num_hidden_layers: int | None = 1
+    num_attention_heads: int | None = 12
+    intermediate_size: int | None = 48
+    max_seq_length: int | None = 32
+    is_decoder: bool = True
+
+    pretrained_model_name: str = PRETRAINED_MODEL_NAME
+    pooling_mode: Literal["mean", "max", "cls", "lasttoken"] = "mean"
+    is_normalized: bool = False
+
+
+def encoder_param_names(num_layers: int) -> list[str]:
+    """HF BERT state_dict keys in the order of the flat buffer (``include/xfmr_hip.h``)."""
+    names = [
+        "embeddings.position_embeddings.weight",
+        "embeddings.token_type_embeddings.weight",
+        "embeddings.LayerNorm.weight",
+        "embeddings.LayerNorm.bias",
+    ]
+    for i in range(num_layers):
+        p = f"encoder.layer.{i}."
+        names += [p + f"attention.self.{n}.weight" for n in ("query", "key", "value")]
+        names += [p + f"attention.self.{n}.bias" for n in ("query", "key", "value")]
+        names += [
+            p + "attention.output.dense.weight", p + "attention.output.dense.bias",
+            p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias",
+            p + "intermediate.dense.weight", p + "intermediate.dense.bias",
+            p + "output.dense.weight", p + "output.dense.bias",
+            p + "output.LayerNorm.weight", p + "output.LayerNorm.bias",
+        ]
+    return names
+
+
+def encoder_param_shapes(H: int, I: int, max_pos: int, num_layers: int) -> list[tuple[int, ...]]:
+    shapes: list[tuple[int, ...]] = [(max_pos, H), (2, H), (H,), (H,)]
+    for _ in range(num_layers):
+        shapes += [(H, H)] * 3 + [(H,)] * 3 + [(H, H), (H,), (H,), (H,), (I, H), (I,), (H, I), (H,), (H,), (H,)]
+    return shapes
+
+
+def flat_layout(H: int, I: int, max_pos: int, num_layers: int):
+    """(names, shapes, offsets, total): pure-Python twin of ``xfmr_param_offsets`` (checked in the tests)."""
+    names = encoder_param_names(num_layers)
+    shapes = encoder_param_shapes(H, I, max_pos, num_layers)
+    offsets, o = [], 0
+    for s in shapes:
+        offsets.append(o)
+        n = 1
+        for d in s:
+            n *= d
+        o += n
+    return names, shapes, offsets, o
+
+
+class RecommenderModel(torch.nn.Module):
+    def __init__(
+        self,
+        config: ModelConfig,
+        *,
+        device: torch.device | str | None = None,
+        model=None,
+        precision: str = "bf16",
+        seed: int = 0,
+    ) -> None:
+        """``model`` (a pre-built sentence-transformers object in the reference, ``models.py:177-199``) may be
+        an HF-keyed state dict here; ``precision`` selects the MFMA arithmetic ("bf16" or "fp32")."""
+        super().__init__()
+        self.config = config
+        self.precision = precision
+        self.embeddings: torch.Tensor | None = None  # frozen (V+1, H) table, row 0 = padding
+        self.table_rnorm: torch.Tensor | None = None
+        self.id2idx = None
+        self._step = 0
+        self._seed = int(seed)
+        self.configure_model(device=device, seed=seed)
+        if model is not None:
+            self.load_encoder_state_dict(model)
+
+    # ------------------------------------------------------------------ construction
+    def configure_model(self, device=None, seed: int = 0) -> None:
+        c = self.config
+        missing = [k for k in ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
+                               "max_seq_length") if getattr(c, k) is None]
+        if missing:
+            raise ValueError(
+                f"ModelConfig fields {missing} are None: the reference resolves them by downloading "
+                f"{c.pretrained_model_name!r} (models.py:69-91); this build is offline -- set them explicitly"
+            )
+        if not c.is_decoder:
+            raise NotImplementedError("only the causal encoder (is_decoder=True, the reference default) is built")
+        if c.hidden_size != 32 * c.num_attention_heads:
+            raise ValueError(
+                f"hidden_size / num_attention_heads must be 32 (got {c.hidden_size}/{c.num_attention_heads}): "
+                "the gfx950 attention kernels are built for head size 32 (the reference's 384/12)"
+            )
+        H, I, Lm, nL = c.hidden_size, c.intermediate_size, c.max_seq_length, c.num_hidden_layers
+        names, shapes, offsets, total = flat_layout(H, I, Lm, nL)
+        self._names, self._shapes, self._offsets = names, shapes, offsets
+        g = torch.Generator().manual_seed(seed)
+        flat = torch.zeros(total, dtype=torch.float32)
+        for name, shape, off in zip(names, shapes, offsets):
+            n = int(torch.tensor(shape).prod())
+            if "LayerNorm.weight" in name:
+                flat[off : off + n] = 1.0
+            elif name.endswith(".weight"):  # HF BERT init: N(0, initializer_range); biases / LN bias = 0
+                flat[off : off + n] = torch.randn(n, generator=g) * INITIALIZER_RANGE
+        self.flat = torch.nn.Parameter(flat.to(device) if device is not None else flat)
+
+    @property
+    def device(self) -> torch.device:
+        return self.flat.device
+
+    @property
+    def max_seq_length(self) -> int:
+        return int(self.config.max_seq_length)
+
+    def encoder_state_dict(self) -> dict[str, torch.Tensor]:
+        """HF-BERT-keyed views into the flat buffer (the reference's checkpoint keys sit under
+        ``model.model.0.auto_model.``: SURVEY section 5)."""
+        out = {}
+        for name, shape, off in zip(self._names, self._shapes, self._offsets):
+            n = int(torch.tensor(shape).prod())
+            out[name] = self.flat.detach()[off : off + n].view(shape)
+        return out
+
+    def load_encoder_state_dict(self, state: dict[str, torch.Tensor], strict: bool = True) -> None:
+        views = self.encoder_state_dict()
+        missing = [k for k in views if k not in state]
+        if strict and missing:
+            raise KeyError(f"missing encoder tensors: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        with torch.no_grad():
+            for k, v in views.items():
+                if k in state:
+                    v.copy_(torch.as_tensor(state[k]).to(v.device, torch.float32).reshape(v.shape))
+
+    def grad_state_dict(self) -> dict[str, torch.Tensor]:
+        if self.flat.grad is None:
+            return {}
+        out = {}
+        for name, shape, off in zip(self._names, self._shapes, self._offsets):
+            n = int(torch.tensor(shape).prod())
+            out[name] = self.flat.grad[off : off + n].view(shape)
+        return out
+
+    def configure_embeddings(self, items_dataset) -> None:
+        """Frozen item table with a zero padding row + ``id2idx`` (``models.py:234-259``).
+
+        ``items_dataset``: a ``datasets.Dataset`` with ``embedding`` / ``item_id`` columns as in the
+        reference, or any mapping with those two keys (arrays)."""
+        if self.embeddings is None:
+            if hasattr(items_dataset, "with_format"):
+                weights = items_dataset.with_format("torch")["embedding"][:]
+            else:
+                weights = torch.as_tensor(items_dataset["embedding"])
+            weights = weights.to(torch.float32)
+            if weights.shape[1] != self.config.hidden_size:
+                raise ValueError(
+                    f"item embedding width {weights.shape[1]} != hidden_size {self.config.hidden_size}: "
+                    "embeddings enter the encoder as inputs_embeds without projection (models.py:336-345)"
+                )
+            table = torch.cat([torch.zeros_like(weights[:1]), weights]).contiguous().to(self.device)
+            self.set_table(table)
+        if self.id2idx is None:
+            if hasattr(items_dataset, "with_format"):
+                ids = list(items_dataset.with_format("pandas")["item_id"].array)
+            else:
+                ids = list(items_dataset["item_id"])
+            try:
+                import pandas as pd
+
+                self.id2idx = pd.Series(pd.RangeIndex(len(ids)) + 1, index=ids)
+            except ImportError:  # pragma: no cover
+                self.id2idx = {k: i + 1 for i, k in enumerate(ids)}
+
+    def set_table(self, table: torch.Tensor) -> None:
+        """Install a ready ``(V+1, H)`` table (row 0 = padding)."""
+        self.embeddings = table.contiguous()
+        self.table_rnorm = ops.table_rnorm(self.embeddings) if table.is_cuda else None
+
+    # ------------------------------------------------------------------ compute
+    def _cfg(self, B: int, L: int) -> N.EncoderCfg:
+        c = self.config
+        train = self.training
+        return ops.make_encoder_cfg(
+            batch=B, seq_len=L, hidden=c.hidden_size, heads=c.num_attention_heads, inter=c.intermediate_size,
+            layers=c.num_hidden_layers, max_pos=c.max_seq_length, precision=self.precision, ln_eps=LAYER_NORM_EPS,
+            hidden_dropout=HIDDEN_DROPOUT_PROB if train else 0.0,
+            attn_dropout=ATTENTION_PROBS_DROPOUT_PROB if train else 0.0,
+            seed=(self._seed * 0x9E3779B97F4A7C15 + self._step) & 0xFFFFFFFFFFFFFFFF,
+        )
+
+    def _encode_tokens(self, item_idx=None, item_embeds=None):
+        assert self.embeddings is not None, "call configure_embeddings() first"
+        if item_embeds is not None:
+            # the gather kernel reads rows by index: use the given embeddings as the table
+            x = item_embeds[:, -self.max_seq_length :, :].to(self.device, torch.float32).contiguous()
+            B, L, H = x.shape
+            table = x.view(B * L, H)
+            idx = torch.arange(B * L, device=self.device, dtype=torch.int64).view(B, L)
+        elif item_idx is not None:
+            idx = item_idx[:, -self.max_seq_length :].to(self.device, torch.int64).contiguous()
+            table = self.embeddings
+            B, L = idx.shape
+        else:
+            msg = "either `item_idx` or `item_embeds` must be provided"
+            raise ValueError(msg)
+        if self.training:
+            self._step += 1
+        tok, key_mask = ops.EncoderFunction.apply(self.flat, idx, table, self._cfg(B, L))
+        return tok, key_mask
+
+    def forward(self, item_idx=None, *, item_embeds=None) -> dict[str, torch.Tensor]:
+        """``models.py:306-345``: returns token_embeddings (B,L,H), sentence_embedding (B,H), attention_mask."""
+        tok, key_mask = self._encode_tokens(item_idx, item_embeds)
+        if self.config.pooling_mode != "mean":
+            raise NotImplementedError("only pooling_mode='mean' (the reference default) is built")
+        with torch.no_grad():
+            sent = ops.mean_pool(tok.detach(), key_mask)
+        if self.config.is_normalized:
+            raise NotImplementedError("is_normalized=True is not built yet")
+        return {"token_embeddings": tok, "sentence_embedding": sent, "attention_mask": key_mask.long()}
+
+    def encode(self, item_ids: list[str]) -> torch.Tensor:
+        """Pooled embedding of a list of item ids; unknown ids are dropped (``models.py:347-364``)."""
+        assert self.id2idx is not None
+        known = [i for i in item_ids if i in self.id2idx.index] if hasattr(self.id2idx, "index") else [
+            i for i in item_ids if i in self.id2idx
+        ]
+        vals = self.id2idx[known].to_numpy() if hasattr(self.id2idx, "index") else [self.id2idx[i] for i in known]
+        item_idx = torch.as_tensor(vals, device=self.device, dtype=torch.int64)
+        return self(item_idx[None, :])["sentence_embedding"][0]
+
+    def compute_embeds(self, history_item_idx, pos_item_idx, neg_item_idx) -> dict:
+        """``models.py:366-419``. ``query_embed`` is the compacted ``(Np, H)`` tensor (this needs the row count
+        on the host, as the reference's boolean indexing does); ``candidate_embed`` is structured."""
+        if self.config.is_normalized:
+            raise NotImplementedError("is_normalized=True is not built yet")
+        tok, key_mask = self._encode_tokens(history_item_idx)
+        am = key_mask.bool()
+        pos = pos_item_idx.to(self.device)[am]
+        neg = neg_item_idx.to(self.device)[am]
+        keep = pos != 0
+        query = tok[am][keep]
+        cand = SharedNegatives(self.embeddings, self.table_rnorm, pos[keep], neg)
+        return {"query_embed": query, "candidate_embed": cand, "attention_mask": am, "positive_mask": keep}
+
+    # ------------------------------------------------------------------ persistence
+    def save(self, path: str) -> None:
+        """Writes ``config.json`` + ``model.safetensors`` with HF BERT keys (``models.py:261-269``)."""
+        from safetensors.torch import save_file
+
+        p = pathlib.Path(path)
+        p.mkdir(parents=True, exist_ok=True)
+        save_file({k: v.contiguous().cpu() for k, v in self.encoder_state_dict().items()}, str(p / "model.safetensors"))
+        c = self.config
+        (p / "config.json").write_text(json.dumps({
+            "model_type": "bert", "is_decoder": c.is_decoder, "vocab_size": c.vocab_size,
+            "hidden_size": c.hidden_size, "num_hidden_layers": c.num_hidden_layers,
+            "num_attention_heads": c.num_attention_heads, "intermediate_size": c.intermediate_size,
+            "max_position_embeddings": c.max_seq_length, "pooling_mode": c.pooling_mode,
+            "is_normalized": c.is_normalized, "pretrained_model_name": c.pretrained_model_name,
+        }, indent=2))
+
+    @classmethod
+    def load(cls, path: str, device=None, precision: str = "bf16") -> "RecommenderModel":
+        from safetensors.torch import load_file
+
+        p = pathlib.Path(path)
+        d = json.loads((p / "config.json").read_text())
+        config = ModelConfig(
+            vocab_size=d["vocab_size"], hidden_size=d["hidden_size"], num_hidden_layers=d["num_hidden_layers"],
+            num_attention_heads=d["num_attention_heads"], intermediate_size=d["intermediate_size"],
+            max_seq_length=d["max_position_embeddings"], is_decoder=d["is_decoder"],
+            pretrained_model_name=d.get("pretrained_model_name", PRETRAINED_MODEL_NAME),
+            pooling_mode=d.get("pooling_mode", "mean"), is_normalized=d.get("is_normalized", False),
+        )
+        return cls(config, device=device, model=load_file(str(p / "model.safetensors")), precision=precision)

@@ -1,0 +1,341 @@
+"""Thin functional wrappers over the C ABI + the two autograd Functions of the training path.
+
+Every function here enqueues HIP kernels from ``libxfmr_hip.so`` on the current stream of the current
+device. Tensors are allocated with torch (device memory + caching allocator are plumbing); the
+arithmetic is never torch's.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+f32 = torch.float32
+
+
+def _empty(shape, like: torch.Tensor, dtype=f32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _bytes(n: int, like: torch.Tensor):
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=like.device)
+
+
+def selftest_mfma(device="cuda") -> list[int]:
+    out = torch.full((4,), -1, dtype=torch.int32, device=device)
+    N.check(N.load().xfmr_selftest_mfma(N.ptr(out), N.stream()), "xfmr_selftest_mfma")
+    return out.tolist()
+
+
+# ------------------------------------------------------------------------------------------------ per-op
+def embed_ln_fwd(item_idx, table, pos_emb, type_emb, gamma, beta, *, eps=1e-12, dropout_p=0.0, seed=0, site=0):
+    B, L = item_idx.shape
+    H = table.shape[1]
+    out, pre = _empty((B, L, H), table), _empty((B, L, H), table)
+    mean, rstd = _empty((B, L), table), _empty((B, L), table)
+    mask = _empty((B, L), table, torch.uint8)
+    N.check(
+        N.load().xfmr_embed_ln_fwd(
+            N.ptr(item_idx), N.ptr(table), table.shape[0], N.ptr(pos_emb), N.ptr(type_emb), N.ptr(gamma),
+            N.ptr(beta), N.ptr(out), N.ptr(pre), N.ptr(mean), N.ptr(rstd), N.ptr(mask), B, L, H, eps, dropout_p,
+            seed, site, N.stream(),
+        ),
+        "xfmr_embed_ln_fwd",
+    )
+    return out, pre, mean, rstd, mask
+
+
+def embed_param_grads(d_pre, max_pos):
+    B, L, H = d_pre.shape
+    d_pos, d_type = _empty((max_pos, H), d_pre), _empty((2, H), d_pre)
+    N.check(
+        N.load().xfmr_embed_param_grads(N.ptr(d_pre), N.ptr(d_pos), N.ptr(d_type), B, L, H, max_pos, N.stream()),
+        "xfmr_embed_param_grads",
+    )
+    return d_pos, d_type
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-12):
+    rows, H = x.numel() // x.shape[-1], x.shape[-1]
+    y, mean, rstd = torch.empty_like(x), _empty((rows,), x), _empty((rows,), x)
+    N.check(
+        N.load().xfmr_layernorm_fwd(N.ptr(x), N.ptr(gamma), N.ptr(beta), N.ptr(y), N.ptr(mean), N.ptr(rstd), rows, H,
+                                    eps, N.stream()),
+        "xfmr_layernorm_fwd",
+    )
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, dropout_p=0.0, seed=0, site=0):
+    rows, H = x.numel() // x.shape[-1], x.shape[-1]
+    lib = N.load()
+    dx = torch.empty_like(x)
+    d_lin = torch.empty_like(x) if dropout_p > 0 else None
+    dg, db, dbias = _empty((H,), x), _empty((H,), x), _empty((H,), x)
+    ws = _bytes(lib.xfmr_layernorm_bwd_workspace(rows, H), x)
+    N.check(
+        lib.xfmr_layernorm_bwd(N.ptr(dy), N.ptr(x), N.ptr(mean), N.ptr(rstd), N.ptr(gamma), N.ptr(dx), N.ptr(d_lin),
+                               N.ptr(dg), N.ptr(db), N.ptr(dbias), rows, H, dropout_p, seed, site, N.ptr(ws),
+                               N.stream()),
+        "xfmr_layernorm_bwd",
+    )
+    return dx, d_lin, dg, db, dbias
+
+
+def linear_fwd(x, w, bias, *, epilogue=N.EPI_BIAS, residual=None, dropout_p=0.0, seed=0, site=0, precision="bf16"):
+    M, K = x.numel() // x.shape[-1], x.shape[-1]
+    Nout = w.shape[0]
+    y = _empty((*x.shape[:-1], Nout), x)
+    aux = torch.empty_like(y) if epilogue == N.EPI_BIAS_GELU else None
+    N.check(
+        N.load().xfmr_linear_fwd(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(y), M, Nout, K, epilogue, N.ptr(residual),
+                                 N.ptr(aux), dropout_p, seed, site, N.precision_id(precision), N.stream()),
+        "xfmr_linear_fwd",
+    )
+    return (y, aux) if aux is not None else y
+
+
+def linear_bwd_dx(dy, w, *, residual_grad=None, gelu_pre=None, precision="bf16"):
+    M, Nout = dy.numel() // dy.shape[-1], dy.shape[-1]
+    K = w.shape[1]
+    dx = _empty((*dy.shape[:-1], K), dy)
+    N.check(
+        N.load().xfmr_linear_bwd_dx(N.ptr(dy), N.ptr(w), N.ptr(dx), M, Nout, K, N.ptr(residual_grad),
+                                    N.ptr(gelu_pre), N.precision_id(precision), N.stream()),
+        "xfmr_linear_bwd_dx",
+    )
+    return dx
+
+
+def linear_bwd_dw(dy, x, *, precision="bf16"):
+    M, Nout = dy.numel() // dy.shape[-1], dy.shape[-1]
+    K = x.shape[-1]
+    lib = N.load()
+    dw = _empty((Nout, K), dy)
+    nbytes = lib.xfmr_linear_bwd_dw_workspace(M, Nout, K)
+    ws = _bytes(nbytes, dy)
+    N.check(
+        lib.xfmr_linear_bwd_dw(N.ptr(dy), N.ptr(x), N.ptr(dw), M, Nout, K, N.precision_id(precision), N.ptr(ws),
+                               nbytes, N.stream()),
+        "xfmr_linear_bwd_dw",
+    )
+    return dw
+
+
+def colsum(a):
+    M, Nc = a.numel() // a.shape[-1], a.shape[-1]
+    lib = N.load()
+    out = _empty((Nc,), a)
+    ws = _bytes(lib.xfmr_colsum_workspace(M, Nc), a)
+    N.check(lib.xfmr_colsum(N.ptr(a), N.ptr(out), M, Nc, N.ptr(ws), N.stream()), "xfmr_colsum")
+    return out
+
+
+def attn_fwd(qkv, key_mask, heads, *, dropout_p=0.0, seed=0, site=0, precision="bf16"):
+    B, L, H3 = qkv.shape
+    H = H3 // 3
+    ctx, lse = _empty((B, L, H), qkv), _empty((B, heads, L), qkv)
+    N.check(
+        N.load().xfmr_attn_fwd(N.ptr(qkv), N.ptr(key_mask), N.ptr(ctx), N.ptr(lse), B, L, heads, H, dropout_p, seed,
+                               site, N.precision_id(precision), N.stream()),
+        "xfmr_attn_fwd",
+    )
+    return ctx, lse
+
+
+def attn_bwd(qkv, key_mask, ctx, lse, d_ctx, heads, *, dropout_p=0.0, seed=0, site=0, precision="bf16"):
+    B, L, H3 = qkv.shape
+    d_qkv = torch.empty_like(qkv)
+    N.check(
+        N.load().xfmr_attn_bwd(N.ptr(qkv), N.ptr(key_mask), N.ptr(ctx), N.ptr(lse), N.ptr(d_ctx), N.ptr(d_qkv), B, L,
+                               heads, H3 // 3, dropout_p, seed, site, N.precision_id(precision), N.stream()),
+        "xfmr_attn_bwd",
+    )
+    return d_qkv
+
+
+def table_rnorm(table):
+    out = _empty((table.shape[0],), table)
+    N.check(N.load().xfmr_table_rnorm(N.ptr(table), N.ptr(out), table.shape[0], table.shape[1], N.stream()),
+            "xfmr_table_rnorm")
+    return out
+
+
+def mean_pool(tok, key_mask):
+    B, L, H = tok.shape
+    out = _empty((B, H), tok)
+    N.check(N.load().xfmr_mean_pool(N.ptr(tok), N.ptr(key_mask), N.ptr(out), B, L, H, N.stream()), "xfmr_mean_pool")
+    return out
+
+
+def adamw_(params, grads, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=1,
+           grad_scale=1.0):
+    N.check(
+        N.load().xfmr_adamw(N.ptr(params), N.ptr(grads), N.ptr(exp_avg), N.ptr(exp_avg_sq), params.numel(), lr, beta1,
+                            beta2, eps, weight_decay, step, grad_scale, N.stream()),
+        "xfmr_adamw",
+    )
+
+
+def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, all_heads=True,
+                 mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
+                 need_grad=True):
+    """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H)."""
+    H = tok.shape[-1]
+    T = tok.numel() // H
+    lib = N.load()
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision)
+    n_rows = table.shape[0]
+    losses = _empty((N.NUM_LOSSES,), tok)
+    stats = _empty((N.NUM_STATS,), tok)
+    d_tok = torch.empty_like(tok) if need_grad else None
+    nbytes = lib.xfmr_sampled_loss_workspace(T, H, n_rows)
+    ws = _bytes(nbytes, tok)
+    N.check(
+        lib.xfmr_sampled_loss(C.byref(cfg), N.ptr(tok), N.ptr(key_mask), N.ptr(pos_idx), N.ptr(neg_idx),
+                              N.ptr(table), N.ptr(rnorm), n_rows, T, H, N.ptr(losses), N.ptr(stats), N.ptr(d_tok),
+                              N.ptr(ws), nbytes, N.stream()),
+        "xfmr_sampled_loss",
+    )
+    return losses, stats, d_tok
+
+
+def _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision) -> N.LossCfg:
+    return N.LossCfg(
+        train_head=N.LOSS_IDS[train_head] if isinstance(train_head, str) else int(train_head),
+        all_heads=int(all_heads), mask_false_negatives=int(mask_false_negatives), mode=mode,
+        precision=N.precision_id(precision), scale=float(scale), margin=float(margin), reserved=0,
+    )
+
+
+def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head, all_heads=False,
+                       mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
+                       need_grad=True):
+    """List form (compacted queries): returns (losses[7], stats[16], d_query or None)."""
+    Np, H = query.shape
+    Nn = 0 if neg_items is None else neg_items.numel()
+    lib = N.load()
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision)
+    n_rows = table.shape[0]
+    losses, stats = _empty((N.NUM_LOSSES,), query), _empty((N.NUM_STATS,), query)
+    d_q = torch.empty_like(query) if need_grad else None
+    nbytes = lib.xfmr_sampled_loss_lists_workspace(Np, Nn, H, n_rows)
+    ws = _bytes(nbytes, query)
+    N.check(
+        lib.xfmr_sampled_loss_lists(C.byref(cfg), N.ptr(query), N.ptr(pos_items), N.ptr(neg_items), Np, Nn,
+                                    N.ptr(table), N.ptr(rnorm), n_rows, H, N.ptr(losses), N.ptr(stats), N.ptr(d_q),
+                                    N.ptr(ws), nbytes, N.stream()),
+        "xfmr_sampled_loss_lists",
+    )
+    return losses, stats, d_q
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, precision, ln_eps=1e-12,
+                     hidden_dropout=0.0, attn_dropout=0.0, seed=0) -> N.EncoderCfg:
+    return N.EncoderCfg(
+        batch=batch, seq_len=seq_len, hidden=hidden, heads=heads, inter=inter, layers=layers, max_pos=max_pos,
+        precision=N.precision_id(precision), ln_eps=ln_eps, hidden_dropout=hidden_dropout,
+        attn_dropout=attn_dropout, reserved=0, seed=seed,
+    )
+
+
+def encoder_fwd(cfg: N.EncoderCfg, flat_params, item_idx, table):
+    lib = N.load()
+    T, H = cfg.batch * cfg.seq_len, cfg.hidden
+    tok = _empty((cfg.batch, cfg.seq_len, H), flat_params)
+    key_mask = _empty((cfg.batch, cfg.seq_len), flat_params, torch.uint8)
+    nbytes = lib.xfmr_encoder_workspace_bytes(C.byref(cfg))
+    if nbytes == 0:
+        raise RuntimeError("xfmr_encoder_workspace_bytes: unsupported encoder configuration "
+                           "(head size must be 32, sizes positive, seq_len <= max_pos)")
+    acts = _bytes(nbytes, flat_params)
+    N.check(
+        lib.xfmr_encoder_fwd(C.byref(cfg), N.ptr(flat_params), N.ptr(item_idx), N.ptr(table), table.shape[0],
+                             N.ptr(tok), N.ptr(key_mask), N.ptr(acts), nbytes, N.stream()),
+        "xfmr_encoder_fwd",
+    )
+    return tok, key_mask, acts
+
+
+def encoder_bwd(cfg: N.EncoderCfg, flat_params, d_tok, key_mask, acts, grads=None):
+    """d_tok is clobbered. Returns the flat gradient buffer."""
+    if grads is None:
+        grads = torch.empty_like(flat_params)
+    N.check(
+        N.load().xfmr_encoder_bwd(C.byref(cfg), N.ptr(flat_params), N.ptr(grads), N.ptr(d_tok), N.ptr(key_mask),
+                                  N.ptr(acts), acts.numel(), N.stream()),
+        "xfmr_encoder_bwd",
+    )
+    return grads
+
+
+class EncoderFunction(torch.autograd.Function):
+    """tok, key_mask = encoder(flat_params, item_idx); backward fills the flat gradient."""
+
+    @staticmethod
+    def forward(ctx, flat_params, item_idx, table, cfg):
+        tok, key_mask, acts = encoder_fwd(cfg, flat_params, item_idx, table)
+        ctx.cfg = cfg
+        ctx.save_for_backward(flat_params, key_mask, acts)
+        ctx.mark_non_differentiable(key_mask)
+        return tok, key_mask
+
+    @staticmethod
+    def backward(ctx, d_tok, _d_mask):
+        flat_params, key_mask, acts = ctx.saved_tensors
+        d = d_tok.contiguous()
+        if d.data_ptr() == d_tok.data_ptr():
+            d = d.clone()  # the kernel sequence reuses this buffer as scratch
+        grads = encoder_bwd(ctx.cfg, flat_params, d, key_mask, acts)
+        return grads, None, None, None
+
+
+class SampledLossFunction(torch.autograd.Function):
+    """(train_loss, losses[7], stats[16]) = fused_loss(tok, ...). Only train_loss carries a gradient; it was
+    computed in the same pass as the forward and is scaled by the incoming gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, tok, key_mask, pos_idx, neg_idx, table, rnorm, opts):
+        need = tok.requires_grad
+        losses, stats, d_tok = sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, need_grad=need, **opts)
+        head = opts["train_head"]
+        head = N.LOSS_IDS[head] if isinstance(head, str) else head
+        if need:
+            ctx.save_for_backward(d_tok)
+        ctx.mark_non_differentiable(losses, stats)
+        return losses[head].clone(), losses, stats
+
+    @staticmethod
+    def backward(ctx, g, _gl, _gs):
+        (d_tok,) = ctx.saved_tensors
+        g = g.contiguous().to(f32)
+        N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(d_tok), d_tok.numel(), N.ptr(g), N.stream()),
+                "xfmr_scale_by_device_scalar")
+        return d_tok, None, None, None, None, None, None
+
+
+class SampledLossListsFunction(torch.autograd.Function):
+    """List form of :class:`SampledLossFunction`: compacted queries, explicit item-id lists."""
+
+    @staticmethod
+    def forward(ctx, query, pos_items, neg_items, table, rnorm, opts):
+        need = query.requires_grad
+        losses, stats, d_q = sampled_loss_lists(query, pos_items, neg_items, table, rnorm, need_grad=need, **opts)
+        head = opts["train_head"]
+        head = N.LOSS_IDS[head] if isinstance(head, str) else head
+        if need:
+            ctx.save_for_backward(d_q)
+        ctx.mark_non_differentiable(losses, stats)
+        return losses[head].clone(), losses, stats
+
+    @staticmethod
+    def backward(ctx, g, _gl, _gs):
+        (d_q,) = ctx.saved_tensors
+        g = g.contiguous().to(f32)
+        N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(d_q), d_q.numel(), N.ptr(g), N.stream()),
+                "xfmr_scale_by_device_scalar")
+        return d_q, None, None, None, None, None

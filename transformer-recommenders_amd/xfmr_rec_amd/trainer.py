@@ -1,0 +1,235 @@
+"""Training-step driver: host-side mirror of ``xfmr_rec/trainer.py`` (the LightningModule surface).
+
+``RecommenderLightningModule`` keeps the reference's method names and semantics for the training path --
+``configure_model``, ``forward``, ``compute_losses`` (all seven heads + batch / logits statistics every
+step, ``trainer.py:213-264``), ``training_step`` (returns ``loss/{train_loss}``, ``trainer.py:288-291``),
+``configure_optimizers`` (AdamW lr 1e-3 / wd 0.01 over all parameters, ``trainer.py:327-332``) and
+``state_dict`` without the frozen table (``trainer.py:352-362``). When ``lightning`` is importable it
+subclasses ``lightning.pytorch.LightningModule`` so ``LightningCLI(lightning_module_cls=...)``
+(``trainer.py:377-395``) accepts it; otherwise it is a plain ``nn.Module`` driven by :class:`Trainer`.
+
+One step on the device is: gather+mask+BertEmbeddings -> N x BertLayer -> fused loss (7 heads + stats +
+dL/dtok in one pass) -> encoder backward -> [flat-gradient all-reduce under DDP] -> fused AdamW. All of it is
+HIP kernels from ``libxfmr_hip.so``; torch supplies memory, streams, autograd bookkeeping and RCCL.
+"""
+
+from __future__ import annotations
+
+import time
+
+import torch
+
+from . import _native as N
+from . import ops
+from .losses import LOSS_CLASSES, LossConfig, LossType, stats_to_dict
+from .models import ModelConfig, RecommenderModel
+from .params import TOP_K
+
+try:  # pragma: no cover - lightning is not installed in the build image
+    import lightning.pytorch as _lp
+
+    _Base = _lp.LightningModule
+except Exception:  # noqa: BLE001
+    _lp = None
+    _Base = torch.nn.Module
+
+
+class LightningConfig(LossConfig, ModelConfig):
+    """``trainer.py:98-115`` minus the LanceDB index configs (retrieval is out of the hot path)."""
+
+    train_loss: LossType = "InfoNCELoss"
+    learning_rate: float = 0.001
+    weight_decay: float = 0.01
+    top_k: int = TOP_K
+    # build-specific knobs (not in the reference)
+    precision: str = "bf16"  # MFMA arithmetic: "bf16" (reference default bf16-mixed) or "fp32"
+    log_all_losses: bool = True  # evaluate all 7 heads + statistics every step like trainer.py:250-264
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """``torch.optim.AdamW`` semantics (decoupled decay, bias correction, eps outside sqrt) as one HIP launch
+    over the flat parameter buffer. Parameters without a gradient are skipped, as torch does."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                ops.adamw_(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], lr=group["lr"], beta1=b1,
+                           beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"], step=st["step"],
+                           grad_scale=group["grad_scale"])
+        return loss
+
+
+class RecommenderLightningModule(_Base):
+    def __init__(self, config: LightningConfig) -> None:
+        super().__init__()
+        self.config = LightningConfig.model_validate(config)
+        if _lp is not None:  # pragma: no cover
+            self.save_hyperparameters(self.config.model_dump())
+            self.strict_loading = False
+        self.model: RecommenderModel | None = None
+        self.items_dataset = None
+        self.loss_fns: torch.nn.ModuleList | None = None
+        self.logged: dict = {}
+
+    # lightning supplies .device; the plain-module build derives it from the parameters
+    def _device(self):
+        if self.model is not None:
+            return self.model.device
+        return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+    def configure_model(self) -> None:
+        """``trainer.py:139-161``."""
+        if self.model is None:
+            self.model = RecommenderModel(self.config, device=self._device(), precision=self.config.precision)
+        if self.items_dataset is None and _lp is not None:  # pragma: no cover
+            try:
+                self.items_dataset = self.trainer.datamodule.items_dataset
+            except RuntimeError:
+                pass
+        if self.items_dataset is not None:
+            self.model.configure_embeddings(self.items_dataset)
+        if self.loss_fns is None:
+            self.loss_fns = self.get_loss_fns()
+
+    def get_loss_fns(self) -> torch.nn.ModuleList:
+        """``trainer.py:163-170``."""
+        return torch.nn.ModuleList([cls(self.config, precision=self.config.precision) for cls in LOSS_CLASSES])
+
+    def forward(self, item_idx: torch.Tensor) -> dict[str, torch.Tensor]:
+        assert self.model is not None
+        return self.model(item_idx.to(self.model.device))
+
+    def compute_losses(self, batch, *, sync_metrics: bool = True) -> dict:
+        """``trainer.py:213-264``: every head's summed loss and ``...Mean``, batch and logits statistics.
+
+        One encoder forward + ONE fused loss launch sequence produce all of it (the reference recomputes the
+        logits eight times). ``loss/{train_loss}`` carries the gradient; the other heads are logging values.
+        ``sync_metrics=False`` keeps the statistics on the device (no host sync in the step).
+        """
+        assert self.model is not None
+        m, c = self.model, self.config
+        if c.num_hard_negatives > 0:
+            raise NotImplementedError("num_hard_negatives > 0 is not fused into the gfx950 loss kernel yet")
+        if c.target_position != "first":
+            raise ValueError("the training path scores [positive | shared negatives]: target_position='first'")
+        dev = m.device
+        hist = batch["history_item_idx"]
+        tok, key_mask = m._encode_tokens(hist)
+        L = tok.shape[1]
+        pos = batch["pos_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
+        neg = batch["neg_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
+        opts = dict(train_head=c.train_loss, all_heads=c.log_all_losses, mask_false_negatives=c.mask_false_negatives,
+                    mode=N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision)
+        train_loss, losses, stats = ops.SampledLossFunction.apply(
+            tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts
+        )
+        out: dict = {}
+        n_query = stats[N.STAT["n_query"]]
+        names = [cls.__name__ for cls in LOSS_CLASSES]
+        for i, name in enumerate(names):
+            if not c.log_all_losses and name != c.train_loss:
+                continue
+            val = train_loss if name == c.train_loss else losses[i]
+            out[f"loss/{name}"] = val
+            out[f"loss/{name}Mean"] = val.detach() / (n_query + 1e-9)
+        batch_size, seq_len = key_mask.shape
+        numel = key_mask.numel()
+        if sync_metrics:
+            s = stats.tolist()  # one device->host sync (the reference does 11 .item() calls)
+            attn_nz, pos_nz = int(s[N.STAT["n_valid"]]), int(s[N.STAT["n_query"]])
+            out |= {
+                "batch/size": batch_size, "batch/seq_len": seq_len, "batch/numel": numel,
+                "batch/attention_non_zero": attn_nz, "batch/attention_density": attn_nz / (numel + 1e-9),
+                "batch/positive_non_zero": pos_nz, "batch/positive_density": pos_nz / (attn_nz + 1e-9),
+            }
+            if c.log_all_losses:
+                out |= stats_to_dict(s)
+        else:
+            out["stats/device"] = stats
+        return out
+
+    def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        loss_dict = self.compute_losses(batch)
+        self.log_dict(loss_dict)
+        return loss_dict[f"loss/{self.config.train_loss}"]
+
+    def log_dict(self, d, *a, **k):  # noqa: D401 - lightning API
+        if _lp is not None and getattr(self, "_trainer", None) is not None:  # pragma: no cover
+            return super().log_dict(d, *a, **k)
+        self.logged = d
+        return None
+
+    def configure_optimizers(self) -> torch.optim.Optimizer:
+        """``trainer.py:327-332`` with the fused kernel."""
+        return FusedAdamW(self.parameters(), lr=self.config.learning_rate, weight_decay=self.config.weight_decay)
+
+    @property
+    def example_input_array(self):
+        return (torch.as_tensor([[0], [1]], device=self._device()),)
+
+    def state_dict(self, *args, **kwargs):
+        """HF-keyed encoder tensors under the reference's prefix; the frozen table is omitted
+        (``trainer.py:352-362``)."""
+        sd = super().state_dict(*args, **kwargs)
+        sd.pop("model.embeddings.weight", None)
+        if self.model is not None:
+            sd.pop("model.flat", None)
+            for k, v in self.model.encoder_state_dict().items():
+                sd[f"model.model.0.auto_model.{k}"] = v
+        return sd
+
+    def save(self, path) -> None:
+        assert self.model is not None
+        self.model.save(str(path))
+
+
+class Trainer:
+    """Minimal stand-in for Lightning's automatic optimisation (``zero_grad -> training_step -> backward ->
+    [all-reduce] -> optimizer.step``), single process or one process per GPU (``torch.distributed``)."""
+
+    def __init__(self, module: RecommenderLightningModule, *, world_size: int = 1, process_group=None):
+        self.module = module
+        module.configure_model()
+        self.optimizer = module.configure_optimizers()
+        self.world_size = world_size
+        self.process_group = process_group
+        if world_size > 1:
+            for g in self.optimizer.param_groups:
+                g["grad_scale"] = 1.0 / world_size  # DDP averages gradients: SUM all-reduce then / W
+
+    def fit_step(self, batch) -> torch.Tensor:
+        m = self.module
+        m.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = m.training_step(batch)
+        loss.backward()
+        if self.world_size > 1:
+            from .distributed import allreduce_flat_grad_
+
+            allreduce_flat_grad_(m.model.flat.grad, self.process_group)
+        self.optimizer.step()
+        return loss.detach()
+
+    def fit(self, batches, max_steps: int | None = None) -> list[float]:
+        out = []
+        t0 = time.time()
+        for i, b in enumerate(batches):
+            if max_steps is not None and i >= max_steps:
+                break
+            out.append(float(self.fit_step(b)))
+        self.elapsed = time.time() - t0
+        return out
