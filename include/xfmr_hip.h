@@ -255,6 +255,10 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
                             const int64_t* neg_items, int64_t n_query, int64_t n_neg, const float* table,
                             const float* table_rnorm, int64_t n_rows, int32_t H, float* losses, float* stats,
                             float* d_query, void* workspace, size_t workspace_bytes, void* stream);
+/* Measurement hook (bench.py): the next xfmr_sampled_loss[_lists] call made by THIS host thread records the two
+ * hipEvent_t (passed as void*) on its stream immediately before and after the dominant kernel
+ * (loss_main_kernel), then forgets them. Pass NULL, NULL to cancel. Has no effect on results. */
+int xfmr_sampled_loss_profile_next(void* start_event, void* stop_event);
 /* table_rnorm[r] = 1 / max(||table[r]||, 1e-8): per-item inverse norms for the cosine heads
  * (torch cosine_similarity, losses.py:206-208); computed once because the table is frozen. */
 int xfmr_table_rnorm(const float* table, float* table_rnorm, int64_t n_rows, int32_t H, void* stream);

@@ -124,12 +124,23 @@ def embed_loss_parts(
     num_hard_negatives: int = 0,
     scale: float = 1.0,
     margin: float = 0.5,
+    ties: torch.Tensor | None = None,
 ):
-    """``EmbedLoss.forward`` (losses.py:128-155) returning every intermediate."""
+    """``EmbedLoss.forward`` (losses.py:128-155) returning every intermediate.
+
+    ``ties`` (optional bool (N,C)): columns that hold the SAME item vector as the row's target. Their logit
+    equals the target's in exact arithmetic, so ``logits < target_logit`` must drop them; in the reference
+    whether that happens depends on the rounding of its ``bmm`` (column 0 and column j are reduced in
+    different vector lanes: observed both ways, see tests/golden/g4 'ties'). Passing ``ties`` makes the
+    outcome independent of that luck by copying the target's logit into those columns -- the semantics the
+    HIP kernel implements by item id. Without ``ties`` this function is the reference, bit for bit.
+    """
     assert q.dim() == 2 and cand.dim() == 3  # losses.py:157-177
     assert q.size(0) == cand.size(0) and q.size(-1) == cand.size(-1)
     logits = cosine_logits(q, cand) if kind in COSINE_KINDS else dot_logits(q, cand)
     tgt = resolve_target(logits.size(0), target, target_position, logits.device)
+    if ties is not None:
+        logits = torch.where(ties, logits.gather(1, tgt), logits)
     mask = negative_mask(logits, tgt, mask_false_negatives)
     mask = hard_negative_mask(logits, mask, num_hard_negatives)
     loss = head(kind, logits, tgt, mask, scale=scale, margin=margin)
@@ -148,11 +159,14 @@ def logits_statistics(
     target_position="first",
     mask_false_negatives: bool = True,
     num_hard_negatives: int = 0,
+    ties: torch.Tensor | None = None,
     **_unused,
 ) -> dict[str, float]:
-    """``LogitsStatistics`` (losses.py:375-405): dot logits, monitoring only."""
+    """``LogitsStatistics`` (losses.py:375-405): dot logits, monitoring only. ``ties``: see embed_loss_parts."""
     logits = dot_logits(q, cand)
     tgt = resolve_target(logits.size(0), target, target_position, logits.device)
+    if ties is not None:
+        logits = torch.where(ties, logits.gather(1, tgt), logits)
     mask = hard_negative_mask(
         logits, negative_mask(logits, tgt, mask_false_negatives), num_hard_negatives
     )

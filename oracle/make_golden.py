@@ -263,16 +263,19 @@ def gen_shared_negatives():
     """The training-path candidate structure (models.py:398-416) through the reference loss classes:
     cand = cat([E[pos][:, None], E[neg][None].expand(Np, -1, -1)], 1), positive at column 0."""
     store: dict[str, np.ndarray] = {"versions": np.array(VERSIONS)}
-    V, H, Np, Nn = 30, 64, 21, 33
+    V, H, Np, Nn = 200, 64, 21, 33
     g = torch.Generator().manual_seed(5)
     items = torch.randn(V, H, generator=g)
     items = items / items.norm(dim=-1, keepdim=True)
     table = torch.cat([torch.zeros(1, H), items])
     q0 = torch.randn(Np, H, generator=g) * 1.5
-    pos = torch.randint(1, V + 1, (Np,), generator=g)
-    neg = torch.randint(0, V + 1, (Nn,), generator=g)  # includes some padding-row (0) negatives
-    neg[3] = pos[0]  # sampled negatives that ARE some row's positive (false negatives, exact ties)
-    neg[7] = pos[5]
+    # positives from ids 1..100, negatives from 101..200 (+ two padding-row negatives): NO row has a negative
+    # that is its own positive, so no logit tie exists and the reference's result does not depend on the
+    # rounding of its bmm (see the 'ties' block below for what happens when one does).
+    pos = torch.randint(1, 101, (Np,), generator=g)
+    neg = torch.randint(101, V + 1, (Nn,), generator=g)
+    neg[10] = 0
+    neg[20] = 0
     variants = [
         dict(),
         dict(mask_false_negatives=False),
@@ -302,6 +305,23 @@ def gen_shared_negatives():
         loss.backward()
         store[f"catalog/{cls.__name__}/loss"] = _np(loss)
         store[f"catalog/{cls.__name__}/dq"] = _np(q.grad)
+    # exact ties: two sampled negatives ARE some row's positive item. Mathematically their logit equals the
+    # positive's and `logits < pos_logit` drops them; what the reference actually does depends on how its bmm
+    # rounds column 0 vs column j, so its mask bits at the tie entries are recorded next to its loss.
+    neg_t = neg.clone()
+    neg_t[3] = pos[0]
+    neg_t[7] = pos[5]
+    neg_t[8] = pos[5]
+    cfg = ref_losses.LossConfig()
+    cand = torch.cat([table[pos][:, None, :], table[neg_t][None, :, :].expand(Np, -1, -1)], dim=1)
+    tie_entries = torch.cat([torch.zeros(Np, 1, dtype=torch.bool), neg_t[None, :] == pos[:, None]], dim=1)
+    for cls in ref_losses.LOSS_CLASSES:
+        fn = cls(cfg)
+        logits = fn.compute_logits(q0, cand)
+        mask = fn.mask_false_negatives(logits, fn.check_target(logits, None))
+        store[f"ties/{cls.__name__}/loss"] = _np(fn(q0, cand))
+        store[f"ties/{cls.__name__}/tie_counted_as_negative"] = _np(mask[tie_entries])
+    store["ties/neg"] = _np(neg_t)
     store["table"] = _np(table)
     store["q"] = _np(q0)
     store["pos"] = _np(pos)

@@ -56,19 +56,25 @@ def compute_embeds(
     neg_e = F.embedding(neg[m], table)[None, :, :].expand(pos_e.size(0), -1, -1)
     cand = torch.cat([pos_e, neg_e], dim=1)
     keep = pos_i != 0
+    # columns (>= 1) whose item IS the row's positive: exact ties, see oracle.losses.embed_loss_parts
+    ties = torch.cat([torch.zeros_like(keep)[:, None], neg[m][None, :] == pos_i[:, None]], dim=1)
     return {
         "query_embed": q[keep],
         "candidate_embed": cand[keep],
         "attention_mask": m,
         "positive_mask": keep,
+        "ties": ties[keep],
     }
 
 
 def compute_losses(
     params, table, batch, *, num_heads, max_seq_length, loss_cfg, is_normalized=False,
-    dropout_p=0.0, training=False, kinds=L.LOSS_KINDS, with_stats=True,
+    dropout_p=0.0, training=False, kinds=L.LOSS_KINDS, with_stats=True, resolve_ties=False,
 ):
-    """trainer.py:213-264: all heads + batch statistics + logits statistics."""
+    """trainer.py:213-264: all heads + batch statistics + logits statistics.
+
+    ``resolve_ties``: resolve exact positive/negative ties by item identity (what the HIP kernel does) rather
+    than by the rounding of the materialised bmm (what the reference does): oracle.losses.embed_loss_parts."""
     e = compute_embeds(
         params, table, batch["history_item_idx"], batch["pos_item_idx"], batch["neg_item_idx"],
         num_heads=num_heads, max_seq_length=max_seq_length, is_normalized=is_normalized,
@@ -79,8 +85,9 @@ def compute_losses(
     attn_nz = int(am.count_nonzero())
     pos_nz = int(e["positive_mask"].count_nonzero())
     out: dict = {}
+    ties = e["ties"] if resolve_ties else None
     for kind in kinds:
-        loss = L.embed_loss(kind, e["query_embed"], e["candidate_embed"], **loss_cfg)
+        loss = L.embed_loss(kind, e["query_embed"], e["candidate_embed"], ties=ties, **loss_cfg)
         out[f"loss/{kind}"] = loss
         out[f"loss/{kind}Mean"] = loss / (pos_nz + 1e-9)
     out |= {
@@ -93,7 +100,7 @@ def compute_losses(
         "batch/positive_density": pos_nz / (attn_nz + 1e-9),
     }
     if with_stats:
-        out |= L.logits_statistics(e["query_embed"], e["candidate_embed"], **loss_cfg)
+        out |= L.logits_statistics(e["query_embed"], e["candidate_embed"], ties=ties, **loss_cfg)
     return out
 
 

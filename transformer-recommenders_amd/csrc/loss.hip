@@ -557,9 +557,19 @@ int launch_main_h(const LossArgs& a, int H, bool all, dim3 grid, hipStream_t st)
   return XFMR_OK;
 }
 
+// one-shot, per host thread: events recorded around the NEXT main-kernel launch (measurement only)
+thread_local hipEvent_t g_prof_start = nullptr;
+thread_local hipEvent_t g_prof_stop = nullptr;
+
 }  // namespace
 
 extern "C" {
+
+int xfmr_sampled_loss_profile_next(void* start_event, void* stop_event) {
+  g_prof_start = (hipEvent_t)start_event;
+  g_prof_stop = (hipEvent_t)stop_event;
+  return XFMR_OK;
+}
 
 size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows) {
   if (positions <= 0 || H <= 0) return 0;
@@ -581,10 +591,14 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   a.mode = cfg->mode; a.need_grad = d_tok != nullptr; a.scale = cfg->scale; a.margin = cfg->margin;
   dim3 grid((unsigned)((T + QB - 1) / QB), p.nsplit);
   int rc;
+  hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
+  g_prof_start = g_prof_stop = nullptr;  // one-shot
+  if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
   if (cfg->precision == XFMR_PREC_BF16) rc = launch_main_h<PrecBF16>(a, H, cfg->all_heads != 0, grid, st);
   else if (cfg->precision == XFMR_PREC_F32) rc = launch_main_h<PrecF32>(a, H, cfg->all_heads != 0, grid, st);
   else rc = XFMR_EINVAL;
   if (rc) return rc;
+  if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
 
   CombineArgs c{};
   c.tok = tok; c.table = table; c.rnorm = table_rnorm; c.counts = counts; c.qrow = qrow; c.qpos = qpos;
