@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: user-sequences/sec of one full training step of the sequential recommender
+(MovieLens-1M-shaped: V=3883 items, seq_len 200, d_model 128, 4 layers, sampled softmax / InfoNCE) on N
+MI355X of one node, data-parallel over RCCL.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = zero_grad -> gather+mask+BertEmbeddings -> 4 x BertLayer -> fused loss (all seven heads +
+LogitsStatistics + dL/dtok, as the reference's training_step evaluates them, xfmr_rec/trainer.py:250-264) ->
+encoder backward -> flat-gradient all-reduce (N > 1) -> AdamW, dropout 0.1 ON, on one batch of synthetic
+sequences already resident in HBM (the batch is 3 x B x 200 int64 = 0.6 MB at B=128; the PCIe-inclusive rate
+is noted in DESIGN.md). Rank 0 prints ONE JSON line; see the task contract for the fields. Extra objects:
+
+  roofline     dominant kernel = loss_main_kernel (the negative-scoring logit GEMM with its fused epilogue and
+               the dQ GEMM): algorithmic flops per launch = 4 * Np * N * H / average
+               launch duration measured with HIP events recorded on the launch stream around that kernel
+               inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline the CPU oracle (oracle/, a restatement of the reference: 'port') timed on this host's cores
+               on a bounded sample (the reference's O(N^2 H) candidate tensor caps the batch it can run).
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "transformer-recommenders_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import torch  # noqa: E402
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_F32_MFMA_TFLOPS = 157.3
+METRIC = "user-sequences/sec (train step) MovieLens-1M seq200 d128 @1/2/4/8 GPU"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step")
+    ap.add_argument("--seq-len", type=int, default=200)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--inter", type=int, default=512)
+    ap.add_argument("--items", type=int, default=3883)
+    ap.add_argument("--loss", default="InfoNCELoss")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--lengths", default="dense", choices=["dense", "ml"])
+    ap.add_argument("--lean", action="store_true", help="only the train head (not the reference's 7 + stats)")
+    ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    return ap.parse_args()
+
+
+def synth_batch(B, L, V, seed, lengths_mode):
+    g = torch.Generator().manual_seed(seed)
+    if lengths_mode == "dense":
+        lens = [L] * B
+    else:  # MovieLens-1M-like: log-normal, clipped to [16, L]
+        lens = torch.exp(torch.randn(B, generator=g) * 1.0 + 4.35).round().clamp(16, L).long().tolist()
+    out = {k: torch.zeros(B, L, dtype=torch.int64) for k in ("history_item_idx", "pos_item_idx", "neg_item_idx")}
+    for b, n in enumerate(lens):
+        for k in out:
+            out[k][b, :n] = torch.randint(1, V + 1, (n,), generator=g)
+    return out, lens
+
+
+def unit_table(V, H, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(V + 1, H, generator=g)
+    t = t / t.norm(dim=-1, keepdim=True)
+    t[0] = 0
+    return t
+
+
+class HipEvents:
+    """hipEvent pairs created through the HIP runtime torch already loaded (same soname)."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.pairs = []
+        for _ in range(n):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
+            self.pairs.append((a, b))
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = ctypes.c_float()
+            if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0:
+                out.append(ms.value)
+        return out
+
+
+def usable_cpus() -> int:
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = pathlib.Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(args):
+    """Reference-faithful CPU step (materialised (Np,1+N,H) candidates, 7 heads + stats, backward, AdamW)
+    through the oracle, on a bounded sample."""
+    from oracle import encoder as enc
+    from oracle import model as OM
+
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    B, L, H, V = args.cpu_batch, args.seq_len, args.hidden, args.items
+    params = enc.init_params(H, args.layers, args.inter, L, seed=0)
+    table = unit_table(V, H)
+    batch, _ = synth_batch(B, L, V, 999, args.lengths)
+    tr = OM.OracleTrainer(params, table, num_heads=H // 32, max_seq_length=L, train_loss=args.loss,
+                          dropout_p=0.0 if args.no_dropout else 0.1, faithful=not args.lean)
+    tr.step(batch)
+    t0 = time.perf_counter()
+    done = 0
+    while done < args.cpu_steps and (done == 0 or time.perf_counter() - t0 < 25.0):  # bounded: ~10-30 s of CPU
+        tr.step(batch)
+        done += 1
+    args.cpu_steps = done
+    dt = (time.perf_counter() - t0) / done
+    return {
+        "value": round(B / dt, 3), "unit": "sequences/s", "cores": threads, "kind": "port",
+        "sample": (f"{args.cpu_steps} steps of B={B} sequences x L={L} (N={B * L} in-batch negatives; the reference's "
+                   f"O(N^2 H) candidate tensor caps the CPU batch), fp32, {'7 heads + stats' if not args.lean else 'train head only'}, "
+                   f"{dt * 1e3:.0f} ms/step"),
+    }
+
+
+def main():
+    args = parse()
+    import xfmr_rec_amd as X
+    from xfmr_rec_amd import _native as N
+    from xfmr_rec_amd import distributed as D
+
+    rank, local, world = D.init_process_group_from_env()
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B, L, H, V = args.batch, args.seq_len, args.hidden, args.items
+    conf = X.LightningConfig(hidden_size=H, num_attention_heads=H // 32, intermediate_size=args.inter,
+                             num_hidden_layers=args.layers, max_seq_length=L, train_loss=args.loss,
+                             precision=args.precision, log_all_losses=not args.lean)
+    mod = X.RecommenderLightningModule(conf)
+    mod.configure_model()
+    mod.model.set_table(unit_table(V, H).to(dev))
+    trainer = X.Trainer(mod, world_size=world)
+    mod.train()
+    if args.no_dropout:
+        mod.eval()
+
+    n_batches = 4
+    batches = []
+    for i in range(n_batches):
+        b, lens = synth_batch(B, L, V, 1000 + rank * 97 + i, args.lengths)
+        batches.append({k: v.to(dev) for k, v in b.items()})
+    tokens_per_seq = sum(lens) / len(lens)
+
+    def step(i):
+        batch = batches[i % n_batches]
+        opt = trainer.optimizer
+        opt.zero_grad(set_to_none=True)
+        out = mod.compute_losses(batch, sync_metrics=False)  # metrics stay on the device: no host sync per step
+        loss = out[f"loss/{conf.train_loss}"]
+        loss.backward()
+        if world > 1:
+            D.allreduce_flat_grad_(mod.model.flat.grad)
+        opt.step()
+        return loss, out
+
+    for i in range(args.warmup):
+        step(i)
+    ev = HipEvents(args.steps)
+    lib = N.load()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lib.xfmr_sampled_loss_profile_next(ev.pairs[i][0], ev.pairs[i][1])
+        loss, out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    stats = out["stats/device"].tolist()
+    n_valid, n_query = stats[N.STAT["n_valid"]], stats[N.STAT["n_query"]]
+    kern_ms = ev.elapsed_ms()
+    kern_avg = sum(kern_ms) / max(len(kern_ms), 1)
+    flops = 4.0 * n_query * n_valid * H
+    achieved = flops / (kern_avg * 1e-3) / 1e12 if kern_avg > 0 else 0.0
+    peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+    traffic = None
+    pmc = ROOT / "profiles" / "loss_main_traffic.json"
+    if pmc.exists():
+        try:
+            rec = json.loads(pmc.read_text())
+            if rec.get("batch") == B and rec.get("precision") == args.precision:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+
+    if rank == 0:
+        seqs = B * world * args.steps
+        result = {
+            "metric": METRIC,
+            "value": round(seqs / elapsed, 2),
+            "unit": "sequences/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {
+                "workload": (f"MovieLens-1M-shaped: {V} items, seq_len={L}, d_model={H}, {args.layers}-layer causal BERT "
+                             f"(heads={H // 32}, ffn={args.inter}), {args.loss} over in-batch shared negatives, AdamW"),
+                "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "lengths": args.lengths,
+                "mean_tokens_per_sequence": round(tokens_per_seq, 1),
+                "loss_heads_evaluated": "train head only" if args.lean else "all 7 + LogitsStatistics (reference training_step)",
+                "dropout": 0.0 if args.no_dropout else 0.1, "parallelism": f"dp{world}",
+                "final_loss": round(float(loss.detach()), 4),
+            },
+            "roofline": {
+                "kernel": "loss_main_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
+                "avg_launch_ms": round(kern_avg, 4), "algorithmic_flops_per_launch": flops,
+                "launches_timed": len(kern_ms),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,6 +152,12 @@ struct RegRows<PrecBF16, K> {
     return acc;
   }
   __device__ __forceinline__ const bf16x8* regs() const { return v; }
+  // write this lane's part of its row into a K-contiguous image row (for tile_nt)
+  __device__ __forceinline__ void store_image(__bf16* img_row) const {
+    const int h = xf_lane() >> 5;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) *reinterpret_cast<bf16x8*>(img_row + 16 * s + 8 * h) = v[s];
+  }
 };
 template <int K>
 struct RegRows<PrecF32, K> {
@@ -168,6 +174,11 @@ struct RegRows<PrecF32, K> {
     return acc;
   }
   __device__ __forceinline__ const float* regs() const { return v; }
+  __device__ __forceinline__ void store_image(float* img_row) const {
+    const int h = xf_lane() >> 5;
+#pragma unroll
+    for (int s = 0; s < K / 2; ++s) img_row[2 * s + h] = v[s];
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -246,8 +257,17 @@ __device__ __forceinline__ float xf_gelu(float x) { return 0.5f * x * (1.f + erf
 __device__ __forceinline__ float xf_gelu_grad(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
-__device__ __forceinline__ float xf_softplus(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
-__device__ __forceinline__ float xf_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+// raw transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32: 1 ulp, no denormal fix-up code around them)
+__device__ __forceinline__ float xf_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float xf_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float xf_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float xf_softplus(float x) {
+  return fmaxf(x, 0.f) + 0.6931471805599453f * xf_log2(1.f + xf_exp2(-fabsf(x) * 1.4426950408889634f));
+}
+__device__ __forceinline__ float xf_sigmoid(float x) {
+  const float t = xf_exp2(-fabsf(x) * 1.4426950408889634f);
+  return xf_rcp(1.f + t) * (x >= 0.f ? 1.f : t);
+}
 
 // Write a wave's 32(d) x 32(row) accumulator tile, transposed, as 32 rows of 32 contiguous floats.
 // scratch: per-wave [32][33] floats. dst row pointer for lane-row j: base + (row0 + j) * stride.

@@ -183,45 +183,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
-// deterministic reduction of `count` slabs: dst[i] = sum_s src[s*n + i]
-__global__ void reduce_slabs_kernel(float* dst, const float* src, int count, int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int c = 0; c < count; ++c) s += src[(int64_t)c * n + i];
-  dst[i] = s;
+// Deterministic column sums of a [rows, cols] fp32 matrix: block (x, y) sums rows [y*rows_per, (y+1)*rows_per)
+// of 64 columns with 4 row groups in flight (each wave instruction reads 256 contiguous bytes), combines the
+// groups through LDS in a fixed order and writes dst[y*cols + col]. Used for bias gradients (two levels) and
+// for the split-K slab reduction (rows = slabs, cols = elements of the weight).
+__global__ __launch_bounds__(256) void rowsum_kernel(float* dst, const float* src, int64_t rows, int64_t cols,
+                                                     int64_t rows_per) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = (r0 + rows_per < rows) ? r0 + rows_per : rows;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < cols) {
+    int64_t r = r0 + rg;
+    for (; r + 12 < r1; r += 16) {
+      s0 += src[r * cols + col];
+      s1 += src[(r + 4) * cols + col];
+      s2 += src[(r + 8) * cols + col];
+      s3 += src[(r + 12) * cols + col];
+    }
+    for (; r < r1; r += 4) s0 += src[r * cols + col];
+  }
+  red[rg][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && col < cols) dst[(int64_t)blockIdx.y * cols + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
-// column sums, stage 1: block b sums rows [b*rows_per, ...) into partial[b][N]
-__global__ void colsum_partial_kernel(const float* a, float* partial, int64_t M, int N, int rows_per) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
-  const int64_t r1 = min(M, r0 + rows_per);
-  float s = 0.f;
-  for (int64_t r = r0; r < r1; ++r) s += a[r * N + n];
-  partial[(int64_t)blockIdx.y * N + n] = s;
+int launch_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, int64_t rows_per, hipStream_t st) {
+  const int64_t ny = (rows + rows_per - 1) / rows_per;
+  hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)ny), dim3(256), 0, st, dst, src, rows,
+                     cols, rows_per);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
 }
 
 template <class P, bool TA, bool TB, int EPI>
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
-  // tile choice: 128x128 when it still fills the chip, otherwise 64-wide tiles for more workgroups
-  const int64_t tiles128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
-  const bool bigN = g.N > 64, bigM = (g.M > 64) && (tiles128 >= 256 || g.M >= 4096);
+  // These GEMMs are skinny (K <= 1024) and bound by operand streaming + latency, not by MFMA issue: prefer
+  // the largest tile that still yields >= 512 workgroups (2 per CU), otherwise the smallest tile.
+  auto wgs = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (int64_t)splits; };
+  int bm = 64, bn = 64;
+  if (g.N > 64 && g.M > 64 && wgs(128, 128) >= 512) { bm = 128; bn = 128; }
+  else if (g.N > 64 && wgs(64, 128) >= 512) { bm = 64; bn = 128; }
+  else if (g.M > 64 && wgs(128, 64) >= 512) { bm = 128; bn = 64; }
   dim3 block(256);
-  if (bigM && bigN) {
-    dim3 grid((g.N + 127) / 128, (unsigned)((g.M + 127) / 128), splits);
-    hipLaunchKernelGGL((gemm_kernel<P, 128, 128, TA, TB, EPI>), grid, block, 0, st, g);
-  } else if (bigN) {
-    dim3 grid((g.N + 127) / 128, (unsigned)((g.M + 63) / 64), splits);
-    hipLaunchKernelGGL((gemm_kernel<P, 64, 128, TA, TB, EPI>), grid, block, 0, st, g);
-  } else if (bigM) {
-    dim3 grid((g.N + 63) / 64, (unsigned)((g.M + 127) / 128), splits);
-    hipLaunchKernelGGL((gemm_kernel<P, 128, 64, TA, TB, EPI>), grid, block, 0, st, g);
-  } else {
-    dim3 grid((g.N + 63) / 64, (unsigned)((g.M + 63) / 64), splits);
-    hipLaunchKernelGGL((gemm_kernel<P, 64, 64, TA, TB, EPI>), grid, block, 0, st, g);
-  }
+  dim3 grid((unsigned)((g.N + bn - 1) / bn), (unsigned)((g.M + bm - 1) / bm), splits);
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 128, 128, TA, TB, EPI>), grid, block, 0, st, g);
+  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, TA, TB, EPI>), grid, block, 0, st, g);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, TA, TB, EPI>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_kernel<P, 64, 64, TA, TB, EPI>), grid, block, 0, st, g);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
@@ -234,9 +245,11 @@ int dispatch_gemm(const GemmArgs& g, int splits, int precision, hipStream_t st) 
 }
 
 int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
-  // reduction dimension = M (tokens). Aim at ~512 workgroups in total.
-  int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int64_t want = (512 + tiles - 1) / tiles;
+  // reduction dimension = M (tokens): <= 64 deterministic slabs, ~256-512 workgroups in total
+  int64_t tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  int64_t want = (1024 + tiles - 1) / tiles;
+  if (want > 64) want = 64;
+  if (want < 1) want = 1;
   int64_t chunk = (M + want - 1) / want;
   chunk = ((chunk + 31) / 32) * 32;
   if (chunk < 64) chunk = 64;
@@ -313,17 +326,17 @@ int xfmr_linear_bwd_dw(const float* dy, const float* x, float* dw, int64_t M, in
   int rc = dispatch_gemm<true, true, EPI_SPLITK>(g, splits, precision, st);
   if (rc) return rc;
   const int64_t n = (int64_t)N * K;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dw,
-                     (const float*)workspace, splits, n);
-  XF_LAUNCH_CHECK();
-  return XFMR_OK;
+  return launch_rowsum(dw, (const float*)workspace, splits, n, splits, st);
 }
 
 static int colsum_plan(int64_t M, int* rows_per) {
-  int64_t blocks = (M + 127) / 128;
-  if (blocks > 256) blocks = 256;
-  *rows_per = (int)((M + blocks - 1) / blocks);
-  return (int)((M + *rows_per - 1) / *rows_per);
+  int64_t blocks = (M + 255) / 256;
+  if (blocks > 128) blocks = 128;
+  if (blocks < 1) blocks = 1;
+  int64_t rp = (M + blocks - 1) / blocks;
+  rp = ((rp + 3) / 4) * 4;
+  *rows_per = (int)rp;
+  return (int)((M + rp - 1) / rp);
 }
 size_t xfmr_colsum_workspace(int64_t M, int32_t N) {
   int rows_per;
@@ -332,15 +345,10 @@ size_t xfmr_colsum_workspace(int64_t M, int32_t N) {
 int xfmr_colsum(const float* a, float* out, int64_t M, int32_t N, void* workspace, void* stream) {
   if (!a || !out || !workspace || M <= 0 || N <= 0) return XFMR_EINVAL;
   int rows_per;
-  int blocks = colsum_plan(M, &rows_per);
+  const int blocks = colsum_plan(M, &rows_per);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, blocks), dim3(64), 0, st, a, (float*)workspace, M,
-                     N, rows_per);
-  XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, st, out, (const float*)workspace,
-                     blocks, (int64_t)N);
-  XF_LAUNCH_CHECK();
-  return XFMR_OK;
+  if (int rc = launch_rowsum((float*)workspace, a, M, N, rows_per, st)) return rc;
+  return launch_rowsum(out, (const float*)workspace, blocks, N, blocks, st);
 }
 
 }  // extern "C"

@@ -41,49 +41,61 @@ struct LossArgs {
 };
 
 // ---- compaction of valid positions (replaces the boolean-mask indexing of models.py:390-404) ------
-__global__ __launch_bounds__(1024) void prepare_kernel(const uint8_t* key_mask, const int64_t* pos_idx,
-                                                       const int64_t* neg_idx, int T, int64_t n_rows, int* counts,
-                                                       int* neg_item, int* qrow, int* qpos) {
-  __shared__ int s_valid[1024], s_query[1024];
-  const int tid = threadIdx.x;
-  const int per = (T + 1023) / 1024;
-  const int beg = tid * per, end = min(T, beg + per);
-  int nv = 0, nq = 0;
-  for (int i = beg; i < end; ++i) {
-    const bool v = key_mask[i] != 0;
-    nv += v;
-    nq += v && (pos_idx[i] != 0);
-  }
-  s_valid[tid] = nv;
-  s_query[tid] = nq;
+// Two fully parallel kernels, order-preserving (the reference's boolean indexing keeps row-major order):
+//   count: workgroup b counts the valid positions / queries of its 1024 positions -> blockcnt[b]
+//   write: workgroup b sums blockcnt[0..b) (at most a few hundred ints), scans its own 1024 flags with
+//          wave ballots, and writes the compacted item lists; the last workgroup publishes the totals.
+constexpr int PREP = 1024;
+__global__ __launch_bounds__(PREP) void prepare_count_kernel(const uint8_t* key_mask, const int64_t* pos_idx, int T,
+                                                             int2* blockcnt) {
+  __shared__ int sv[PREP / 64], sq[PREP / 64];
+  const int i = blockIdx.x * PREP + threadIdx.x;
+  const bool v = i < T && key_mask[i] != 0;
+  const bool q = v && pos_idx[i] != 0;
+  const int nv = __popcll(__ballot(v)), nq = __popcll(__ballot(q));
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = nv; sq[threadIdx.x >> 6] = nq; }
   __syncthreads();
-  // inclusive Hillis-Steele scan over 1024 entries
-  for (int off = 1; off < 1024; off <<= 1) {
+  if (threadIdx.x == 0) {
     int a = 0, b = 0;
-    if (tid >= off) { a = s_valid[tid - off]; b = s_query[tid - off]; }
-    __syncthreads();
-    s_valid[tid] += a;
-    s_query[tid] += b;
-    __syncthreads();
+    for (int w = 0; w < PREP / 64; ++w) { a += sv[w]; b += sq[w]; }
+    blockcnt[blockIdx.x] = make_int2(a, b);
   }
-  int ov = s_valid[tid] - nv, oq = s_query[tid] - nq;
-  for (int i = beg; i < end; ++i) {
-    if (key_mask[i] != 0) {
-      int64_t ni = neg_idx ? neg_idx[i] : 0;
-      if (ni < 0 || ni >= n_rows) ni = 0;
-      neg_item[ov++] = (int)ni;
-      int64_t pi = pos_idx[i];
-      if (pi != 0) {
-        if (pi < 0 || pi >= n_rows) pi = 0;
-        qrow[oq] = i;
-        qpos[oq] = (int)pi;
-        ++oq;
-      }
+}
+__global__ __launch_bounds__(PREP) void prepare_write_kernel(const uint8_t* key_mask, const int64_t* pos_idx,
+                                                             const int64_t* neg_idx, int T, int64_t n_rows,
+                                                             const int2* blockcnt, int* counts, int* neg_item,
+                                                             int* qrow, int* qpos) {
+  __shared__ int sv[PREP / 64], sq[PREP / 64], base[2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = blockIdx.x * PREP + tid;
+  const bool v = i < T && key_mask[i] != 0;
+  const int64_t pi = v ? pos_idx[i] : 0;
+  const bool q = v && pi != 0;
+  const unsigned long long bv = __ballot(v), bq = __ballot(q);
+  if (lane == 0) { sv[w] = __popcll(bv); sq[w] = __popcll(bq); }
+  if (tid == 0) {
+    int a = 0, b = 0;
+    for (int k = 0; k < (int)blockIdx.x; ++k) { a += blockcnt[k].x; b += blockcnt[k].y; }
+    base[0] = a; base[1] = b;
+  }
+  __syncthreads();
+  int ov = base[0], oq = base[1];
+  for (int k = 0; k < w; ++k) { ov += sv[k]; oq += sq[k]; }
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  ov += __popcll(bv & below);
+  oq += __popcll(bq & below);
+  if (v) {
+    int64_t ni = neg_idx ? neg_idx[i] : 0;
+    if (ni < 0 || ni >= n_rows) ni = 0;
+    neg_item[ov] = (int)ni;
+    if (q) {
+      qrow[oq] = i;
+      qpos[oq] = (int)((pi < 0 || pi >= n_rows) ? 0 : pi);
     }
   }
-  if (tid == 1023) {
-    counts[0] = s_valid[1023];
-    counts[1] = s_query[1023];
+  if (blockIdx.x == gridDim.x - 1 && tid == PREP - 1) {
+    counts[0] = ov + (v ? 1 : 0);
+    counts[1] = oq + (q ? 1 : 0);
   }
 }
 
@@ -110,15 +122,24 @@ __global__ void prepare_lists_kernel(const int64_t* pos_items, const int64_t* ne
 
 // ---- main kernel -------------------------------------------------------------------------------------
 template <class P, int H, bool ALL>
-__global__ __launch_bounds__(256) void loss_main_kernel(LossArgs a) {
+__global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(LossArgs a) {
   using elem = typename P::elem;
   constexpr int LDE = xf_ld<P>(H);
   constexpr int NPASS = 2 * (H / 64);  // staging passes: 32 rows x 64 columns per pass per workgroup
-  __shared__ __attribute__((aligned(16))) elem sE[BN * LDE];
-  __shared__ __attribute__((aligned(16))) elem sET[H * LDT];
-  __shared__ __attribute__((aligned(16))) float sScratch[4 * 32 * 33];
-  __shared__ int sNid[BN];
-  __shared__ float sRc[BN];
+  // With every head evaluated the epilogue needs the registers: the wave's query rows then live in LDS
+  // (B operand read like the A operand) so the kernel still fits 2 waves/SIMD (<= 256 registers).
+  constexpr bool Q_IN_LDS = ALL && (P::kId == XFMR_PREC_BF16) && (H <= 128);
+  constexpr size_t E_BYTES = BN * LDE * sizeof(elem), ET_BYTES = H * LDT * sizeof(elem);
+  constexpr size_t SCR_BYTES = 4 * 32 * 33 * sizeof(float);
+  constexpr size_t MAIN_BYTES = (E_BYTES + ET_BYTES > SCR_BYTES) ? E_BYTES + ET_BYTES : SCR_BYTES;
+  constexpr size_t Q_BYTES = Q_IN_LDS ? QB * LDE * sizeof(elem) : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + Q_BYTES];
+  elem* const sE = reinterpret_cast<elem*>(smem);
+  elem* const sET = reinterpret_cast<elem*>(smem + E_BYTES);
+  float* const sScratch = reinterpret_cast<float*>(smem);  // epilogue only: aliases the tile images
+  elem* const sQ = reinterpret_cast<elem*>(smem + MAIN_BYTES);
+  __shared__ __attribute__((aligned(16))) int sNid[BN];
+  __shared__ __attribute__((aligned(16))) float sRc[BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
   const int Nq = a.counts[1];
@@ -153,6 +174,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(LossArgs a) {
     }
     qq += xf_half_swap(qq);
   }
+  if (Q_IN_LDS) qreg.store_image(sQ + (wid * 32 + (lane & 31)) * LDE);  // visible after the first barrier
   const float rq = 1.f / fmaxf(sqrtf(qq), 1e-8f);
   const float rcpos = qvalid ? a.rnorm[pos_item] : 1.f;
   const float cpos = pos_dot * rq * rcpos;
@@ -217,43 +239,47 @@ __global__ __launch_bounds__(256) void loss_main_kernel(LossArgs a) {
     }
   };
 
-  if (t_beg < t_end) prefetch(t_beg);
+  // PREFETCH_ACROSS: keep the next tile's gather in registers while this tile is multiplied (1 workgroup/CU
+  // variants); otherwise gather-then-commit back to back and let the second resident workgroup of the CU
+  // cover the latency (2 waves/SIMD variants: the 32 staging registers are not live across the math).
+  constexpr bool PREFETCH_ACROSS = (H > 128);
+  if (PREFETCH_ACROSS && t_beg < t_end) prefetch(t_beg);
   for (int tile = t_beg; tile < t_end; ++tile) {
     __syncthreads();
+    if (!PREFETCH_ACROSS) prefetch(tile);
     commit();
     __syncthreads();
-    if (tile + 1 < t_end) prefetch(tile + 1);
+    if (PREFETCH_ACROSS && tile + 1 < t_end) prefetch(tile + 1);
 
 #pragma unroll 1
     for (int sb = 0; sb < BN / 32; ++sb) {
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
-      P::tile_nreg(s, sE, LDE, sb * 32, qreg.regs(), H);
+      if (Q_IN_LDS) P::tile_nt(s, sE, LDE, sb * 32, sQ, LDE, wid * 32, H);
+      else P::tile_nreg(s, sE, LDE, sb * 32, qreg.regs(), H);
 
-      // pass 1: tie handling, dot-family mask, block max for the online log-sum-exp
-      unsigned mdbits = 0, samebits = 0;
-      float bmax = m;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jl = sb * 32 + xf_acc_row(r, lane);
-        const int nid = sNid[jl];
-        const bool valid = nid >= 0;
-        const bool same = nid == pos_item;
-        const float sv = same ? pos_dot : s[r];
-        s[r] = sv;
-        const bool md = valid && (mask_fn ? (sv < pos_dot) : true) && !(catalog && same);
-        mdbits |= (md ? 1u : 0u) << r;
-        samebits |= (same ? 1u : 0u) << r;
-        if (md) bmax = fmaxf(bmax, sv * sc2);
-      }
+      // The lane's 16 accumulator rows (r&3) + 8*(r>>2) + 4*hh are four runs of 4 consecutive negatives:
+      // per-negative side data (item id, inverse norm) comes as one 16-byte LDS read per run and array.
       const bool want_lse = ALL || head == XFMR_LOSS_INFONCE;
-      float mnew = m;
-      if (want_lse) {
+      if (want_lse && !mask_fn) {
+        // online log-sum-exp: without false-negative masking a counted logit may exceed the running max
+        // (with masking every counted logit is < the positive's, and m = scale * pos stays fixed)
+        float bmax = m;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int4 n4 = *reinterpret_cast<const int4*>(&sNid[sb * 32 + 8 * g + 4 * hh]);
+          const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool same = nn[u] == pos_item;
+            const bool md = (nn[u] >= 0) & !(catalog & same);
+            bmax = fmaxf(bmax, md ? (same ? pos_dot : s[4 * g + u]) * sc2 : m);
+          }
+        }
         bmax = fmaxf(bmax, xf_half_swap(bmax));
-        mnew = bmax;  // >= m by construction
-        if (__any(mnew > m)) {
-          const float alpha = exp2f(m - mnew);
+        if (__any(bmax > m)) {
+          const float alpha = xf_exp2(m - bmax);
           l *= alpha;
           if (head == XFMR_LOSS_INFONCE) {
 #pragma unroll
@@ -262,57 +288,73 @@ __global__ __launch_bounds__(256) void loss_main_kernel(LossArgs a) {
               for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             sw *= alpha;
           }
-          m = mnew;
+          m = bmax;
         }
       }
-      // pass 2: every head's row reductions + the train head's gradient weight (left in s[r])
+      // Every head's row reductions and the train head's gradient weight (left in s[r] for the second MFMA).
+      // Branch-free per element; the `head` switches are wave-uniform.
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jl = sb * 32 + xf_acc_row(r, lane);
-        const float sv = s[r];
-        const bool md = (mdbits >> r) & 1u;
-        const float mdf = md ? 1.f : 0.f;
-        float w = 0.f;
-        cnt_d += mdf;
-        if (want_lse) {
-          const float e = md ? exp2f(sv * sc2 - m) : 0.f;
-          l += e;
-          if (head == XFMR_LOSS_INFONCE) w = e;
-        }
-        if (ALL || head == XFMR_LOSS_NCE) {
-          nce += md ? xf_softplus(sv) : 0.f;
-          if (head == XFMR_LOSS_NCE) w = md ? xf_sigmoid(sv) : 0.f;
-        }
-        if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE) {
-          const float d = sv - chinge;
-          hinge += md ? fmaxf(d, 0.f) : 0.f;
-          if (head == XFMR_LOSS_PAIRWISE_HINGE) w = (md && d > 0.f) ? 1.f : 0.f;
-        }
-        if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
-          const float d = sv - chinge;
-          logi += md ? xf_softplus(d) : 0.f;
-          if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md ? xf_sigmoid(d) : 0.f;
-        }
+      for (int g = 0; g < 4; ++g) {
+        const int jl0 = sb * 32 + 8 * g + 4 * hh;
+        const int4 n4 = *reinterpret_cast<const int4*>(&sNid[jl0]);
+        const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+        float rc[4] = {0.f, 0.f, 0.f, 0.f};
         if (ALL || cos_head) {
-          const float rc = sRc[jl];
-          const bool same = (samebits >> r) & 1u;
-          const float c = same ? cpos : sv * rq * rc;
-          const bool valid = sNid[jl] >= 0;
-          const bool mc = valid && (mask_fn ? (c < cpos) : true) && !(catalog && same);
-          cnt_c += mc ? 1.f : 0.f;
-          const float d = c - 1.f + a.margin;
-          contr += mc ? fmaxf(d, 0.f) : 0.f;
-          if (head == XFMR_LOSS_CONTRASTIVE || head == XFMR_LOSS_ALIGNMENT_CONTRASTIVE)
-            w = (mc && d > 0.f) ? rc : 0.f;
+          const float4 c4 = *reinterpret_cast<const float4*>(&sRc[jl0]);
+          rc[0] = c4.x; rc[1] = c4.y; rc[2] = c4.z; rc[3] = c4.w;
         }
-        if (ALL) {
-          ssum += md ? sv : 0.f;
-          ssq += md ? sv * sv : 0.f;
-          smin = md ? fminf(smin, sv) : smin;
-          smax = md ? fmaxf(smax, sv) : smax;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = 4 * g + u;
+          const bool valid = nn[u] >= 0;
+          const bool same = nn[u] == pos_item;  // exact tie: the negative IS the positive item
+          const float sv = same ? pos_dot : s[r];
+          const bool excl = catalog & same;
+          const float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? 1.f : 0.f;
+          float w = 0.f;
+          cnt_d += md;
+          if (want_lse) {
+            // counted logits are <= m by construction; the clamp keeps an uncounted large logit from inf * 0
+            const float e = xf_exp2(fminf(sv * sc2 - m, 0.f)) * md;
+            l += e;
+            if (head == XFMR_LOSS_INFONCE) w = e;
+          }
+          if (ALL || head == XFMR_LOSS_NCE) {
+            const float t = xf_exp2(-fabsf(sv) * kLog2e);                    // exp(-|x|)
+            nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // softplus(x)
+            if (head == XFMR_LOSS_NCE) w = md * xf_rcp(1.f + t) * (sv >= 0.f ? 1.f : t);  // sigmoid(x)
+          }
+          if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
+            const float d = sv - chinge;
+            hinge = fmaf(fmaxf(d, 0.f), md, hinge);
+            if (head == XFMR_LOSS_PAIRWISE_HINGE) w = d > 0.f ? md : 0.f;
+            if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
+              const float t = xf_exp2(-fabsf(d) * kLog2e);
+              logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
+              if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md * xf_rcp(1.f + t) * (d >= 0.f ? 1.f : t);
+            }
+          }
+          if (ALL || cos_head) {
+            const float c = same ? cpos : sv * rq * rc[u];
+            const float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? 1.f : 0.f;
+            cnt_c += mc;
+            const float d = c - 1.f + a.margin;
+            contr = fmaf(fmaxf(d, 0.f), mc, contr);
+            if (head == XFMR_LOSS_CONTRASTIVE || head == XFMR_LOSS_ALIGNMENT_CONTRASTIVE)
+              w = d > 0.f ? mc * rc[u] : 0.f;
+          }
+          if (ALL) {
+            ssum = fmaf(sv, md, ssum);
+            ssq = fmaf(sv * sv, md, ssq);
+            smin = fminf(smin, md > 0.f ? sv : INFINITY);
+            smax = fmaxf(smax, md > 0.f ? sv : -INFINITY);
+          }
+          sw += w;
+          s[r] = w;
         }
-        sw += w;
-        s[r] = w;
+        // keep the scheduler from interleaving the four runs (it otherwise holds all 16 elements' temporaries
+        // live at once and spills at 2 waves/SIMD)
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (do_grad) {
 #pragma unroll
@@ -333,6 +375,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(LossArgs a) {
     rec[R_SMAX] = smax; rec[R_SW] = sw; rec[R_POSDOT] = pos_dot; rec[R_RQ] = rq; rec[R_QQ] = qq;
   }
   if (do_grad) {
+    __syncthreads();  // sScratch aliases the tile images other waves may still be reading
     float* base = a.partO + (int64_t)split * a.T * H;
 #pragma unroll
     for (int i = 0; i < H / 32; ++i)
@@ -462,37 +505,40 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
 }
 
 // ---- final: deterministic reduction of the block partials ------------------------------------------------
-__global__ __launch_bounds__(256) void loss_final_kernel(const double* blockpart, int nblocks, const int* counts,
-                                                         int mode, int64_t n_rows, float* losses, float* stats) {
-  __shared__ double sRed[256];
-  const int Nq = counts[1];
-  const int N = (mode == XFMR_NEG_CATALOG) ? (int)n_rows : counts[0];
-  const int used = (Nq + 3) / 4;  // blocks that carried queries
+// 16 waves; wave w reduces quantities k = w, w+16 over the blocks that carried queries (lanes stride the
+// blocks, fixed shuffle tree), then one thread finishes the statistics.
+__device__ __forceinline__ double shfl_xor_f64(double v, int o) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, o, 64);
+  hi = __shfl_xor(hi, o, 64);
+  return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(1024) void loss_final_kernel(const double* blockpart, int nblocks, const int* counts,
+                                                          int mode, int64_t n_rows, float* losses, float* stats) {
   __shared__ double tot[BP];
-  for (int k = 0; k < BP; ++k) {
+  const int Nq = counts[1];
+  int used = (Nq + 3) / 4;  // blocks that carried queries
+  if (used > nblocks) used = nblocks;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = w; k < BP; k += 16) {
     const bool is_min = (k == 20 || k == 22), is_max = (k == 21 || k == 23);
     double v = is_min ? INFINITY : is_max ? -INFINITY : 0.0;
-    for (int b = threadIdx.x; b < used && b < nblocks; b += 256) {
+    for (int b = lane; b < used; b += 64) {
       const double x = blockpart[(int64_t)b * BP + k];
       v = is_min ? fmin(v, x) : is_max ? fmax(v, x) : v + x;
     }
-    sRed[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off) {
-        const double x = sRed[threadIdx.x + off];
-        sRed[threadIdx.x] = is_min ? fmin(sRed[threadIdx.x], x) : is_max ? fmax(sRed[threadIdx.x], x) : sRed[threadIdx.x] + x;
-      }
-      __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+      const double x = shfl_xor_f64(v, o);
+      v = is_min ? fmin(v, x) : is_max ? fmax(v, x) : v + x;
     }
-    if (threadIdx.x == 0) tot[k] = sRed[0];
-    __syncthreads();
+    if (lane == 0) tot[k] = v;
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
     for (int k = 0; k < XFMR_NUM_LOSSES; ++k) losses[k] = (float)tot[k];
     for (int k = 0; k < XFMR_NUM_STATS; ++k) stats[k] = 0.f;
     const double nq = (double)Nq;
-    stats[XFMR_STAT_N_VALID] = (float)counts[0];
+    stats[XFMR_STAT_N_VALID] = (float)((mode == XFMR_NEG_CATALOG) ? (int)n_rows : counts[0]);
     stats[XFMR_STAT_N_QUERY] = (float)Nq;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     stats[XFMR_STAT_NEG_DENSITY] = (float)(Nq > 0 ? tot[8] / nq : nan);
@@ -506,14 +552,13 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const double* blockpart
     stats[XFMR_STAT_NEG_STD] = (float)(nn > 1 ? sqrt(fmax(0.0, (tot[12] - tot[11] * tot[11] / nn) / (nn - 1.0))) : nan);
     stats[XFMR_STAT_NEG_MIN] = (float)(nn > 0 ? tot[22] : nan);
     stats[XFMR_STAT_NEG_MAX] = (float)(nn > 0 ? tot[23] : nan);
-    (void)N;
   }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
 struct Plan {
   int nsplit;
-  size_t off_counts, off_neg, off_qrow, off_qpos, off_part, off_partO, off_block, total;
+  size_t off_counts, off_blockcnt, off_neg, off_qrow, off_qpos, off_part, off_partO, off_block, total;
   int nblocks;
 };
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -530,6 +575,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows) {
   p.nblocks = (int)((T + 3) / 4);
   size_t o = 0;
   p.off_counts = o; o += 256;
+  p.off_blockcnt = o; o += up256((size_t)((T + PREP - 1) / PREP) * sizeof(int2));
   p.off_neg = o; o += up256((size_t)T * 4);
   p.off_qrow = o; o += up256((size_t)T * 4);
   p.off_qpos = o; o += up256((size_t)T * 4);
@@ -607,7 +653,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, (const double*)c.blockpart, p.nblocks,
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, st, (const double*)c.blockpart, p.nblocks,
                      (const int*)counts, cfg->mode, n_rows, losses, stats);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
@@ -636,10 +682,14 @@ int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t*
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
   const int T = (int)positions;
-  hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(1024), 0, st, key_mask, pos_idx,
+  const int nprep = (T + PREP - 1) / PREP;
+  int2* blockcnt = (int2*)(ws + p.off_blockcnt);
+  hipLaunchKernelGGL(prepare_count_kernel, dim3(nprep), dim3(PREP), 0, st, key_mask, pos_idx, T, blockcnt);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(prepare_write_kernel, dim3(nprep), dim3(PREP), 0, st, key_mask, pos_idx,
                      cfg->mode == XFMR_NEG_SHARED ? neg_idx : (const int64_t*)nullptr, T, n_rows,
-                     (int*)(ws + p.off_counts), (int*)(ws + p.off_neg), (int*)(ws + p.off_qrow),
-                     (int*)(ws + p.off_qpos));
+                     (const int2*)blockcnt, (int*)(ws + p.off_counts), (int*)(ws + p.off_neg),
+                     (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
   XF_LAUNCH_CHECK();
   if (d_tok && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   return run_loss(cfg, tok, table, table_rnorm, n_rows, T, H, losses, stats, d_tok, ws, p, st);

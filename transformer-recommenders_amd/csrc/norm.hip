@@ -159,16 +159,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   }
 }
 
-// sums `blocks` partial records [blocks][3][H] into up to three destinations
-__global__ void ln_bwd_reduce_kernel(const float* partials, int blocks, int H, float* d_gamma, float* d_beta,
-                                     float* d_bias) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= 3 * H) return;
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partials[(int64_t)b * 3 * H + o];
-  const int which = o / H, c = o % H;
-  float* dst = which == 0 ? d_gamma : which == 1 ? d_beta : d_bias;
-  if (dst) dst[c] = s;
+// sums `blocks` partial records [blocks][3][H] into up to three destinations: 64 outputs per workgroup,
+// 4 record groups in flight, fixed combine order (deterministic)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partials, int blocks, int H, float* d_gamma,
+                                                            float* d_beta, float* d_bias) {
+  __shared__ float red[4][64];
+  const int c64 = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + c64;
+  float s0 = 0.f, s1 = 0.f;
+  if (o < 3 * H) {
+    int b = rg;
+    for (; b + 4 < blocks; b += 8) {
+      s0 += partials[(int64_t)b * 3 * H + o];
+      s1 += partials[(int64_t)(b + 4) * 3 * H + o];
+    }
+    for (; b < blocks; b += 4) s0 += partials[(int64_t)b * 3 * H + o];
+  }
+  red[rg][c64] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && o < 3 * H) {
+    const float s = (red[0][c64] + red[1][c64]) + (red[2][c64] + red[3][c64]);
+    const int which = o / H, c = o % H;
+    float* dst = which == 0 ? d_gamma : which == 1 ? d_beta : d_bias;
+    if (dst) dst[c] = s;
+  }
 }
 
 // d_pos[t,c] = sum_b d_pre[b,t,c]  (t < L), 0 for L <= t < max_pos
@@ -273,7 +287,7 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
 
 int ln_bwd_blocks(int64_t rows, int* rows_per_block) {
   int64_t blocks = (rows + 63) / 64;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   int64_t rpb = (rows + blocks - 1) / blocks;
   rpb = ((rpb + 3) / 4) * 4;
@@ -336,7 +350,7 @@ int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, co
   else if (npl <= kMaxPerLane) hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, shmem, st, a);
   else return XFMR_EUNSUPPORTED;
   XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * H + 255) / 256), dim3(256), 0, st, (const float*)partials,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * H + 63) / 64), dim3(256), 0, st, (const float*)partials,
                      blocks, H, d_gamma, d_beta, d_bias);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
