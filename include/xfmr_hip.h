@@ -217,7 +217,7 @@ int xfmr_mean_pool(const float* tok, const uint8_t* key_mask, float* out, int32_
  *   losses[7]        summed loss per head (fp64 -> written as fp32), order XFMR_LOSS_*
  *   stats[16]        see XFMR_STAT_*; fp32
  *   d_tok (B*L,H)    dL(train_head)/d tok, rows that are not queries are zero; may be NULL (eval)
- * workspace: xfmr_sampled_loss_workspace(B*L, H, n_rows) bytes.
+ * workspace: xfmr_sampled_loss_workspace(B*L, H, n_rows) bytes. table_bf16: see xfmr_table_prepare (may be NULL).
  * ---------------------------------------------------------------------------------------------- */
 enum { XFMR_NEG_SHARED = 0, XFMR_NEG_CATALOG = 1 };
 enum {
@@ -242,8 +242,8 @@ typedef struct xfmr_loss_cfg {
 } xfmr_loss_cfg;
 size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows);
 int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
-                      const int64_t* neg_idx, const float* table, const float* table_rnorm, int64_t n_rows,
-                      int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
+                      const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
+                      int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
                       size_t workspace_bytes, void* stream);
 /* List form of the same computation, for queries that are already compacted -- the calling convention of
  * EmbedLoss.forward(query_embed (Np,H), candidate_embed) (xfmr_rec/losses.py:128-155) when the candidates are
@@ -253,8 +253,8 @@ int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t*
 size_t xfmr_sampled_loss_lists_workspace(int64_t n_query, int64_t n_neg, int32_t H, int64_t n_rows);
 int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const int64_t* pos_items,
                             const int64_t* neg_items, int64_t n_query, int64_t n_neg, const float* table,
-                            const float* table_rnorm, int64_t n_rows, int32_t H, float* losses, float* stats,
-                            float* d_query, void* workspace, size_t workspace_bytes, void* stream);
+                            const float* table_rnorm, const void* table_bf16, int64_t n_rows, int32_t H,
+                            float* losses, float* stats, float* d_query, void* workspace, size_t workspace_bytes, void* stream);
 /* Measurement hook (bench.py): the next xfmr_sampled_loss[_lists] call made by THIS host thread records the two
  * hipEvent_t (passed as void*) on its stream immediately before and after the dominant kernel
  * (loss_main_kernel), then forgets them. Pass NULL, NULL to cancel. Has no effect on results. */
@@ -262,6 +262,11 @@ int xfmr_sampled_loss_profile_next(void* start_event, void* stop_event);
 /* table_rnorm[r] = 1 / max(||table[r]||, 1e-8): per-item inverse norms for the cosine heads
  * (torch cosine_similarity, losses.py:206-208); computed once because the table is frozen. */
 int xfmr_table_rnorm(const float* table, float* table_rnorm, int64_t n_rows, int32_t H, void* stream);
+/* Same, plus (optionally) table_bf16 (n_rows,H): a bf16 copy of the frozen table. When it is passed to
+ * xfmr_sampled_loss[_lists] with XFMR_PREC_BF16, negatives are gathered from it by LDS-DMA (no staging
+ * registers); with NULL the fp32 table is converted on the fly. Either output may be NULL. */
+int xfmr_table_prepare(const float* table, float* table_rnorm, void* table_bf16, int64_t n_rows, int32_t H,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K18: AdamW over the flat buffer (torch.optim.AdamW as configured at xfmr_rec/trainer.py:327-332:
@@ -275,8 +280,10 @@ int xfmr_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg
 /* Elementwise helpers used by the autograd wrappers. */
 int xfmr_scale_by_device_scalar(float* x, int64_t n, const float* scalar, void* stream);
 
-/* Self-test of the MFMA operand / accumulator lane maps this library relies on (A = I against an
- * asymmetric B, both precisions). out[0] = mismatching elements in total, out[1] = bf16 maps, out[2] = f32 maps. */
+/* Self-test of the MFMA operand / accumulator lane maps this library relies on (exact integers, asymmetric
+ * operands, both precisions) and of the swizzled LDS-DMA gather image with its row and transposed
+ * (ds_read_b64_tr_b16) fragment reads. `out`: >= 16 KiB + 16 B of device memory; out[0] = mismatches of the
+ * plain maps in total, out[1] = bf16, out[2] = f32, out[3] = swizzled-image path. */
 int xfmr_selftest_mfma(int32_t* out, void* stream);
 
 #ifdef __cplusplus

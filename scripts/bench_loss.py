@@ -42,7 +42,7 @@ def main():
     table = table / table.norm(dim=-1, keepdim=True)
     table[0] = 0
     table = table.to(dev)
-    rn = ops.table_rnorm(table)
+    rn, tb = ops.table_prepare(table)
     tok = torch.randn(B * L, H, generator=g).to(dev)
     mask = torch.ones(B * L, dtype=torch.uint8, device=dev)
     pos = torch.randint(1, V + 1, (B * L,), generator=g).to(dev)
@@ -64,7 +64,7 @@ def main():
                 lib.xfmr_sampled_loss_profile_next(a, b)
                 outer[i][0].record()
                 losses, stats, d = ops.sampled_loss(tok, mask, pos, neg, table, rn, train_head=args.head,
-                                                    all_heads=all_heads, precision=prec)
+                                                    all_heads=all_heads, precision=prec, table_bf16=tb)
                 outer[i][1].record()
             torch.cuda.synchronize()
             ms = []

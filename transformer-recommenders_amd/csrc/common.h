@@ -294,3 +294,76 @@ __device__ __forceinline__ void xf_store_tile_T(float* scratch, const f32x16& ac
   __builtin_amdgcn_wave_barrier();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Swizzled bf16 row images: what an LDS-DMA gather (global_load_lds_dwordx4, one 1-KiB wave instruction =
+// 64 lanes x 16 B, destination = uniform base + lane*16) can produce. Rows are UNPADDED (H*2 bytes), so the
+// bank-conflict fix is an XOR swizzle applied on the SOURCE address at gather time and on every read:
+// logical 16-byte chunk c of row r lives at chunk position c ^ (r & SW).
+//   * row-operand fragments (ds_read_b128, 16 lanes = 16 rows): positions c ^ r are 16 distinct slots
+//   * transposed fragments for "contract over the image's ROW index" products come from
+//     ds_read_b64_tr_b16 on the SAME image (no second, transposed copy of the tile).
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short xf_s16x4;
+
+template <int H>
+struct SwzImg {
+  static constexpr int CPR = H / 8;                         // 16-byte chunks per row
+  static constexpr int SW = (CPR < 16 ? CPR : 16) - 1;      // swizzle mask
+  __device__ static __forceinline__ int off(int r, int c) { return r * H + 8 * (c ^ (r & SW)); }
+
+  // acc += A[arow0..+32][0..H) * B^T, B rows in registers (8 bf16 per 16-deep k-step)
+  __device__ static __forceinline__ void tile_nreg(f32x16& acc, const __bf16* A, int arow0, const bf16x8* breg) {
+    const int l = xf_lane(), r = arow0 + (l & 31), hh = l >> 5;
+#pragma unroll
+    for (int s = 0; s < H / 16; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + off(r, 2 * s + hh));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, breg[s], acc, 0, 0, 0);
+    }
+  }
+  // acc += A[arow0..+32] * B[brow0..+32]^T, both swizzled images
+  __device__ static __forceinline__ void tile_nt(f32x16& acc, const __bf16* A, int arow0, const __bf16* B, int brow0) {
+    const int l = xf_lane(), ra = arow0 + (l & 31), rb = brow0 + (l & 31), hh = l >> 5;
+#pragma unroll
+    for (int s = 0; s < H / 16; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + off(ra, 2 * s + hh));
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + off(rb, 2 * s + hh));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+  }
+  // acc[h][col] += sum_k IMG[jrow0 + k][hsub*32 + h] * X[k][col], k = 0..31, X = accumulator tile in registers.
+  // Per k-step s and half t, every 16-lane group reads one 4-row x 16-column block transposed:
+  // lane 4q+p of the group supplies the address of (row q, columns 4p..4p+3); lane i receives column i.
+  __device__ static __forceinline__ void tile_xb_tr(f32x16& acc, const __bf16* img, int hsub, int jrow0,
+                                                    const f32x16& x) {
+    const int l = xf_lane(), g16 = l >> 4, hh = g16 >> 1, li = l & 15, q = li >> 2, p = li & 3;
+    const int col = hsub * 32 + 16 * (g16 & 1) + 4 * p;
+    const int c = col >> 3, within = col & 7;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = (__bf16)x[8 * s + j];
+      union { xf_s16x4 v[2]; bf16x8 f; } a;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = jrow0 + 16 * s + 8 * t + 4 * hh + q;
+        const __bf16* ptr = img + off(row, c) + within;
+        a.v[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) xf_s16x4*)(ptr));
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.f, b, acc, 0, 0, 0);
+    }
+  }
+  // One wave instruction of the gather: lane -> (row = row0 + lane / CPR, position = lane % CPR);
+  // returns the SOURCE chunk index this lane must fetch so that position holds chunk (position ^ swizzle).
+  __device__ static __forceinline__ int gather_row(int row0) { return row0 + xf_lane() / CPR; }
+  __device__ static __forceinline__ int gather_src_chunk(int row) { return (xf_lane() % CPR) ^ (row & SW); }
+  static constexpr int kRowsPerInstr = 64 / CPR;            // rows covered by one 1-KiB wave instruction
+};
+
+// 16 bytes per lane global -> LDS without registers; lds_base must be wave-uniform.
+__device__ __forceinline__ void xf_glds16(const void* gsrc, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}

@@ -120,6 +120,141 @@ __global__ void prepare_lists_kernel(const int64_t* pos_items, const int64_t* ne
   }
 }
 
+// ---- per-sub-block epilogue shared by both main kernels ----------------------------------------------------
+// s: the 32x32 tile S^T (negative in the registers, query on the lane) on entry, the train head's gradient
+// weights on exit. nid_sb / rc_sb: LDS side data (item id, inverse norm) of the sub-block's 32 negatives.
+struct RowState {
+  float cnt_d, m, l, nce, hinge, logi, cnt_c, contr, ssum, ssq, smin, smax, sw;
+};
+struct RowConst {
+  float pos_dot, cpos, chinge, sc2, rq, margin;
+  int pos_item, head;
+  bool mask_fn, catalog, cos_head;
+};
+template <bool ALL, int NO>
+__device__ __forceinline__ void loss_epilogue(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
+                                              const int* nid_sb, const float* rc_sb, int hh) {
+  float& cnt_d = st.cnt_d; float& m = st.m; float& l = st.l; float& nce = st.nce; float& hinge = st.hinge;
+  float& logi = st.logi; float& cnt_c = st.cnt_c; float& contr = st.contr; float& ssum = st.ssum;
+  float& ssq = st.ssq; float& smin = st.smin; float& smax = st.smax; float& sw = st.sw;
+  const float pos_dot = k.pos_dot, cpos = k.cpos, chinge = k.chinge, sc2 = k.sc2, rq = k.rq;
+  const int pos_item = k.pos_item, head = k.head;
+  const bool mask_fn = k.mask_fn, catalog = k.catalog, cos_head = k.cos_head;
+  constexpr int H = NO * 32;  // only used to walk the gradient accumulators
+  // The lane's 16 accumulator rows (r&3) + 8*(r>>2) + 4*hh are four runs of 4 consecutive negatives:
+  // per-negative side data (item id, inverse norm) comes as one 16-byte LDS read per run and array.
+  const bool want_lse = ALL || head == XFMR_LOSS_INFONCE;
+  if (want_lse && !mask_fn) {
+    // online log-sum-exp: without false-negative masking a counted logit may exceed the running max
+    // (with masking every counted logit is < the positive's, and m = scale * pos stays fixed)
+    float bmax = m;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[8 * g + 4 * hh]);
+      const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool same = nn[u] == pos_item;
+        const bool md = (nn[u] >= 0) & !(catalog & same);
+        bmax = fmaxf(bmax, md ? (same ? pos_dot : s[4 * g + u]) * sc2 : m);
+      }
+    }
+    bmax = fmaxf(bmax, xf_half_swap(bmax));
+    if (__any(bmax > m)) {
+      const float alpha = xf_exp2(m - bmax);
+      l *= alpha;
+      if (head == XFMR_LOSS_INFONCE) {
+#pragma unroll
+        for (int i = 0; i < H / 32; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        sw *= alpha;
+      }
+      m = bmax;
+    }
+  }
+  // Every head's row reductions and the train head's gradient weight (left in s[r] for the second MFMA).
+  // Branch-free per element; the `head` switches are wave-uniform.
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl0 = 8 * g + 4 * hh;
+    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[jl0]);
+    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+    float rc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ALL || cos_head) {
+      const float4 c4 = *reinterpret_cast<const float4*>(&rc_sb[jl0]);
+      rc[0] = c4.x; rc[1] = c4.y; rc[2] = c4.z; rc[3] = c4.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * g + u;
+      const bool valid = nn[u] >= 0;
+      const bool same = nn[u] == pos_item;  // exact tie: the negative IS the positive item
+      const float sv = same ? pos_dot : s[r];
+      const bool excl = catalog & same;
+      const float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? 1.f : 0.f;
+      float w = 0.f;
+      cnt_d += md;
+      if (want_lse) {
+        // counted logits are <= m by construction; the clamp keeps an uncounted large logit from inf * 0
+        const float e = xf_exp2(fminf(sv * sc2 - m, 0.f)) * md;
+        l += e;
+        if (head == XFMR_LOSS_INFONCE) w = e;
+      }
+      if (ALL || head == XFMR_LOSS_NCE) {
+        const float t = xf_exp2(-fabsf(sv) * kLog2e);                    // exp(-|x|)
+        nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // softplus(x)
+        if (head == XFMR_LOSS_NCE) w = md * xf_rcp(1.f + t) * (sv >= 0.f ? 1.f : t);  // sigmoid(x)
+      }
+      if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
+        const float d = sv - chinge;
+        hinge = fmaf(fmaxf(d, 0.f), md, hinge);
+        if (head == XFMR_LOSS_PAIRWISE_HINGE) w = d > 0.f ? md : 0.f;
+        if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
+          const float t = xf_exp2(-fabsf(d) * kLog2e);
+          logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
+          if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md * xf_rcp(1.f + t) * (d >= 0.f ? 1.f : t);
+        }
+      }
+      if (ALL || cos_head) {
+        const float c = same ? cpos : sv * rq * rc[u];
+        const float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? 1.f : 0.f;
+        cnt_c += mc;
+        const float d = c - 1.f + k.margin;
+        contr = fmaf(fmaxf(d, 0.f), mc, contr);
+        if (head == XFMR_LOSS_CONTRASTIVE || head == XFMR_LOSS_ALIGNMENT_CONTRASTIVE)
+          w = d > 0.f ? mc * rc[u] : 0.f;
+      }
+      if (ALL) {
+        ssum = fmaf(sv, md, ssum);
+        ssq = fmaf(sv * sv, md, ssq);
+        smin = fminf(smin, md > 0.f ? sv : INFINITY);
+        smax = fmaxf(smax, md > 0.f ? sv : -INFINITY);
+      }
+      sw += w;
+      s[r] = w;
+    }
+    // keep the scheduler from interleaving the four runs (it otherwise holds all 16 elements' temporaries
+    // live at once and spills at 2 waves/SIMD)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// halves of a lane pair (l, l^32) hold disjoint negatives of the same query: combine, then one lane writes
+__device__ __forceinline__ void write_partial(RowState st, float* rec, bool writer, float pos_dot, float rq, float qq) {
+  st.cnt_d += xf_half_swap(st.cnt_d); st.l += xf_half_swap(st.l); st.nce += xf_half_swap(st.nce);
+  st.hinge += xf_half_swap(st.hinge); st.logi += xf_half_swap(st.logi); st.cnt_c += xf_half_swap(st.cnt_c);
+  st.contr += xf_half_swap(st.contr); st.ssum += xf_half_swap(st.ssum); st.ssq += xf_half_swap(st.ssq);
+  st.sw += xf_half_swap(st.sw);
+  st.smin = fminf(st.smin, xf_half_swap(st.smin)); st.smax = fmaxf(st.smax, xf_half_swap(st.smax));
+  if (writer) {
+    rec[R_CNTD] = st.cnt_d; rec[R_M] = st.m; rec[R_L] = st.l; rec[R_NCE] = st.nce; rec[R_HINGE] = st.hinge;
+    rec[R_LOGI] = st.logi; rec[R_CNTC] = st.cnt_c; rec[R_CONTR] = st.contr; rec[R_SSUM] = st.ssum;
+    rec[R_SSQ] = st.ssq; rec[R_SMIN] = st.smin; rec[R_SMAX] = st.smax; rec[R_SW] = st.sw;
+    rec[R_POSDOT] = pos_dot; rec[R_RQ] = rq; rec[R_QQ] = qq;
+  }
+}
+
 // ---- main kernel -------------------------------------------------------------------------------------
 template <class P, int H, bool ALL>
 __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(LossArgs a) {
@@ -186,8 +321,8 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   const bool cos_head = head <= XFMR_LOSS_CONTRASTIVE;
   const bool do_grad = a.need_grad && head != XFMR_LOSS_ALIGNMENT;
 
-  float cnt_d = 0.f, m = z2pos, l = 0.f, nce = 0.f, hinge = 0.f, logi = 0.f, cnt_c = 0.f, contr = 0.f;
-  float ssum = 0.f, ssq = 0.f, smin = INFINITY, smax = -INFINITY, sw = 0.f;
+  RowState st{0.f, z2pos, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, INFINITY, -INFINITY, 0.f};
+  const RowConst kc{pos_dot, cpos, chinge, sc2, rq, a.margin, pos_item, head, mask_fn, catalog, cos_head};
   f32x16 o[H / 32];
 #pragma unroll
   for (int i = 0; i < H / 32; ++i)
@@ -259,103 +394,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
       if (Q_IN_LDS) P::tile_nt(s, sE, LDE, sb * 32, sQ, LDE, wid * 32, H);
       else P::tile_nreg(s, sE, LDE, sb * 32, qreg.regs(), H);
 
-      // The lane's 16 accumulator rows (r&3) + 8*(r>>2) + 4*hh are four runs of 4 consecutive negatives:
-      // per-negative side data (item id, inverse norm) comes as one 16-byte LDS read per run and array.
-      const bool want_lse = ALL || head == XFMR_LOSS_INFONCE;
-      if (want_lse && !mask_fn) {
-        // online log-sum-exp: without false-negative masking a counted logit may exceed the running max
-        // (with masking every counted logit is < the positive's, and m = scale * pos stays fixed)
-        float bmax = m;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int4 n4 = *reinterpret_cast<const int4*>(&sNid[sb * 32 + 8 * g + 4 * hh]);
-          const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const bool same = nn[u] == pos_item;
-            const bool md = (nn[u] >= 0) & !(catalog & same);
-            bmax = fmaxf(bmax, md ? (same ? pos_dot : s[4 * g + u]) * sc2 : m);
-          }
-        }
-        bmax = fmaxf(bmax, xf_half_swap(bmax));
-        if (__any(bmax > m)) {
-          const float alpha = xf_exp2(m - bmax);
-          l *= alpha;
-          if (head == XFMR_LOSS_INFONCE) {
-#pragma unroll
-            for (int i = 0; i < H / 32; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            sw *= alpha;
-          }
-          m = bmax;
-        }
-      }
-      // Every head's row reductions and the train head's gradient weight (left in s[r] for the second MFMA).
-      // Branch-free per element; the `head` switches are wave-uniform.
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int jl0 = sb * 32 + 8 * g + 4 * hh;
-        const int4 n4 = *reinterpret_cast<const int4*>(&sNid[jl0]);
-        const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
-        float rc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ALL || cos_head) {
-          const float4 c4 = *reinterpret_cast<const float4*>(&sRc[jl0]);
-          rc[0] = c4.x; rc[1] = c4.y; rc[2] = c4.z; rc[3] = c4.w;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int r = 4 * g + u;
-          const bool valid = nn[u] >= 0;
-          const bool same = nn[u] == pos_item;  // exact tie: the negative IS the positive item
-          const float sv = same ? pos_dot : s[r];
-          const bool excl = catalog & same;
-          const float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? 1.f : 0.f;
-          float w = 0.f;
-          cnt_d += md;
-          if (want_lse) {
-            // counted logits are <= m by construction; the clamp keeps an uncounted large logit from inf * 0
-            const float e = xf_exp2(fminf(sv * sc2 - m, 0.f)) * md;
-            l += e;
-            if (head == XFMR_LOSS_INFONCE) w = e;
-          }
-          if (ALL || head == XFMR_LOSS_NCE) {
-            const float t = xf_exp2(-fabsf(sv) * kLog2e);                    // exp(-|x|)
-            nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // softplus(x)
-            if (head == XFMR_LOSS_NCE) w = md * xf_rcp(1.f + t) * (sv >= 0.f ? 1.f : t);  // sigmoid(x)
-          }
-          if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
-            const float d = sv - chinge;
-            hinge = fmaf(fmaxf(d, 0.f), md, hinge);
-            if (head == XFMR_LOSS_PAIRWISE_HINGE) w = d > 0.f ? md : 0.f;
-            if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
-              const float t = xf_exp2(-fabsf(d) * kLog2e);
-              logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
-              if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md * xf_rcp(1.f + t) * (d >= 0.f ? 1.f : t);
-            }
-          }
-          if (ALL || cos_head) {
-            const float c = same ? cpos : sv * rq * rc[u];
-            const float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? 1.f : 0.f;
-            cnt_c += mc;
-            const float d = c - 1.f + a.margin;
-            contr = fmaf(fmaxf(d, 0.f), mc, contr);
-            if (head == XFMR_LOSS_CONTRASTIVE || head == XFMR_LOSS_ALIGNMENT_CONTRASTIVE)
-              w = d > 0.f ? mc * rc[u] : 0.f;
-          }
-          if (ALL) {
-            ssum = fmaf(sv, md, ssum);
-            ssq = fmaf(sv * sv, md, ssq);
-            smin = fminf(smin, md > 0.f ? sv : INFINITY);
-            smax = fmaxf(smax, md > 0.f ? sv : -INFINITY);
-          }
-          sw += w;
-          s[r] = w;
-        }
-        // keep the scheduler from interleaving the four runs (it otherwise holds all 16 elements' temporaries
-        // live at once and spills at 2 waves/SIMD)
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      loss_epilogue<ALL>(s, st, o, kc, &sNid[sb * 32], &sRc[sb * 32], hh);
       if (do_grad) {
 #pragma unroll
         for (int i = 0; i < H / 32; ++i) P::tile_xb(o[i], sET, LDT, i * 32, sb * 32, s);
@@ -364,16 +403,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   }
 
   // ---- write the (split, query) partial -----------------------------------------------------------
-  cnt_d += xf_half_swap(cnt_d); l += xf_half_swap(l); nce += xf_half_swap(nce); hinge += xf_half_swap(hinge);
-  logi += xf_half_swap(logi); cnt_c += xf_half_swap(cnt_c); contr += xf_half_swap(contr);
-  ssum += xf_half_swap(ssum); ssq += xf_half_swap(ssq); sw += xf_half_swap(sw);
-  smin = fminf(smin, xf_half_swap(smin)); smax = fmaxf(smax, xf_half_swap(smax));
-  if (lane < 32 && qvalid) {
-    float* rec = a.part + ((int64_t)split * a.T + qi) * REC;
-    rec[R_CNTD] = cnt_d; rec[R_M] = m; rec[R_L] = l; rec[R_NCE] = nce; rec[R_HINGE] = hinge; rec[R_LOGI] = logi;
-    rec[R_CNTC] = cnt_c; rec[R_CONTR] = contr; rec[R_SSUM] = ssum; rec[R_SSQ] = ssq; rec[R_SMIN] = smin;
-    rec[R_SMAX] = smax; rec[R_SW] = sw; rec[R_POSDOT] = pos_dot; rec[R_RQ] = rq; rec[R_QQ] = qq;
-  }
+  write_partial(st, a.part + ((int64_t)split * a.T + qi) * REC, lane < 32 && qvalid, pos_dot, rq, qq);
   if (do_grad) {
     __syncthreads();  // sScratch aliases the tile images other waves may still be reading
     float* base = a.partO + (int64_t)split * a.T * H;
@@ -383,11 +413,30 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   }
 }
 
+#include "loss_dma.inc"
+
+// bf16 copy of the frozen table (gather source of the LDS-DMA path) + per-item inverse norms
+__global__ void table_prepare_kernel(const float* table, float* rnorm, __bf16* tbf, int64_t rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < H; c += 64) {
+    const float e = table[row * H + c];
+    s += e * e;
+    if (tbf) tbf[row * H + c] = (__bf16)e;
+  }
+  s = xf_wave_sum(s);
+  if (lane == 0 && rnorm) rnorm[row] = 1.f / fmaxf(sqrtf(s), 1e-8f);
+}
+
 // ---- combine: one wave per query -----------------------------------------------------------------------
 struct CombineArgs {
   const float* tok; const float* table; const float* rnorm;
   const int* counts; const int* qrow; const int* qpos;
-  const float* part; const float* partO;
+  const float* part;       // records of the gradient pass (m, l, sw, counts as the gradient weights used them)
+  const float* part_loss;  // records the loss values / statistics are read from (== part in single-pass modes)
+  const float* partO;
   float* d_tok; double* blockpart;
   int T, H, nsplit, train_head, need_grad, mode; int64_t n_rows;
   float scale, margin;
@@ -405,45 +454,53 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
   for (int k = 0; k < BP; ++k) acc[k] = 0.0;
   acc[20] = INFINITY; acc[21] = -INFINITY; acc[22] = INFINITY; acc[23] = -INFINITY;
   if (qi < Nq) {
-    // merge the split partials (every lane computes the same scalars)
+    // merge the split partials (every lane computes the same scalars). Loss VALUES come from part_loss (the
+    // logging pass when there is one), everything the gradient is normalised with from the gradient pass.
     const float* r0 = a.part + (int64_t)qi * REC;
     const float pos_dot = r0[R_POSDOT], rq = r0[R_RQ], qq = r0[R_QQ];
-    float M = -INFINITY;
-    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part[((int64_t)s * a.T + qi) * REC + R_M]);
-    float cnt_d = 0, l = 0, nce = 0, hinge = 0, logi = 0, cnt_c = 0, contr = 0, ssum = 0, ssq = 0, sw = 0;
-    float smin = INFINITY, smax = -INFINITY;
-    for (int s = 0; s < a.nsplit; ++s) {
-      const float* r = a.part + ((int64_t)s * a.T + qi) * REC;
-      const float f = exp2f(r[R_M] - M);
-      cnt_d += r[R_CNTD]; l += r[R_L] * f; nce += r[R_NCE]; hinge += r[R_HINGE]; logi += r[R_LOGI];
-      cnt_c += r[R_CNTC]; contr += r[R_CONTR]; ssum += r[R_SSUM]; ssq += r[R_SSQ];
-      smin = fminf(smin, r[R_SMIN]); smax = fmaxf(smax, r[R_SMAX]);
-      sw += (a.train_head == XFMR_LOSS_INFONCE) ? r[R_SW] * f : r[R_SW];
-    }
     const int pit = a.qpos[qi];
     const float rcpos = a.rnorm[pit];
     const float cpos = pos_dot * rq * rcpos;
     const float sc2 = a.scale * kLog2e;
     const float z2pos = pos_dot * sc2;
+    struct Merged { float M, l, cnt_d, cnt_c, sw, nce, hinge, logi, contr, ssum, ssq, smin, smax; };
+    auto merge = [&](const float* base) {
+      Merged g{-INFINITY, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, INFINITY, -INFINITY};
+      for (int s = 0; s < a.nsplit; ++s) g.M = fmaxf(g.M, base[((int64_t)s * a.T + qi) * REC + R_M]);
+      for (int s = 0; s < a.nsplit; ++s) {
+        const float* r = base + ((int64_t)s * a.T + qi) * REC;
+        const float f = exp2f(r[R_M] - g.M);
+        g.cnt_d += r[R_CNTD]; g.l += r[R_L] * f; g.nce += r[R_NCE]; g.hinge += r[R_HINGE]; g.logi += r[R_LOGI];
+        g.cnt_c += r[R_CNTC]; g.contr += r[R_CONTR]; g.ssum += r[R_SSUM]; g.ssq += r[R_SSQ];
+        g.smin = fminf(g.smin, r[R_SMIN]); g.smax = fmaxf(g.smax, r[R_SMAX]);
+        g.sw += (a.train_head == XFMR_LOSS_INFONCE) ? r[R_SW] * f : r[R_SW];
+      }
+      return g;
+    };
+    const Merged G = merge(a.part);
+    const Merged V = (a.part_loss == a.part) ? G : merge(a.part_loss);
+    {
+      const float ltot_v = V.l + exp2f(z2pos - V.M);
+      const float inv_dv = 1.f / (V.cnt_d + 1e-9f), inv_cv = 1.f / (V.cnt_c + 1e-9f);
+      const float loss_align = 1.f - cpos;
+      const float loss_contr = V.contr * inv_cv;
+      acc[XFMR_LOSS_ALIGNMENT] = loss_align;
+      acc[XFMR_LOSS_ALIGNMENT_CONTRASTIVE] = loss_align + loss_contr;
+      acc[XFMR_LOSS_CONTRASTIVE] = loss_contr;
+      acc[XFMR_LOSS_INFONCE] = (V.M + log2f(ltot_v)) * kLn2 - a.scale * pos_dot;
+      acc[XFMR_LOSS_NCE] = xf_softplus(-pos_dot) + V.nce * inv_dv;
+      acc[XFMR_LOSS_PAIRWISE_HINGE] = V.hinge * inv_dv;
+      acc[XFMR_LOSS_PAIRWISE_LOGISTIC] = V.logi * inv_dv;
+      acc[8] = (double)V.cnt_d / ((double)N + 1e-9);  // density term
+      acc[9] = pos_dot; acc[10] = (double)pos_dot * pos_dot;
+      acc[11] = V.ssum; acc[12] = V.ssq; acc[13] = V.cnt_d; acc[14] = 1.0;
+      acc[20] = pos_dot; acc[21] = pos_dot; acc[22] = V.smin; acc[23] = V.smax;
+    }
+    // gradient-side quantities
+    const float M = G.M, sw = G.sw;
     const float epos = exp2f(z2pos - M);  // M >= z2pos
-    const float ltot = l + epos;
-    const float inv_d = 1.f / (cnt_d + 1e-9f), inv_c = 1.f / (cnt_c + 1e-9f);
-    const float loss_align = 1.f - cpos;
-    const float loss_contr = contr * inv_c;
-    const float loss_info = (M + log2f(ltot)) * kLn2 - a.scale * pos_dot;
-    const float loss_nce = xf_softplus(-pos_dot) + nce * inv_d;
-    const float loss_hinge = hinge * inv_d, loss_logi = logi * inv_d;
-    acc[XFMR_LOSS_ALIGNMENT] = loss_align;
-    acc[XFMR_LOSS_ALIGNMENT_CONTRASTIVE] = loss_align + loss_contr;
-    acc[XFMR_LOSS_CONTRASTIVE] = loss_contr;
-    acc[XFMR_LOSS_INFONCE] = loss_info;
-    acc[XFMR_LOSS_NCE] = loss_nce;
-    acc[XFMR_LOSS_PAIRWISE_HINGE] = loss_hinge;
-    acc[XFMR_LOSS_PAIRWISE_LOGISTIC] = loss_logi;
-    acc[8] = (double)cnt_d / ((double)N + 1e-9);  // density term
-    acc[9] = pos_dot; acc[10] = (double)pos_dot * pos_dot;
-    acc[11] = ssum; acc[12] = ssq; acc[13] = cnt_d; acc[14] = 1.0;
-    acc[20] = pos_dot; acc[21] = pos_dot; acc[22] = smin; acc[23] = smax;
+    const float ltot = G.l + epos;
+    const float inv_d = 1.f / (G.cnt_d + 1e-9f), inv_c = 1.f / (G.cnt_c + 1e-9f);
 
     if (a.need_grad) {
       const int head = a.train_head;
@@ -558,6 +615,7 @@ __global__ __launch_bounds__(1024) void loss_final_kernel(const double* blockpar
 // ---- host side ---------------------------------------------------------------------------------------------
 struct Plan {
   int nsplit;
+  size_t off_part2;
   size_t off_counts, off_blockcnt, off_neg, off_qrow, off_qpos, off_part, off_partO, off_block, total;
   int nblocks;
 };
@@ -580,6 +638,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows) {
   p.off_qrow = o; o += up256((size_t)T * 4);
   p.off_qpos = o; o += up256((size_t)T * 4);
   p.off_part = o; o += up256((size_t)ns * T * REC * 4);
+  p.off_part2 = o; o += up256((size_t)ns * T * REC * 4);
   p.off_partO = o; o += up256((size_t)ns * T * H * 4);
   p.off_block = o; o += up256((size_t)p.nblocks * BP * 8);
   p.total = o;
@@ -597,6 +656,24 @@ int launch_main_h(const LossArgs& a, int H, bool all, dim3 grid, hipStream_t st)
     case 64: launch_main<P, 64>(a, all, grid, st); break;
     case 128: launch_main<P, 128>(a, all, grid, st); break;
     case 256: launch_main<P, 256>(a, all, grid, st); break;
+    default: return XFMR_EUNSUPPORTED;
+  }
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+// role 0: train head + gradient; role 1: all heads + statistics, values only; role 2: train head, values only
+template <int H>
+void launch_dma(const LossArgs& a, const __bf16* tbf, int role, dim3 grid, hipStream_t st) {
+  if (role == 0) hipLaunchKernelGGL((loss_main_dma_kernel<H, false, true>), grid, dim3(256), 0, st, a, tbf);
+  else if (role == 1) hipLaunchKernelGGL((loss_main_dma_kernel<H, true, false>), grid, dim3(256), 0, st, a, tbf);
+  else hipLaunchKernelGGL((loss_main_dma_kernel<H, false, false>), grid, dim3(256), 0, st, a, tbf);
+}
+int launch_dma_h(const LossArgs& a, const __bf16* tbf, int H, int role, dim3 grid, hipStream_t st) {
+  switch (H) {
+    case 64: launch_dma<64>(a, tbf, role, grid, st); break;
+    case 128: launch_dma<128>(a, tbf, role, grid, st); break;
+    case 256: launch_dma<256>(a, tbf, role, grid, st); break;
     default: return XFMR_EUNSUPPORTED;
   }
   XF_LAUNCH_CHECK();
@@ -623,7 +700,7 @@ size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows)
 }
 
 static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* table, const float* table_rnorm,
-                    int64_t n_rows, int T, int32_t H, float* losses, float* stats, float* d_tok, unsigned char* ws,
+                    const void* table_bf16, int64_t n_rows, int T, int32_t H, float* losses, float* stats, float* d_tok, unsigned char* ws,
                     const Plan& p, hipStream_t st) {
   int* counts = (int*)(ws + p.off_counts);
   int* neg_item = (int*)(ws + p.off_neg);
@@ -639,16 +716,41 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   int rc;
   hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
   g_prof_start = g_prof_stop = nullptr;  // one-shot
-  if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
-  if (cfg->precision == XFMR_PREC_BF16) rc = launch_main_h<PrecBF16>(a, H, cfg->all_heads != 0, grid, st);
-  else if (cfg->precision == XFMR_PREC_F32) rc = launch_main_h<PrecF32>(a, H, cfg->all_heads != 0, grid, st);
-  else rc = XFMR_EINVAL;
-  if (rc) return rc;
-  if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
+  const float* part_loss = nullptr;  // records the loss VALUES are read from (null: the same as the gradient's)
+  if (cfg->precision == XFMR_PREC_BF16 && table_bf16) {
+    const __bf16* tbf = (const __bf16*)table_bf16;
+    const bool all = cfg->all_heads != 0;
+    if (a.need_grad) {
+      if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
+      rc = launch_dma_h(a, tbf, H, 0, grid, st);
+      if (rc) return rc;
+      if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
+      if (all) {
+        LossArgs b = a;
+        b.part = (float*)(ws + p.off_part2);
+        b.need_grad = 0;
+        rc = launch_dma_h(b, tbf, H, 1, grid, st);
+        if (rc) return rc;
+        part_loss = b.part;
+      }
+    } else {
+      if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
+      rc = launch_dma_h(a, tbf, H, all ? 1 : 2, grid, st);
+      if (rc) return rc;
+      if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
+    }
+  } else {
+    if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
+    if (cfg->precision == XFMR_PREC_BF16) rc = launch_main_h<PrecBF16>(a, H, cfg->all_heads != 0, grid, st);
+    else if (cfg->precision == XFMR_PREC_F32) rc = launch_main_h<PrecF32>(a, H, cfg->all_heads != 0, grid, st);
+    else rc = XFMR_EINVAL;
+    if (rc) return rc;
+    if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
+  }
 
   CombineArgs c{};
   c.tok = tok; c.table = table; c.rnorm = table_rnorm; c.counts = counts; c.qrow = qrow; c.qpos = qpos;
-  c.part = a.part; c.partO = a.partO; c.d_tok = d_tok; c.blockpart = (double*)(ws + p.off_block);
+  c.part = a.part; c.part_loss = part_loss ? part_loss : a.part; c.partO = a.partO; c.d_tok = d_tok; c.blockpart = (double*)(ws + p.off_block);
   c.T = T; c.H = H; c.nsplit = p.nsplit; c.train_head = cfg->train_head; c.need_grad = d_tok != nullptr;
   c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
@@ -670,8 +772,8 @@ static int check_loss_args(const xfmr_loss_cfg* cfg, const float* tok, const flo
 }
 
 int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
-                      const int64_t* neg_idx, const float* table, const float* table_rnorm, int64_t n_rows,
-                      int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
+                      const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
+                      int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
                       size_t workspace_bytes, void* stream) {
   if (int rc = check_loss_args(cfg, tok, table, table_rnorm, losses, stats, workspace, d_tok, positions, n_rows))
     return rc;
@@ -692,7 +794,8 @@ int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t*
                      (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
   XF_LAUNCH_CHECK();
   if (d_tok && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
-  return run_loss(cfg, tok, table, table_rnorm, n_rows, T, H, losses, stats, d_tok, ws, p, st);
+  if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
+  return run_loss(cfg, tok, table, table_rnorm, table_bf16, n_rows, T, H, losses, stats, d_tok, ws, p, st);
 }
 
 size_t xfmr_sampled_loss_lists_workspace(int64_t n_query, int64_t n_neg, int32_t H, int64_t n_rows) {
@@ -703,8 +806,8 @@ size_t xfmr_sampled_loss_lists_workspace(int64_t n_query, int64_t n_neg, int32_t
 
 int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const int64_t* pos_items,
                             const int64_t* neg_items, int64_t n_query, int64_t n_neg, const float* table,
-                            const float* table_rnorm, int64_t n_rows, int32_t H, float* losses, float* stats,
-                            float* d_query, void* workspace, size_t workspace_bytes, void* stream) {
+                            const float* table_rnorm, const void* table_bf16, int64_t n_rows, int32_t H,
+                            float* losses, float* stats, float* d_query, void* workspace, size_t workspace_bytes, void* stream) {
   const int64_t rows = n_query > n_neg ? n_query : n_neg;
   if (int rc = check_loss_args(cfg, query, table, table_rnorm, losses, stats, workspace, d_query, rows, n_rows))
     return rc;
@@ -720,7 +823,17 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
                      (int)(cfg->mode == XFMR_NEG_SHARED ? n_neg : 0), n_rows, (int*)(ws + p.off_counts),
                      (int*)(ws + p.off_neg), (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
   XF_LAUNCH_CHECK();
-  return run_loss(cfg, query, table, table_rnorm, n_rows, T, H, losses, stats, d_query, ws, p, st);
+  if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
+  return run_loss(cfg, query, table, table_rnorm, table_bf16, n_rows, T, H, losses, stats, d_query, ws, p, st);
+}
+
+int xfmr_table_prepare(const float* table, float* table_rnorm, void* table_bf16, int64_t n_rows, int32_t H,
+                       void* stream) {
+  if (!table || n_rows <= 0 || H <= 0 || (!table_rnorm && !table_bf16)) return XFMR_EINVAL;
+  hipLaunchKernelGGL(table_prepare_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     table, table_rnorm, (__bf16*)table_bf16, n_rows, H);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
 }
 
 }  // extern "C"

@@ -82,11 +82,74 @@ __global__ __launch_bounds__(64) void selftest_kernel(int* out) {
   }
 }
 
+// ---- swizzled LDS-DMA image: gather layout, row-operand reads, ds_read_b64_tr_b16 transposed reads ----------
+constexpr int SH = 128, SROWS = 64;
+__global__ void selftest_fill_kernel(__bf16* src) {
+  for (int i = threadIdx.x; i < SROWS * SH; i += blockDim.x) src[i] = (__bf16)tval(5, i / SH, i % SH);
+}
+__global__ __launch_bounds__(64) void selftest_swz_kernel(const __bf16* src, int* out) {
+  using SI = SwzImg<SH>;
+  __shared__ __attribute__((aligned(16))) __bf16 img[SROWS * SH];
+  __shared__ __attribute__((aligned(16))) float sRow[32 * SH];
+  const int lane = xf_lane();
+  int bad = 0;
+  // gather rows in a permuted order (row r of the image <- source row perm(r)) through LDS-DMA
+  for (int q = 0; q < SROWS / SI::kRowsPerInstr; ++q) {
+    const int r = SI::gather_row(q * SI::kRowsPerInstr);
+    const int srow = (r * 7 + 3) % SROWS;
+    xf_glds16(src + srow * SH + 8 * SI::gather_src_chunk(r), img + q * 512);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  // (a) placement: logical element (r, col) sits at off(r, col/8) + col%8
+  for (int i = lane; i < SROWS * SH; i += 64) {
+    const int r = i / SH, col = i % SH;
+    bad += ((float)img[SI::off(r, col >> 3) + (col & 7)] != tval(5, (r * 7 + 3) % SROWS, col));
+  }
+  // (b) row-operand product: C[j][i] = sum_h IMG[32 + j][h] * B[i][h], B rows via RegRows
+  for (int i = lane; i < 32 * SH; i += 64) sRow[i] = tval(2, i / SH, i % SH);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  RegRows<PrecBF16, SH> breg;
+  breg.load(sRow + (lane & 31) * SH, true);
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  SI::tile_nreg(acc, img, 32, breg.regs());
+  for (int r = 0; r < 16; ++r) {
+    const int j = 32 + xf_acc_row(r, lane), i = lane & 31;
+    float ref = 0.f;
+    for (int h = 0; h < SH; ++h) ref += tval(5, (j * 7 + 3) % SROWS, h) * tval(2, i, h);
+    bad += (acc[r] != ref);
+  }
+  // (c) transposed product: Y[h][col] = sum_k IMG[32 + k][hsub*32 + h] * X[k][col]
+  f32x16 x;
+  for (int r = 0; r < 16; ++r) x[r] = tval(4, xf_acc_row(r, lane), lane & 31);
+  for (int hsub = 0; hsub < SH / 32; ++hsub) {
+    f32x16 y;
+    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+    SI::tile_xb_tr(y, img, hsub, 32, x);
+    for (int r = 0; r < 16; ++r) {
+      const int h = hsub * 32 + xf_acc_row(r, lane), col = lane & 31;
+      float ref = 0.f;
+      for (int kk = 0; kk < 32; ++kk) ref += tval(5, ((32 + kk) * 7 + 3) % SROWS, h) * tval(4, kk, col);
+      bad += (y[r] != ref);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if (lane == 0) out[3] = bad;
+}
+
 }  // namespace
 
 extern "C" int xfmr_selftest_mfma(int32_t* out, void* stream) {
   if (!out) return XFMR_EINVAL;
-  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, out);
+  XF_LAUNCH_CHECK();
+  __bf16* src = reinterpret_cast<__bf16*>(out + 4);  // scratch: 64 x 128 bf16 = 16 KiB behind the 4 result words
+  hipLaunchKernelGGL(selftest_fill_kernel, dim3(1), dim3(256), 0, st, src);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(selftest_swz_kernel, dim3(1), dim3(64), 0, st, (const __bf16*)src, out);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }

@@ -58,8 +58,8 @@ class _StructuredCandidates:
 class SharedNegatives(_StructuredCandidates):
     """``cat([E[pos_items][:, None], E[neg_items][None].expand(Np, -1, -1)], 1)`` without the copy."""
 
-    def __init__(self, table, table_rnorm, pos_items, neg_items):
-        self.table, self.table_rnorm = table, table_rnorm
+    def __init__(self, table, table_rnorm, pos_items, neg_items, table_bf16=None):
+        self.table, self.table_rnorm, self.table_bf16 = table, table_rnorm, table_bf16
         self.pos_items, self.neg_items = pos_items.contiguous(), neg_items.contiguous()
 
     @property
@@ -76,8 +76,8 @@ class SharedNegatives(_StructuredCandidates):
 class CatalogCandidates(_StructuredCandidates):
     """``table[None].expand(Np, -1, -1)``: every item is a column; ``target`` names the positive."""
 
-    def __init__(self, table, table_rnorm, n_query: int):
-        self.table, self.table_rnorm, self.n_query = table, table_rnorm, int(n_query)
+    def __init__(self, table, table_rnorm, n_query: int, table_bf16=None):
+        self.table, self.table_rnorm, self.n_query, self.table_bf16 = table, table_rnorm, int(n_query), table_bf16
 
     @property
     def shape(self):
@@ -148,12 +148,13 @@ class EmbedLoss(torch.nn.Module, abc.ABC):
                 raise ValueError("SharedNegatives candidates put the positive at column 0: target_position='first'")
             return ops.SampledLossListsFunction.apply(
                 q, candidate_embed.pos_items, candidate_embed.neg_items, candidate_embed.table,
-                candidate_embed.table_rnorm, self._opts(N.NEG_SHARED, all_heads=all_heads),
+                candidate_embed.table_rnorm,
+                self._opts(N.NEG_SHARED, all_heads=all_heads) | {"table_bf16": candidate_embed.table_bf16},
             )
         if isinstance(candidate_embed, CatalogCandidates):
             if target is None:
                 raise ValueError("CatalogCandidates need `target` (the positive item index per row)")
-            opts = self._opts(N.NEG_CATALOG, all_heads=all_heads)
+            opts = self._opts(N.NEG_CATALOG, all_heads=all_heads) | {"table_bf16": candidate_embed.table_bf16}
             if opts["mask_false_negatives"]:
                 # the reference would additionally mask catalogue items scoring above the positive; supported
                 pass

@@ -114,6 +114,7 @@ class RecommenderModel(torch.nn.Module):
         self.precision = precision
         self.embeddings: torch.Tensor | None = None  # frozen (V+1, H) table, row 0 = padding
         self.table_rnorm: torch.Tensor | None = None
+        self.table_bf16: torch.Tensor | None = None
         self.id2idx = None
         self._step = 0
         self._seed = int(seed)
@@ -220,7 +221,8 @@ class RecommenderModel(torch.nn.Module):
     def set_table(self, table: torch.Tensor) -> None:
         """Install a ready ``(V+1, H)`` table (row 0 = padding)."""
         self.embeddings = table.contiguous()
-        self.table_rnorm = ops.table_rnorm(self.embeddings) if table.is_cuda else None
+        # frozen table => per-item inverse norms and the bf16 gather copy are computed once
+        self.table_rnorm, self.table_bf16 = ops.table_prepare(self.embeddings) if table.is_cuda else (None, None)
 
     # ------------------------------------------------------------------ compute
     def _cfg(self, B: int, L: int) -> N.EncoderCfg:
@@ -286,7 +288,7 @@ class RecommenderModel(torch.nn.Module):
         neg = neg_item_idx.to(self.device)[am]
         keep = pos != 0
         query = tok[am][keep]
-        cand = SharedNegatives(self.embeddings, self.table_rnorm, pos[keep], neg)
+        cand = SharedNegatives(self.embeddings, self.table_rnorm, pos[keep], neg, table_bf16=self.table_bf16)
         return {"query_embed": query, "candidate_embed": cand, "attention_mask": am, "positive_mask": keep}
 
     # ------------------------------------------------------------------ persistence

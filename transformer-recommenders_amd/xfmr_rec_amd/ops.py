@@ -25,9 +25,9 @@ def _bytes(n: int, like: torch.Tensor):
 
 
 def selftest_mfma(device="cuda") -> list[int]:
-    out = torch.full((4,), -1, dtype=torch.int32, device=device)
+    out = torch.full((4 + 4096,), -1, dtype=torch.int32, device=device)  # 4 result words + 16 KiB scratch
     N.check(N.load().xfmr_selftest_mfma(N.ptr(out), N.stream()), "xfmr_selftest_mfma")
-    return out.tolist()
+    return out[:4].tolist()
 
 
 # ------------------------------------------------------------------------------------------------ per-op
@@ -164,6 +164,15 @@ def table_rnorm(table):
     return out
 
 
+def table_prepare(table):
+    """(rnorm, table_bf16): per-item inverse norms + the bf16 gather copy of the frozen table."""
+    rn = _empty((table.shape[0],), table)
+    tb = torch.empty(table.shape, dtype=torch.bfloat16, device=table.device)
+    N.check(N.load().xfmr_table_prepare(N.ptr(table), N.ptr(rn), N.ptr(tb), table.shape[0], table.shape[1],
+                                        N.stream()), "xfmr_table_prepare")
+    return rn, tb
+
+
 def mean_pool(tok, key_mask):
     B, L, H = tok.shape
     out = _empty((B, H), tok)
@@ -182,7 +191,7 @@ def adamw_(params, grads, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, ep
 
 def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, all_heads=True,
                  mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
-                 need_grad=True):
+                 need_grad=True, table_bf16=None):
     """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H)."""
     H = tok.shape[-1]
     T = tok.numel() // H
@@ -196,7 +205,8 @@ def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, a
     ws = _bytes(nbytes, tok)
     N.check(
         lib.xfmr_sampled_loss(C.byref(cfg), N.ptr(tok), N.ptr(key_mask), N.ptr(pos_idx), N.ptr(neg_idx),
-                              N.ptr(table), N.ptr(rnorm), n_rows, T, H, N.ptr(losses), N.ptr(stats), N.ptr(d_tok),
+                              N.ptr(table), N.ptr(rnorm), N.ptr(table_bf16), n_rows, T, H, N.ptr(losses),
+                              N.ptr(stats), N.ptr(d_tok),
                               N.ptr(ws), nbytes, N.stream()),
         "xfmr_sampled_loss",
     )
@@ -213,7 +223,7 @@ def _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, 
 
 def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head, all_heads=False,
                        mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
-                       need_grad=True):
+                       need_grad=True, table_bf16=None):
     """List form (compacted queries): returns (losses[7], stats[16], d_query or None)."""
     Np, H = query.shape
     Nn = 0 if neg_items is None else neg_items.numel()
@@ -226,7 +236,8 @@ def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head,
     ws = _bytes(nbytes, query)
     N.check(
         lib.xfmr_sampled_loss_lists(C.byref(cfg), N.ptr(query), N.ptr(pos_items), N.ptr(neg_items), Np, Nn,
-                                    N.ptr(table), N.ptr(rnorm), n_rows, H, N.ptr(losses), N.ptr(stats), N.ptr(d_q),
+                                    N.ptr(table), N.ptr(rnorm), N.ptr(table_bf16), n_rows, H, N.ptr(losses),
+                                    N.ptr(stats), N.ptr(d_q),
                                     N.ptr(ws), nbytes, N.stream()),
         "xfmr_sampled_loss_lists",
     )

@@ -133,7 +133,8 @@ class RecommenderLightningModule(_Base):
         pos = batch["pos_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
         neg = batch["neg_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
         opts = dict(train_head=c.train_loss, all_heads=c.log_all_losses, mask_false_negatives=c.mask_false_negatives,
-                    mode=N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision)
+                    mode=N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision,
+                    table_bf16=m.table_bf16)
         train_loss, losses, stats = ops.SampledLossFunction.apply(
             tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts
         )
