@@ -25,16 +25,88 @@ struct GemmArgs {
   XfDropout drop;
 };
 
-constexpr int BK = 32;
+// One operand tile (ROWS x BK, fp32 in memory) in flight in registers, then committed to an LDS image
+// [ROWS][BK + pad] of the MFMA element type. TRANS: memory is [K][rows] (rows contiguous) instead of [rows][K].
+template <class P, int ROWS, int BK, bool TRANS>
+struct OperandTile {
+  static constexpr int N4 = ROWS * BK / 4 / 256;  // float4 per thread
+  static constexpr int LD = xf_ld<P>(BK);
+  float4 reg[N4];
 
-template <class P, int BM, int BN, bool TA, bool TB, int EPI>
+  __device__ __forceinline__ void load(const float* src, int64_t ld, int64_t row0, int64_t rows_total, int k0,
+                                       int kend) {
+    const int tid = threadIdx.x;
+    if (!TRANS) {
+      constexpr int CH = BK / 4;  // 16-byte chunks per row
+#pragma unroll
+      for (int i = 0; i < N4; ++i) {
+        const int c = tid + i * 256;
+        const int r = c / CH, kk = (c % CH) * 4;
+        const int64_t gr = row0 + r;
+        const int gk = k0 + kk;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (gr < rows_total && gk < kend) {
+          const float* p = src + gr * ld + gk;
+          if (gk + 3 < kend) v = *reinterpret_cast<const float4*>(p);
+          else { v.x = p[0]; if (gk + 1 < kend) v.y = p[1]; if (gk + 2 < kend) v.z = p[2]; }
+        }
+        reg[i] = v;
+      }
+    } else {
+      // item -> (k-pair kp, 4 consecutive rows): two float4 (k, k+1) per item so the LDS write is a packed pair
+      constexpr int R4 = ROWS / 4;
+#pragma unroll
+      for (int i = 0; i < N4 / 2; ++i) {
+        const int item = tid + i * 256;
+        const int kp = item / R4, rc = (item % R4) * 4;
+        const int64_t gr = row0 + rc;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int gk = k0 + 2 * kp + u;
+          float4 v = make_float4(0, 0, 0, 0);
+          if (gk < kend && gr < rows_total) {
+            const float* p = src + (int64_t)gk * ld + gr;
+            if (gr + 3 < rows_total) v = *reinterpret_cast<const float4*>(p);
+            else { v.x = p[0]; if (gr + 1 < rows_total) v.y = p[1]; if (gr + 2 < rows_total) v.z = p[2]; }
+          }
+          reg[2 * i + u] = v;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(typename P::elem* dst) const {
+    const int tid = threadIdx.x;
+    if (!TRANS) {
+      constexpr int CH = BK / 4;
+#pragma unroll
+      for (int i = 0; i < N4; ++i) {
+        const int c = tid + i * 256;
+        xf_store4<P>(dst + (c / CH) * LD + (c % CH) * 4, reg[i]);
+      }
+    } else {
+      constexpr int R4 = ROWS / 4;
+#pragma unroll
+      for (int i = 0; i < N4 / 2; ++i) {
+        const int item = tid + i * 256;
+        const int kp = item / R4, rc = (item % R4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          xf_store2<P>(dst + (rc + j) * LD + 2 * kp, xf_get(reg[2 * i], j), xf_get(reg[2 * i + 1], j));
+      }
+    }
+  }
+};
+
+template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using elem = typename P::elem;
-  constexpr int LD = xf_ld<P>(BK);
+  using TileA = OperandTile<P, BM, BK, TA>;
+  using TileB = OperandTile<P, BN, BK, TB>;
+  constexpr int LD = TileA::LD;
   __shared__ __attribute__((aligned(16))) elem sA[BM * LD];
   __shared__ __attribute__((aligned(16))) elem sB[BN * LD];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   const int64_t m0 = (int64_t)blockIdx.y * BM;
@@ -45,80 +117,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     kend = min(g.K, kbeg + g.k_chunk);
   }
 
-  constexpr int NA = BM * BK / 4 / 256;  // float4 per thread per slice
-  constexpr int NB = BN * BK / 4 / 256;
-  float4 ra[NA], rb[NB];
-
-  // ---- global -> register loaders ------------------------------------------------------------
-  auto load_operand = [&](const float* src, int64_t ld, int64_t row0, int64_t rows_total, bool transposed,
-                          int k0, float4* reg, int count, int tile_rows) {
-    if (!transposed) {
-      // memory [rows][K]: chunk c -> row c/8, k-offset (c%8)*4
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < count) {
-          int c = tid + i * 256;
-          int r = c >> 3, kk = (c & 7) * 4;
-          int64_t gr = row0 + r;
-          int gk = k0 + kk;
-          float4 v = make_float4(0, 0, 0, 0);
-          if (gr < rows_total && gk < kend) {
-            const float* p = src + gr * ld + gk;
-            if (gk + 3 < kend) v = *reinterpret_cast<const float4*>(p);
-            else { v.x = p[0]; if (gk + 1 < kend) v.y = p[1]; if (gk + 2 < kend) v.z = p[2]; }
-          }
-          reg[i] = v;
-        }
-      }
-    } else {
-      // memory [K][rows]: item -> k-pair kp, 4 consecutive rows; two float4 (k, k+1) per item
-      const int rows4 = tile_rows / 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (2 * i < count) {
-          int item = tid + i * 256;
-          int kp = item / rows4, rc = (item % rows4) * 4;
-          int64_t gr = row0 + rc;
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            int gk = k0 + 2 * kp + u;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (gk < kend && gr < rows_total) {
-              const float* p = src + (int64_t)gk * ld + gr;
-              if (gr + 3 < rows_total) v = *reinterpret_cast<const float4*>(p);
-              else { v.x = p[0]; if (gr + 1 < rows_total) v.y = p[1]; if (gr + 2 < rows_total) v.z = p[2]; }
-            }
-            reg[2 * i + u] = v;
-          }
-        }
-      }
-    }
-  };
-  auto store_operand = [&](elem* dst, bool transposed, const float4* reg, int count, int tile_rows) {
-    if (!transposed) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < count) {
-          int c = tid + i * 256;
-          int r = c >> 3, kk = (c & 7) * 4;
-          xf_store4<P>(dst + r * LD + kk, reg[i]);
-        }
-      }
-    } else {
-      const int rows4 = tile_rows / 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (2 * i < count) {
-          int item = tid + i * 256;
-          int kp = item / rows4, rc = (item % rows4) * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            xf_store2<P>(dst + (rc + j) * LD + 2 * kp, xf_get(reg[2 * i], j), xf_get(reg[2 * i + 1], j));
-        }
-      }
-    }
-  };
-
   f32x16 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -127,19 +125,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  TileA ta;
+  TileB tb;
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
-    load_operand(g.A, g.lda, m0, g.M, TA, kbeg, ra, NA, BM);
-    load_operand(g.B, g.ldb, n0, g.N, TB, kbeg, rb, NB, BN);
+    ta.load(g.A, g.lda, m0, g.M, kbeg, kend);
+    tb.load(g.B, g.ldb, n0, g.N, kbeg, kend);
   }
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
-    store_operand(sA, TA, ra, NA, BM);
-    store_operand(sB, TB, rb, NB, BN);
+    ta.commit(sA);
+    tb.commit(sB);
     __syncthreads();
-    if (kt + 1 < nk) {
-      load_operand(g.A, g.lda, m0, g.M, TA, kbeg + (kt + 1) * BK, ra, NA, BM);
-      load_operand(g.B, g.ldb, n0, g.N, TB, kbeg + (kt + 1) * BK, rb, NB, BN);
+    if (kt + 1 < nk) {  // next slice in flight while this one is multiplied
+      ta.load(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend);
+      tb.load(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -218,23 +218,40 @@ int launch_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, int6
   return XFMR_OK;
 }
 
-template <class P, bool TA, bool TB, int EPI>
-int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
+template <class P, int BK, bool TA, bool TB, int EPI>
+int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   // These GEMMs are skinny (K <= 1024) and bound by operand streaming + latency, not by MFMA issue: prefer
   // the largest tile that still yields >= 512 workgroups (2 per CU), otherwise the smallest tile.
   auto wgs = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (int64_t)splits; };
   int bm = 64, bn = 64;
-  if (g.N > 64 && g.M > 64 && wgs(128, 128) >= 512) { bm = 128; bn = 128; }
-  else if (g.N > 64 && wgs(64, 128) >= 512) { bm = 64; bn = 128; }
-  else if (g.M > 64 && wgs(128, 64) >= 512) { bm = 128; bn = 64; }
+  if (BK <= 64) {
+    if (g.N > 64 && g.M > 64 && wgs(128, 128) >= 512) { bm = 128; bn = 128; }
+    else if (g.N > 64 && wgs(64, 128) >= 512) { bm = 64; bn = 128; }
+    else if (g.M > 64 && wgs(128, 64) >= 512) { bm = 128; bn = 64; }
+  }
   dim3 block(256);
   dim3 grid((unsigned)((g.N + bn - 1) / bn), (unsigned)((g.M + bm - 1) / bm), splits);
-  if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 128, 128, TA, TB, EPI>), grid, block, 0, st, g);
-  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, TA, TB, EPI>), grid, block, 0, st, g);
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, TA, TB, EPI>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_kernel<P, 64, 64, TA, TB, EPI>), grid, block, 0, st, g);
+  if constexpr (BK <= 64) {
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
+  }
   XF_LAUNCH_CHECK();
   return XFMR_OK;
+}
+
+template <class P, bool TA, bool TB, int EPI>
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
+  // deep slices (one or four trips through the K loop at K = 128 / 512) when the contraction allows it:
+  // more bytes in flight per barrier. bf16 only (the fp32 LDS images would be twice as large).
+  const int kspan = g.k_chunk > 0 ? g.k_chunk : g.K;
+  if constexpr (P::kId == XFMR_PREC_BF16) {
+    if (kspan % 128 == 0) return launch_gemm_bk<P, 128, TA, TB, EPI>(g, splits, st);
+  }
+  return launch_gemm_bk<P, 32, TA, TB, EPI>(g, splits, st);
 }
 
 template <bool TA, bool TB, int EPI>
@@ -251,7 +268,7 @@ int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
   if (want > 64) want = 64;
   if (want < 1) want = 1;
   int64_t chunk = (M + want - 1) / want;
-  chunk = ((chunk + 31) / 32) * 32;
+  chunk = ((chunk + 127) / 128) * 128;  // multiple of the deep K slice
   if (chunk < 64) chunk = 64;
   *k_chunk = (int)chunk;
   return (int)((M + chunk - 1) / chunk);

@@ -15,30 +15,9 @@
 //   * the negatives axis is split across workgroups (grid.y) to fill 256 CUs; a combine kernel merges the
 //     split partials per query, finishes the seven row losses and the gradient row, and a final
 //     single-workgroup kernel reduces them deterministically.
-#include "common.h"
+#include "loss_common.h"
 
 namespace {
-
-constexpr int BN = 64;        // negatives per tile
-constexpr int QB = 128;       // queries per workgroup
-constexpr int REC = 16;       // floats per (split, query) partial record
-constexpr int LDT = BN + 4;   // transposed image [h][j] leading dimension (see attention.hip note)
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
-enum { R_CNTD = 0, R_M, R_L, R_NCE, R_HINGE, R_LOGI, R_CNTC, R_CONTR, R_SSUM, R_SSQ, R_SMIN, R_SMAX, R_SW,
-       R_POSDOT, R_RQ, R_QQ };
-constexpr int BP = 24;        // doubles per block-partial record
-
-struct LossArgs {
-  const float* tok; const float* table; const float* rnorm; int64_t n_rows;
-  const int* counts;      // [0] = N valid positions, [1] = Np queries
-  const int* neg_item;    // [N] (shared mode) or null (catalogue mode: item j)
-  const int* qrow; const int* qpos;
-  float* part; float* partO;
-  int T; int nsplit;
-  int train_head, mask_fn, mode, need_grad;
-  float scale, margin;
-};
 
 // ---- compaction of valid positions (replaces the boolean-mask indexing of models.py:390-404) ------
 // Two fully parallel kernels, order-preserving (the reference's boolean indexing keeps row-major order):
@@ -63,8 +42,8 @@ __global__ __launch_bounds__(PREP) void prepare_count_kernel(const uint8_t* key_
 }
 __global__ __launch_bounds__(PREP) void prepare_write_kernel(const uint8_t* key_mask, const int64_t* pos_idx,
                                                              const int64_t* neg_idx, int T, int64_t n_rows,
-                                                             const int2* blockcnt, int* counts, int* neg_item,
-                                                             int* qrow, int* qpos) {
+                                                             const int2* blockcnt, const float* rnorm, int* counts,
+                                                             int* neg_item, float* neg_rc, int* qrow, int* qpos) {
   __shared__ int sv[PREP / 64], sq[PREP / 64], base[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = blockIdx.x * PREP + tid;
@@ -88,6 +67,7 @@ __global__ __launch_bounds__(PREP) void prepare_write_kernel(const uint8_t* key_
     int64_t ni = neg_idx ? neg_idx[i] : 0;
     if (ni < 0 || ni >= n_rows) ni = 0;
     neg_item[ov] = (int)ni;
+    neg_rc[ov] = rnorm[ni];
     if (q) {
       qrow[oq] = i;
       qpos[oq] = (int)((pi < 0 || pi >= n_rows) ? 0 : pi);
@@ -101,7 +81,8 @@ __global__ __launch_bounds__(PREP) void prepare_write_kernel(const uint8_t* key_
 
 // ---- list form: queries already compacted (EmbedLoss.forward(query_embed, candidates)) ------------
 __global__ void prepare_lists_kernel(const int64_t* pos_items, const int64_t* neg_items, int Np, int N,
-                                     int64_t n_rows, int* counts, int* neg_item, int* qrow, int* qpos) {
+                                     int64_t n_rows, const float* rnorm, int* counts, int* neg_item, float* neg_rc,
+                                     int* qrow, int* qpos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
     counts[0] = N;
@@ -117,141 +98,7 @@ __global__ void prepare_lists_kernel(const int64_t* pos_items, const int64_t* ne
     int64_t n = neg_items[i];
     if (n < 0 || n >= n_rows) n = 0;
     neg_item[i] = (int)n;
-  }
-}
-
-// ---- per-sub-block epilogue shared by both main kernels ----------------------------------------------------
-// s: the 32x32 tile S^T (negative in the registers, query on the lane) on entry, the train head's gradient
-// weights on exit. nid_sb / rc_sb: LDS side data (item id, inverse norm) of the sub-block's 32 negatives.
-struct RowState {
-  float cnt_d, m, l, nce, hinge, logi, cnt_c, contr, ssum, ssq, smin, smax, sw;
-};
-struct RowConst {
-  float pos_dot, cpos, chinge, sc2, rq, margin;
-  int pos_item, head;
-  bool mask_fn, catalog, cos_head;
-};
-template <bool ALL, int NO>
-__device__ __forceinline__ void loss_epilogue(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
-                                              const int* nid_sb, const float* rc_sb, int hh) {
-  float& cnt_d = st.cnt_d; float& m = st.m; float& l = st.l; float& nce = st.nce; float& hinge = st.hinge;
-  float& logi = st.logi; float& cnt_c = st.cnt_c; float& contr = st.contr; float& ssum = st.ssum;
-  float& ssq = st.ssq; float& smin = st.smin; float& smax = st.smax; float& sw = st.sw;
-  const float pos_dot = k.pos_dot, cpos = k.cpos, chinge = k.chinge, sc2 = k.sc2, rq = k.rq;
-  const int pos_item = k.pos_item, head = k.head;
-  const bool mask_fn = k.mask_fn, catalog = k.catalog, cos_head = k.cos_head;
-  constexpr int H = NO * 32;  // only used to walk the gradient accumulators
-  // The lane's 16 accumulator rows (r&3) + 8*(r>>2) + 4*hh are four runs of 4 consecutive negatives:
-  // per-negative side data (item id, inverse norm) comes as one 16-byte LDS read per run and array.
-  const bool want_lse = ALL || head == XFMR_LOSS_INFONCE;
-  if (want_lse && !mask_fn) {
-    // online log-sum-exp: without false-negative masking a counted logit may exceed the running max
-    // (with masking every counted logit is < the positive's, and m = scale * pos stays fixed)
-    float bmax = m;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[8 * g + 4 * hh]);
-      const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool same = nn[u] == pos_item;
-        const bool md = (nn[u] >= 0) & !(catalog & same);
-        bmax = fmaxf(bmax, md ? (same ? pos_dot : s[4 * g + u]) * sc2 : m);
-      }
-    }
-    bmax = fmaxf(bmax, xf_half_swap(bmax));
-    if (__any(bmax > m)) {
-      const float alpha = xf_exp2(m - bmax);
-      l *= alpha;
-      if (head == XFMR_LOSS_INFONCE) {
-#pragma unroll
-        for (int i = 0; i < H / 32; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        sw *= alpha;
-      }
-      m = bmax;
-    }
-  }
-  // Every head's row reductions and the train head's gradient weight (left in s[r] for the second MFMA).
-  // Branch-free per element; the `head` switches are wave-uniform.
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int jl0 = 8 * g + 4 * hh;
-    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[jl0]);
-    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
-    float rc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ALL || cos_head) {
-      const float4 c4 = *reinterpret_cast<const float4*>(&rc_sb[jl0]);
-      rc[0] = c4.x; rc[1] = c4.y; rc[2] = c4.z; rc[3] = c4.w;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = 4 * g + u;
-      const bool valid = nn[u] >= 0;
-      const bool same = nn[u] == pos_item;  // exact tie: the negative IS the positive item
-      const float sv = same ? pos_dot : s[r];
-      const bool excl = catalog & same;
-      const float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? 1.f : 0.f;
-      float w = 0.f;
-      cnt_d += md;
-      if (want_lse) {
-        // counted logits are <= m by construction; the clamp keeps an uncounted large logit from inf * 0
-        const float e = xf_exp2(fminf(sv * sc2 - m, 0.f)) * md;
-        l += e;
-        if (head == XFMR_LOSS_INFONCE) w = e;
-      }
-      if (ALL || head == XFMR_LOSS_NCE) {
-        const float t = xf_exp2(-fabsf(sv) * kLog2e);                    // exp(-|x|)
-        nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // softplus(x)
-        if (head == XFMR_LOSS_NCE) w = md * xf_rcp(1.f + t) * (sv >= 0.f ? 1.f : t);  // sigmoid(x)
-      }
-      if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
-        const float d = sv - chinge;
-        hinge = fmaf(fmaxf(d, 0.f), md, hinge);
-        if (head == XFMR_LOSS_PAIRWISE_HINGE) w = d > 0.f ? md : 0.f;
-        if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
-          const float t = xf_exp2(-fabsf(d) * kLog2e);
-          logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
-          if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md * xf_rcp(1.f + t) * (d >= 0.f ? 1.f : t);
-        }
-      }
-      if (ALL || cos_head) {
-        const float c = same ? cpos : sv * rq * rc[u];
-        const float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? 1.f : 0.f;
-        cnt_c += mc;
-        const float d = c - 1.f + k.margin;
-        contr = fmaf(fmaxf(d, 0.f), mc, contr);
-        if (head == XFMR_LOSS_CONTRASTIVE || head == XFMR_LOSS_ALIGNMENT_CONTRASTIVE)
-          w = d > 0.f ? mc * rc[u] : 0.f;
-      }
-      if (ALL) {
-        ssum = fmaf(sv, md, ssum);
-        ssq = fmaf(sv * sv, md, ssq);
-        smin = fminf(smin, md > 0.f ? sv : INFINITY);
-        smax = fmaxf(smax, md > 0.f ? sv : -INFINITY);
-      }
-      sw += w;
-      s[r] = w;
-    }
-    // keep the scheduler from interleaving the four runs (it otherwise holds all 16 elements' temporaries
-    // live at once and spills at 2 waves/SIMD)
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// halves of a lane pair (l, l^32) hold disjoint negatives of the same query: combine, then one lane writes
-__device__ __forceinline__ void write_partial(RowState st, float* rec, bool writer, float pos_dot, float rq, float qq) {
-  st.cnt_d += xf_half_swap(st.cnt_d); st.l += xf_half_swap(st.l); st.nce += xf_half_swap(st.nce);
-  st.hinge += xf_half_swap(st.hinge); st.logi += xf_half_swap(st.logi); st.cnt_c += xf_half_swap(st.cnt_c);
-  st.contr += xf_half_swap(st.contr); st.ssum += xf_half_swap(st.ssum); st.ssq += xf_half_swap(st.ssq);
-  st.sw += xf_half_swap(st.sw);
-  st.smin = fminf(st.smin, xf_half_swap(st.smin)); st.smax = fmaxf(st.smax, xf_half_swap(st.smax));
-  if (writer) {
-    rec[R_CNTD] = st.cnt_d; rec[R_M] = st.m; rec[R_L] = st.l; rec[R_NCE] = st.nce; rec[R_HINGE] = st.hinge;
-    rec[R_LOGI] = st.logi; rec[R_CNTC] = st.cnt_c; rec[R_CONTR] = st.contr; rec[R_SSUM] = st.ssum;
-    rec[R_SSQ] = st.ssq; rec[R_SMIN] = st.smin; rec[R_SMAX] = st.smax; rec[R_SW] = st.sw;
-    rec[R_POSDOT] = pos_dot; rec[R_RQ] = rq; rec[R_QQ] = qq;
+    neg_rc[i] = rnorm[n];
   }
 }
 
@@ -394,7 +241,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
       if (Q_IN_LDS) P::tile_nt(s, sE, LDE, sb * 32, sQ, LDE, wid * 32, H);
       else P::tile_nreg(s, sE, LDE, sb * 32, qreg.regs(), H);
 
-      loss_epilogue<ALL>(s, st, o, kc, &sNid[sb * 32], &sRc[sb * 32], hh);
+      loss_epilogue<ALL, true>(s, st, o, kc, &sNid[sb * 32], &sRc[sb * 32], hh);
       if (do_grad) {
 #pragma unroll
         for (int i = 0; i < H / 32; ++i) P::tile_xb(o[i], sET, LDT, i * 32, sb * 32, s);
@@ -412,8 +259,6 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
       xf_store_tile_T(sScratch + wid * 32 * 33, o[i], 1.f, base + i * 32, H, qb0 + wid * 32, Nq);
   }
 }
-
-#include "loss_dma.inc"
 
 // bf16 copy of the frozen table (gather source of the LDS-DMA path) + per-item inverse norms
 __global__ void table_prepare_kernel(const float* table, float* rnorm, __bf16* tbf, int64_t rows, int H) {
@@ -615,7 +460,7 @@ __global__ __launch_bounds__(1024) void loss_final_kernel(const double* blockpar
 // ---- host side ---------------------------------------------------------------------------------------------
 struct Plan {
   int nsplit;
-  size_t off_part2;
+  size_t off_part2, off_negrc;
   size_t off_counts, off_blockcnt, off_neg, off_qrow, off_qpos, off_part, off_partO, off_block, total;
   int nblocks;
 };
@@ -625,7 +470,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows) {
   const int64_t qblocks = (T + QB - 1) / QB;
   const int64_t cols = T > n_rows ? T : n_rows;
   const int64_t tiles = (cols + BN - 1) / BN;
-  int64_t ns = (768 + qblocks - 1) / qblocks;
+  int64_t ns = (1024 + qblocks / 2) / qblocks;  // ~1024 workgroups: two full rounds at 2 workgroups/CU
   if (ns > 16) ns = 16;
   if (ns > tiles) ns = tiles;
   if (ns < 1) ns = 1;
@@ -635,6 +480,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows) {
   p.off_counts = o; o += 256;
   p.off_blockcnt = o; o += up256((size_t)((T + PREP - 1) / PREP) * sizeof(int2));
   p.off_neg = o; o += up256((size_t)T * 4);
+  p.off_negrc = o; o += up256((size_t)T * 4);
   p.off_qrow = o; o += up256((size_t)T * 4);
   p.off_qpos = o; o += up256((size_t)T * 4);
   p.off_part = o; o += up256((size_t)ns * T * REC * 4);
@@ -662,22 +508,13 @@ int launch_main_h(const LossArgs& a, int H, bool all, dim3 grid, hipStream_t st)
   return XFMR_OK;
 }
 
-// role 0: train head + gradient; role 1: all heads + statistics, values only; role 2: train head, values only
-template <int H>
-void launch_dma(const LossArgs& a, const __bf16* tbf, int role, dim3 grid, hipStream_t st) {
-  if (role == 0) hipLaunchKernelGGL((loss_main_dma_kernel<H, false, true>), grid, dim3(256), 0, st, a, tbf);
-  else if (role == 1) hipLaunchKernelGGL((loss_main_dma_kernel<H, true, false>), grid, dim3(256), 0, st, a, tbf);
-  else hipLaunchKernelGGL((loss_main_dma_kernel<H, false, false>), grid, dim3(256), 0, st, a, tbf);
-}
-int launch_dma_h(const LossArgs& a, const __bf16* tbf, int H, int role, dim3 grid, hipStream_t st) {
+int launch_dma_h(const LossArgs& a, const void* tbf, int H, int head, dim3 grid, hipStream_t st) {
   switch (H) {
-    case 64: launch_dma<64>(a, tbf, role, grid, st); break;
-    case 128: launch_dma<128>(a, tbf, role, grid, st); break;
-    case 256: launch_dma<256>(a, tbf, role, grid, st); break;
+    case 64: return xf_launch_loss_dma_64(a, tbf, head, grid, st);
+    case 128: return xf_launch_loss_dma_128(a, tbf, head, grid, st);
+    case 256: return xf_launch_loss_dma_256(a, tbf, head, grid, st);
     default: return XFMR_EUNSUPPORTED;
   }
-  XF_LAUNCH_CHECK();
-  return XFMR_OK;
 }
 
 // one-shot, per host thread: events recorded around the NEXT main-kernel launch (measurement only)
@@ -709,6 +546,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   LossArgs a{};
   a.tok = tok; a.table = table; a.rnorm = table_rnorm; a.n_rows = n_rows; a.counts = counts;
   a.neg_item = cfg->mode == XFMR_NEG_SHARED ? neg_item : nullptr;
+  a.neg_rc = (const float*)(ws + p.off_negrc);
   a.qrow = qrow; a.qpos = qpos; a.part = (float*)(ws + p.off_part); a.partO = (float*)(ws + p.off_partO);
   a.T = T; a.nsplit = p.nsplit; a.train_head = cfg->train_head; a.mask_fn = cfg->mask_false_negatives;
   a.mode = cfg->mode; a.need_grad = d_tok != nullptr; a.scale = cfg->scale; a.margin = cfg->margin;
@@ -718,26 +556,25 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   g_prof_start = g_prof_stop = nullptr;  // one-shot
   const float* part_loss = nullptr;  // records the loss VALUES are read from (null: the same as the gradient's)
   if (cfg->precision == XFMR_PREC_BF16 && table_bf16) {
-    const __bf16* tbf = (const __bf16*)table_bf16;
+    // bf16 production path: the gradient pass of the train head (skipped for AlignmentLoss, whose gradient has
+    // no negative term) and, when every head is wanted or no gradient is, the values-only logging pass.
     const bool all = cfg->all_heads != 0;
-    if (a.need_grad) {
+    const bool grad_pass = a.need_grad && cfg->train_head != XFMR_LOSS_ALIGNMENT;
+    if (grad_pass) {
       if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
-      rc = launch_dma_h(a, tbf, H, 0, grid, st);
+      rc = launch_dma_h(a, table_bf16, H, cfg->train_head, grid, st);
       if (rc) return rc;
       if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
-      if (all) {
-        LossArgs b = a;
-        b.part = (float*)(ws + p.off_part2);
-        b.need_grad = 0;
-        rc = launch_dma_h(b, tbf, H, 1, grid, st);
-        if (rc) return rc;
-        part_loss = b.part;
-      }
-    } else {
-      if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
-      rc = launch_dma_h(a, tbf, H, all ? 1 : 2, grid, st);
+    }
+    if (all || !grad_pass) {
+      LossArgs b = a;
+      if (grad_pass) b.part = (float*)(ws + p.off_part2);
+      b.need_grad = 0;
+      if (!grad_pass && ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
+      rc = launch_dma_h(b, table_bf16, H, -1, grid, st);
       if (rc) return rc;
-      if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
+      if (!grad_pass && ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
+      if (grad_pass) part_loss = b.part;
     }
   } else {
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
@@ -790,8 +627,8 @@ int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t*
   XF_LAUNCH_CHECK();
   hipLaunchKernelGGL(prepare_write_kernel, dim3(nprep), dim3(PREP), 0, st, key_mask, pos_idx,
                      cfg->mode == XFMR_NEG_SHARED ? neg_idx : (const int64_t*)nullptr, T, n_rows,
-                     (const int2*)blockcnt, (int*)(ws + p.off_counts), (int*)(ws + p.off_neg),
-                     (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
+                     (const int2*)blockcnt, table_rnorm, (int*)(ws + p.off_counts), (int*)(ws + p.off_neg),
+                     (float*)(ws + p.off_negrc), (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
   XF_LAUNCH_CHECK();
   if (d_tok && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
@@ -820,8 +657,9 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
   const int T = (int)rows;
   hipLaunchKernelGGL(prepare_lists_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, pos_items,
                      cfg->mode == XFMR_NEG_SHARED ? neg_items : (const int64_t*)nullptr, (int)n_query,
-                     (int)(cfg->mode == XFMR_NEG_SHARED ? n_neg : 0), n_rows, (int*)(ws + p.off_counts),
-                     (int*)(ws + p.off_neg), (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
+                     (int)(cfg->mode == XFMR_NEG_SHARED ? n_neg : 0), n_rows, table_rnorm,
+                     (int*)(ws + p.off_counts), (int*)(ws + p.off_neg), (float*)(ws + p.off_negrc),
+                     (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
   XF_LAUNCH_CHECK();
   if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
   return run_loss(cfg, query, table, table_rnorm, table_bf16, n_rows, T, H, losses, stats, d_query, ws, p, st);

@@ -1,0 +1,196 @@
+// Shared between loss.hip (generic / fp32 main kernel, compaction, combine, host code) and the per-H
+// translation units of the LDS-DMA bf16 main kernel (loss_dma_h*.hip).
+#pragma once
+#include "common.h"
+
+namespace xfl {  // named: LossArgs crosses translation units
+
+constexpr int BN = 64;        // negatives per tile
+constexpr int QB = 128;       // queries per workgroup
+constexpr int REC = 16;       // floats per (split, query) partial record
+constexpr int LDT = BN + 4;   // transposed image [h][j] leading dimension (see attention.hip note)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+enum { R_CNTD = 0, R_M, R_L, R_NCE, R_HINGE, R_LOGI, R_CNTC, R_CONTR, R_SSUM, R_SSQ, R_SMIN, R_SMAX, R_SW,
+       R_POSDOT, R_RQ, R_QQ };
+constexpr int BP = 24;        // doubles per block-partial record
+
+struct LossArgs {
+  const float* tok; const float* table; const float* rnorm; int64_t n_rows;
+  const int* counts;      // [0] = N valid positions, [1] = Np queries
+  const int* neg_item;    // [N] (shared mode) or null (catalogue mode: item j)
+  const float* neg_rc;    // [N] inverse norm of each negative's row (shared mode)
+  const int* qrow; const int* qpos;
+  float* part; float* partO;
+  int T; int nsplit;
+  int train_head, mask_fn, mode, need_grad;
+  float scale, margin;
+};
+
+// ---- per-sub-block epilogue shared by both main kernels ----------------------------------------------------
+// s: the 32x32 tile S^T (negative in the registers, query on the lane) on entry, the train head's gradient
+// weights on exit. nid_sb / rc_sb: LDS side data (item id, inverse norm) of the sub-block's 32 negatives.
+struct RowState {
+  float cnt_d, m, l, nce, hinge, logi, cnt_c, contr, ssum, ssq, smin, smax, sw;
+};
+struct RowConst {
+  float pos_dot, cpos, chinge, sc2, rq, margin;
+  int pos_item, head;
+  bool mask_fn, catalog, cos_head;
+};
+// HC: the train head as a compile-time constant (its gradient weight is produced), or -1 = values only.
+template <bool ALL, int HC, int NO>
+__device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
+                                                const int* nid_sb, const float* rc_sb, int hh) {
+  float& cnt_d = st.cnt_d; float& m = st.m; float& l = st.l; float& nce = st.nce; float& hinge = st.hinge;
+  float& logi = st.logi; float& cnt_c = st.cnt_c; float& contr = st.contr; float& ssum = st.ssum;
+  float& ssq = st.ssq; float& smin = st.smin; float& smax = st.smax; float& sw = st.sw;
+  const float pos_dot = k.pos_dot, cpos = k.cpos, chinge = k.chinge, sc2 = k.sc2, rq = k.rq;
+  const int pos_item = k.pos_item;
+  constexpr int head = HC;
+  const bool mask_fn = k.mask_fn, catalog = k.catalog;
+  constexpr bool cos_head = HC >= 0 && HC <= XFMR_LOSS_CONTRASTIVE;
+  constexpr int H = NO * 32;  // only used to walk the gradient accumulators
+  // The lane's 16 accumulator rows (r&3) + 8*(r>>2) + 4*hh are four runs of 4 consecutive negatives:
+  // per-negative side data (item id, inverse norm) comes as one 16-byte LDS read per run and array.
+  const bool want_lse = ALL || head == XFMR_LOSS_INFONCE;
+  if (want_lse && !mask_fn) {
+    // online log-sum-exp: without false-negative masking a counted logit may exceed the running max
+    // (with masking every counted logit is < the positive's, and m = scale * pos stays fixed)
+    float bmax = m;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[8 * g + 4 * hh]);
+      const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool same = nn[u] == pos_item;
+        const bool md = (nn[u] >= 0) & !(catalog & same);
+        bmax = fmaxf(bmax, md ? (same ? pos_dot : s[4 * g + u]) * sc2 : m);
+      }
+    }
+    bmax = fmaxf(bmax, xf_half_swap(bmax));
+    if (__any(bmax > m)) {
+      const float alpha = xf_exp2(m - bmax);
+      l *= alpha;
+      if (head == XFMR_LOSS_INFONCE) {
+#pragma unroll
+        for (int i = 0; i < H / 32; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        sw *= alpha;
+      }
+      m = bmax;
+    }
+  }
+  // Every head's row reductions and the train head's gradient weight (left in s[r] for the second MFMA).
+  // Branch-free per element; the `head` switches are wave-uniform.
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl0 = 8 * g + 4 * hh;
+    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[jl0]);
+    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+    float rc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ALL || cos_head) {
+      const float4 c4 = *reinterpret_cast<const float4*>(&rc_sb[jl0]);
+      rc[0] = c4.x; rc[1] = c4.y; rc[2] = c4.z; rc[3] = c4.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * g + u;
+      const bool valid = nn[u] >= 0;
+      const bool same = nn[u] == pos_item;  // exact tie: the negative IS the positive item
+      const float sv = same ? pos_dot : s[r];
+      const bool excl = catalog & same;
+      const float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? 1.f : 0.f;
+      float w = 0.f;
+      cnt_d += md;
+      if (want_lse) {
+        // counted logits are <= m by construction; the clamp keeps an uncounted large logit from inf * 0
+        const float e = xf_exp2(fminf(sv * sc2 - m, 0.f)) * md;
+        l += e;
+        if (head == XFMR_LOSS_INFONCE) w = e;
+      }
+      if (ALL || head == XFMR_LOSS_NCE) {
+        const float t = xf_exp2(-fabsf(sv) * kLog2e);                    // exp(-|x|)
+        nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // softplus(x)
+        if (head == XFMR_LOSS_NCE) w = md * xf_rcp(1.f + t) * (sv >= 0.f ? 1.f : t);  // sigmoid(x)
+      }
+      if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
+        const float d = sv - chinge;
+        hinge = fmaf(fmaxf(d, 0.f), md, hinge);
+        if (head == XFMR_LOSS_PAIRWISE_HINGE) w = d > 0.f ? md : 0.f;
+        if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
+          const float t = xf_exp2(-fabsf(d) * kLog2e);
+          logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
+          if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md * xf_rcp(1.f + t) * (d >= 0.f ? 1.f : t);
+        }
+      }
+      if (ALL || cos_head) {
+        const float c = same ? cpos : sv * rq * rc[u];
+        const float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? 1.f : 0.f;
+        cnt_c += mc;
+        const float d = c - 1.f + k.margin;
+        contr = fmaf(fmaxf(d, 0.f), mc, contr);
+        if (head == XFMR_LOSS_CONTRASTIVE || head == XFMR_LOSS_ALIGNMENT_CONTRASTIVE)
+          w = d > 0.f ? mc * rc[u] : 0.f;
+      }
+      if (ALL) {
+        ssum = fmaf(sv, md, ssum);
+        ssq = fmaf(sv * sv, md, ssq);
+        smin = fminf(smin, md > 0.f ? sv : INFINITY);
+        smax = fmaxf(smax, md > 0.f ? sv : -INFINITY);
+      }
+      sw += w;
+      s[r] = w;
+    }
+    // keep the scheduler from interleaving the four runs (it otherwise holds all 16 elements' temporaries
+    // live at once and spills at 2 waves/SIMD)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// runtime head -> compile-time head (one wave-uniform switch per sub-block instead of ~6 per element)
+template <bool ALL, bool GRAD, int NO>
+__device__ __forceinline__ void loss_epilogue(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
+                                              const int* nid_sb, const float* rc_sb, int hh) {
+  if (!GRAD) {
+    if (ALL) return loss_epilogue_t<true, -1>(s, st, o, k, nid_sb, rc_sb, hh);
+    // values of ONE head: its accumulators are selected by the head, no weights needed -> reuse the
+    // weighted variants (the weight computation is dead code without the second product)
+  }
+  switch (k.head) {
+    case XFMR_LOSS_ALIGNMENT: return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:
+      return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_CONTRASTIVE: return loss_epilogue_t<ALL, XFMR_LOSS_CONTRASTIVE>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_INFONCE: return loss_epilogue_t<ALL, XFMR_LOSS_INFONCE>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_NCE: return loss_epilogue_t<ALL, XFMR_LOSS_NCE>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_PAIRWISE_HINGE: return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_HINGE>(s, st, o, k, nid_sb, rc_sb, hh);
+    default: return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_LOGISTIC>(s, st, o, k, nid_sb, rc_sb, hh);
+  }
+}
+
+// halves of a lane pair (l, l^32) hold disjoint negatives of the same query: combine, then one lane writes
+__device__ __forceinline__ void write_partial(RowState st, float* rec, bool writer, float pos_dot, float rq, float qq) {
+  st.cnt_d += xf_half_swap(st.cnt_d); st.l += xf_half_swap(st.l); st.nce += xf_half_swap(st.nce);
+  st.hinge += xf_half_swap(st.hinge); st.logi += xf_half_swap(st.logi); st.cnt_c += xf_half_swap(st.cnt_c);
+  st.contr += xf_half_swap(st.contr); st.ssum += xf_half_swap(st.ssum); st.ssq += xf_half_swap(st.ssq);
+  st.sw += xf_half_swap(st.sw);
+  st.smin = fminf(st.smin, xf_half_swap(st.smin)); st.smax = fmaxf(st.smax, xf_half_swap(st.smax));
+  if (writer) {
+    rec[R_CNTD] = st.cnt_d; rec[R_M] = st.m; rec[R_L] = st.l; rec[R_NCE] = st.nce; rec[R_HINGE] = st.hinge;
+    rec[R_LOGI] = st.logi; rec[R_CNTC] = st.cnt_c; rec[R_CONTR] = st.contr; rec[R_SSUM] = st.ssum;
+    rec[R_SSQ] = st.ssq; rec[R_SMIN] = st.smin; rec[R_SMAX] = st.smax; rec[R_SW] = st.sw;
+    rec[R_POSDOT] = pos_dot; rec[R_RQ] = rq; rec[R_QQ] = qq;
+  }
+}
+
+}  // namespace xfl
+using namespace xfl;
+
+// launchers of the LDS-DMA main kernel, one translation unit per hidden size (compile time)
+// head: XFMR_LOSS_* = gradient pass of that head; -1 = logging pass (all heads + statistics, values only)
+int xf_launch_loss_dma_64(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st);
+int xf_launch_loss_dma_128(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st);
+int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st);
