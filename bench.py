@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--lean", action="store_true", help="only the train head (not the reference's 7 + stats)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="logging heads on the main stream (no side stream)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
@@ -90,7 +91,7 @@ class HipEvents:
     """hipEvent pairs created through the HIP runtime torch already loaded (same soname)."""
 
     def __init__(self, n):
-        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip = ctypes.CDLL("libamdhip64.so.7")  # soname: resolves to the HIP runtime torch already loaded
         self.pairs = []
         for _ in range(n):
             a, b = ctypes.c_void_p(), ctypes.c_void_p()
@@ -183,12 +184,14 @@ def main():
         batch = batches[i % n_batches]
         opt = trainer.optimizer
         opt.zero_grad(set_to_none=True)
-        out = mod.compute_losses(batch, sync_metrics=False)  # metrics stay on the device: no host sync per step
+        # metrics stay on the device (no host sync per step); the logging heads run on a side stream under the backward
+        out = mod.compute_losses(batch, sync_metrics=False, defer_logging=not args.no_overlap)
         loss = out[f"loss/{conf.train_loss}"]
         loss.backward()
         if world > 1:
             D.allreduce_flat_grad_(mod.model.flat.grad)
         opt.step()
+        mod.sync_logging()
         return loss, out
 
     for i in range(args.warmup):

@@ -47,7 +47,7 @@ def main():
     mask = torch.ones(B * L, dtype=torch.uint8, device=dev)
     pos = torch.randint(1, V + 1, (B * L,), generator=g).to(dev)
     neg = torch.randint(1, V + 1, (B * L,), generator=g).to(dev)
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = ctypes.CDLL("libamdhip64.so.7")  # soname: resolves to the HIP runtime torch already loaded
     lib = N.load()
     flops = 4.0 * (B * L) ** 2 * H
     precs = ["bf16"] + (["fp32"] if args.fp32 else [])

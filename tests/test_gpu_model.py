@@ -349,3 +349,20 @@ def test_save_load_roundtrip(X, golden_dir, tmp_path):
     a = mod.model(batch["history_item_idx"].to(DEV))["sentence_embedding"]
     b = m2(batch["history_item_idx"].to(DEV))["sentence_embedding"]
     assert torch.equal(a, b)
+
+
+def test_deferred_logging_on_side_stream_matches_inline(X, golden_dir):
+    """compute_losses(defer_logging=True) evaluates the logging heads on a side stream; after sync_logging() the
+    values are bit-identical to the single-stream evaluation."""
+    g3, mod, batch = _g3_module(X, golden_dir, "bf16", "InfoNCELoss")
+    mod.eval()
+    mod.model.flat.requires_grad_(True)
+    a = mod.compute_losses(batch, sync_metrics=False)
+    b = mod.compute_losses(batch, sync_metrics=False, defer_logging=True)
+    b["loss/InfoNCELoss"].backward()
+    mod.sync_logging()
+    torch.cuda.synchronize()
+    assert torch.equal(a["stats/device"], b["stats/device"])
+    for i, cls in enumerate(X.LOSS_CLASSES):
+        assert float(a[f"loss/{cls.__name__}"]) == float(b["losses/device"][i]), cls.__name__
+    assert float(a["loss/InfoNCELoss"]) == float(b["loss/InfoNCELoss"])

@@ -25,12 +25,20 @@ struct GemmArgs {
   XfDropout drop;
 };
 
-// One operand tile (ROWS x BK, fp32 in memory) in flight in registers, then committed to an LDS image
-// [ROWS][BK + pad] of the MFMA element type. TRANS: memory is [K][rows] (rows contiguous) instead of [rows][K].
+// One operand tile (ROWS x BK, fp32 in memory) in flight in registers, then committed to an LDS image of the
+// MFMA element type.
+//   TRANS = false: memory [rows][K]  -> image [ROWS][BK + pad]  (K-contiguous; fragments are 16-byte row reads)
+//   TRANS = true : memory [K][rows]  -> image [BK][ROWS + pad]  (natural layout, coalesced 8/16-byte commits);
+//                  the MFMA fragment (8 consecutive k for one row) is then a COLUMN of the image: two
+//                  ds_read_b64_tr_b16 for bf16, one ds_read_b32 for fp32 -- no scattered, bank-conflicting
+//                  transposing stores (they were 63-78 % of the LDS cycles of the dX / dW GEMMs).
 template <class P, int ROWS, int BK, bool TRANS>
 struct OperandTile {
+  using elem = typename P::elem;
   static constexpr int N4 = ROWS * BK / 4 / 256;  // float4 per thread
-  static constexpr int LD = xf_ld<P>(BK);
+  // TRANS bf16: row stride = 64 B (mod 256 B) so the 4 rows of a transposed read hit 4 distinct bank windows
+  static constexpr int LD = TRANS ? (sizeof(elem) == 2 ? ROWS + 32 : ROWS + 4) : xf_ld<P>(BK);
+  static constexpr int IMG_ELEMS = TRANS ? BK * LD : ROWS * LD;
   float4 reg[N4];
 
   __device__ __forceinline__ void load(const float* src, int64_t ld, int64_t row0, int64_t rows_total, int k0,
@@ -53,58 +61,95 @@ struct OperandTile {
         reg[i] = v;
       }
     } else {
-      // item -> (k-pair kp, 4 consecutive rows): two float4 (k, k+1) per item so the LDS write is a packed pair
       constexpr int R4 = ROWS / 4;
-#pragma unroll
-      for (int i = 0; i < N4 / 2; ++i) {
-        const int item = tid + i * 256;
-        const int kp = item / R4, rc = (item % R4) * 4;
-        const int64_t gr = row0 + rc;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int gk = k0 + 2 * kp + u;
-          float4 v = make_float4(0, 0, 0, 0);
-          if (gk < kend && gr < rows_total) {
-            const float* p = src + (int64_t)gk * ld + gr;
-            if (gr + 3 < rows_total) v = *reinterpret_cast<const float4*>(p);
-            else { v.x = p[0]; if (gr + 1 < rows_total) v.y = p[1]; if (gr + 2 < rows_total) v.z = p[2]; }
-          }
-          reg[2 * i + u] = v;
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void commit(typename P::elem* dst) const {
-    const int tid = threadIdx.x;
-    if (!TRANS) {
-      constexpr int CH = BK / 4;
 #pragma unroll
       for (int i = 0; i < N4; ++i) {
         const int c = tid + i * 256;
-        xf_store4<P>(dst + (c / CH) * LD + (c % CH) * 4, reg[i]);
-      }
-    } else {
-      constexpr int R4 = ROWS / 4;
-#pragma unroll
-      for (int i = 0; i < N4 / 2; ++i) {
-        const int item = tid + i * 256;
-        const int kp = item / R4, rc = (item % R4) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          xf_store2<P>(dst + (rc + j) * LD + 2 * kp, xf_get(reg[2 * i], j), xf_get(reg[2 * i + 1], j));
+        const int k = c / R4, rc = (c % R4) * 4;
+        const int64_t gr = row0 + rc;
+        const int gk = k0 + k;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (gk < kend && gr < rows_total) {
+          const float* p = src + (int64_t)gk * ld + gr;
+          if (gr + 3 < rows_total) v = *reinterpret_cast<const float4*>(p);
+          else { v.x = p[0]; if (gr + 1 < rows_total) v.y = p[1]; if (gr + 2 < rows_total) v.z = p[2]; }
+        }
+        reg[i] = v;
       }
     }
   }
+  __device__ __forceinline__ void commit(elem* dst) const {
+    const int tid = threadIdx.x;
+    constexpr int CH = TRANS ? ROWS / 4 : BK / 4;
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      const int c = tid + i * 256;
+      xf_store4<P>(dst + (c / CH) * LD + (c % CH) * 4, reg[i]);
+    }
+  }
 };
+
+// MFMA fragments of one 32-row block (rows row0..row0+31 of the operand) for the k-step starting at k0.
+template <class P, bool TRANS>
+struct Frag;
+template <>
+struct Frag<PrecBF16, false> {
+  using type = bf16x8;
+  static constexpr int KS = 16;
+  __device__ static __forceinline__ type get(const __bf16* img, int ld, int row0, int k0) {
+    const int l = xf_lane();
+    return *reinterpret_cast<const bf16x8*>(img + (row0 + (l & 31)) * ld + k0 + 8 * (l >> 5));
+  }
+};
+template <>
+struct Frag<PrecBF16, true> {
+  using type = bf16x8;
+  static constexpr int KS = 16;
+  // image [k][row]: lane (row i = l&31, h = l>>5) needs IMG[k0 + 8h + 0..7][row0 + i]: per 16-lane group two
+  // transposed 4-row x 16-column block reads (lane 4q+p supplies row q, columns 4p..4p+3).
+  __device__ static __forceinline__ type get(const __bf16* img, int ld, int row0, int k0) {
+    const int l = xf_lane(), g16 = l >> 4, li = l & 15, q = li >> 2, p = li & 3;
+    const __bf16* base = img + (k0 + 8 * (g16 >> 1) + q) * ld + row0 + 16 * (g16 & 1) + 4 * p;
+    union { xf_s16x4 v[2]; bf16x8 f; } a;
+    a.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) xf_s16x4*)(base));
+    a.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) xf_s16x4*)(base + 4 * ld));
+    return a.f;
+  }
+};
+template <>
+struct Frag<PrecF32, false> {
+  using type = float;
+  static constexpr int KS = 2;
+  __device__ static __forceinline__ type get(const float* img, int ld, int row0, int k0) {
+    const int l = xf_lane();
+    return img[(row0 + (l & 31)) * ld + k0 + (l >> 5)];
+  }
+};
+template <>
+struct Frag<PrecF32, true> {
+  using type = float;
+  static constexpr int KS = 2;
+  __device__ static __forceinline__ type get(const float* img, int ld, int row0, int k0) {
+    const int l = xf_lane();
+    return img[(k0 + (l >> 5)) * ld + row0 + (l & 31)];
+  }
+};
+__device__ __forceinline__ f32x16 xf_mma(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 xf_mma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
 
 template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using elem = typename P::elem;
   using TileA = OperandTile<P, BM, BK, TA>;
   using TileB = OperandTile<P, BN, BK, TB>;
-  constexpr int LD = TileA::LD;
-  __shared__ __attribute__((aligned(16))) elem sA[BM * LD];
-  __shared__ __attribute__((aligned(16))) elem sB[BN * LD];
+  using FA = Frag<P, TA>;
+  using FB = Frag<P, TB>;
+  __shared__ __attribute__((aligned(16))) elem sA[TileA::IMG_ELEMS];
+  __shared__ __attribute__((aligned(16))) elem sB[TileB::IMG_ELEMS];
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -132,6 +177,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     ta.load(g.A, g.lda, m0, g.M, kbeg, kend);
     tb.load(g.B, g.ldb, n0, g.N, kbeg, kend);
   }
+  // epilogue operands (residual / pre-activation) are fetched up front so their latency hides under the K loop
+  float aux[MI][NI][16];
+  if (EPI == EPI_STORE || EPI == EPI_DROP_RES || EPI == EPI_GELU_GRAD) {
+    const float* src = (EPI == EPI_GELU_GRAD) ? g.P : g.R;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wc * WN + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + wr * WM + i * 32 + xf_acc_row(r, lane);
+          aux[i][j][r] = (src && n < g.N && m < g.M) ? src[m * g.ldc + n] : 0.f;
+        }
+      }
+  }
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
     ta.commit(sA);
@@ -142,10 +203,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       tb.load(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend);
     }
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int k0 = 0; k0 < BK; k0 += FA::KS) {
+      typename FA::type fa[MI];
+      typename FB::type fb[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        P::tile_nt(acc[i][j], sA, LD, wr * WM + i * 32, sB, LD, wc * WN + j * 32, BK);
+      for (int i = 0; i < MI; ++i) fa[i] = FA::get(sA, TileA::LD, wr * WM + i * 32, k0);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = FB::get(sB, TileB::LD, wc * WN + j * 32, k0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = xf_mma(fa[i], fb[j], acc[i][j]);
+    }
   }
 
   // ---- epilogue --------------------------------------------------------------------------------
@@ -165,16 +234,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const int64_t o = m * g.ldc + n;
         float v = acc[i][j][r] + bias;
         if (EPI == EPI_STORE) {
-          if (g.R) v += g.R[o];
-          C[o] = v;
+          C[o] = v + aux[i][j][r];
         } else if (EPI == EPI_GELU) {
           g.C2[o] = v;
           C[o] = xf_gelu(v);
         } else if (EPI == EPI_DROP_RES) {
           if (g.drop.on) v *= xf_keep_scale(g.drop, (uint32_t)(m * g.N + n));
-          C[o] = v + g.R[o];
+          C[o] = v + aux[i][j][r];
         } else if (EPI == EPI_GELU_GRAD) {
-          C[o] = v * xf_gelu_grad(g.P[o]);
+          C[o] = v * xf_gelu_grad(aux[i][j][r]);
         } else {
           C[o] = v;
         }
@@ -224,20 +292,17 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   // the largest tile that still yields >= 512 workgroups (2 per CU), otherwise the smallest tile.
   auto wgs = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (int64_t)splits; };
   int bm = 64, bn = 64;
-  if (BK <= 64) {
-    if (g.N > 64 && g.M > 64 && wgs(128, 128) >= 512) { bm = 128; bn = 128; }
-    else if (g.N > 64 && wgs(64, 128) >= 512) { bm = 64; bn = 128; }
-    else if (g.M > 64 && wgs(128, 64) >= 512) { bm = 128; bn = 64; }
-  }
+  if (BK <= 64 && g.N > 64 && g.M > 64 && wgs(128, 128) >= 512) { bm = 128; bn = 128; }
+  else if (g.N > 64 && wgs(64, 128) >= 512) { bm = 64; bn = 128; }
+  else if (g.M > 64 && wgs(128, 64) >= 512) { bm = 128; bn = 64; }
   dim3 block(256);
   dim3 grid((unsigned)((g.N + bn - 1) / bn), (unsigned)((g.M + bm - 1) / bm), splits);
-  if constexpr (BK <= 64) {
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
-  } else {
-    hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
+  if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
+  else if (bm == 64) hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
+  else {
+    if constexpr (BK <= 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
+    else return XFMR_EINVAL;
   }
   XF_LAUNCH_CHECK();
   return XFMR_OK;

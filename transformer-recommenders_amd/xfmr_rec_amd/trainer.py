@@ -113,12 +113,25 @@ class RecommenderLightningModule(_Base):
         assert self.model is not None
         return self.model(item_idx.to(self.model.device))
 
-    def compute_losses(self, batch, *, sync_metrics: bool = True) -> dict:
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.model.device)
+        return self._side
+
+    def sync_logging(self) -> None:
+        """Join the side stream of a deferred logging pass (see compute_losses(defer_logging=True))."""
+        if getattr(self, "_logging_pending", False):
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._logging_pending = False
+
+    def compute_losses(self, batch, *, sync_metrics: bool = True, defer_logging: bool = False) -> dict:
         """``trainer.py:213-264``: every head's summed loss and ``...Mean``, batch and logits statistics.
 
         One encoder forward + ONE fused loss launch sequence produce all of it (the reference recomputes the
         logits eight times). ``loss/{train_loss}`` carries the gradient; the other heads are logging values.
         ``sync_metrics=False`` keeps the statistics on the device (no host sync in the step).
+        ``defer_logging=True`` (implies device-side metrics) runs the logging heads on a side stream; the non-train
+        entries of the returned dict must then only be read after ``sync_logging()``.
         """
         assert self.model is not None
         m, c = self.model, self.config
@@ -135,9 +148,29 @@ class RecommenderLightningModule(_Base):
         opts = dict(train_head=c.train_loss, all_heads=c.log_all_losses, mask_false_negatives=c.mask_false_negatives,
                     mode=N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision,
                     table_bf16=m.table_bf16)
-        train_loss, losses, stats = ops.SampledLossFunction.apply(
-            tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts
-        )
+        overlap = (defer_logging and c.log_all_losses and tok.requires_grad and torch.is_grad_enabled()
+                   and m.table_bf16 is not None and c.precision == "bf16")
+        if overlap:
+            # The six logging heads + statistics do not feed the gradient: evaluate them on a side stream so the
+            # (VALU-bound) logging pass runs underneath the (latency-bound) encoder backward. The caller joins
+            # with sync_logging() before reading them (Trainer.fit_step / bench.py do, after optimizer.step()).
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            train_loss, _l, stats_t = ops.SampledLossFunction.apply(
+                tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts | {"all_heads": False}
+            )
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                losses, stats, _ = ops.sampled_loss(
+                    tok.detach(), key_mask, pos, neg, m.embeddings, m.table_rnorm, need_grad=False, **opts
+                )
+            for tns in (tok, key_mask, pos, neg):
+                tns.record_stream(side)
+            self._logging_pending = True
+        else:
+            train_loss, losses, stats = ops.SampledLossFunction.apply(
+                tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts
+            )
         out: dict = {}
         n_query = stats[N.STAT["n_query"]]
         names = [cls.__name__ for cls in LOSS_CLASSES]
@@ -146,10 +179,13 @@ class RecommenderLightningModule(_Base):
                 continue
             val = train_loss if name == c.train_loss else losses[i]
             out[f"loss/{name}"] = val
-            out[f"loss/{name}Mean"] = val.detach() / (n_query + 1e-9)
+            if not overlap:
+                out[f"loss/{name}Mean"] = val.detach() / (n_query + 1e-9)
+        if overlap:  # the ...Mean values are derived lazily (after the join) by loss_means()
+            out["losses/device"] = losses
         batch_size, seq_len = key_mask.shape
         numel = key_mask.numel()
-        if sync_metrics:
+        if sync_metrics and not overlap:
             s = stats.tolist()  # one device->host sync (the reference does 11 .item() calls)
             attn_nz, pos_nz = int(s[N.STAT["n_valid"]]), int(s[N.STAT["n_query"]])
             out |= {
@@ -216,13 +252,16 @@ class Trainer:
         m = self.module
         m.train()
         self.optimizer.zero_grad(set_to_none=True)
-        loss = m.training_step(batch)
+        out = m.compute_losses(batch, sync_metrics=False, defer_logging=True)
+        m.log_dict(out)
+        loss = out[f"loss/{m.config.train_loss}"]
         loss.backward()
         if self.world_size > 1:
             from .distributed import allreduce_flat_grad_
 
             allreduce_flat_grad_(m.model.flat.grad, self.process_group)
         self.optimizer.step()
+        m.sync_logging()
         return loss.detach()
 
     def fit(self, batches, max_steps: int | None = None) -> list[float]:
