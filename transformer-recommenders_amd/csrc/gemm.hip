@@ -7,6 +7,9 @@
 // flight while slice k is multiplied) -> converted to the MFMA element type on the way into LDS.
 // These GEMMs are skinny (K = H or I <= 1024, except dW where K = tokens and the split-K grid supplies
 // the parallelism); the operands are L2 / Infinity-Cache resident between the kernels of one step.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -286,35 +289,46 @@ int launch_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, int6
   return XFMR_OK;
 }
 
+// Tuning override for experiments: XFMR_GEMM_TILE="bm,bn,bk" (64|128, 64|128, 32|128) forces the tile.
+struct TileOverride { int bm, bn, bk; };
+static TileOverride tile_override() {
+  static TileOverride o = [] {
+    TileOverride t{0, 0, 0};
+    if (const char* e = getenv("XFMR_GEMM_TILE")) sscanf(e, "%d,%d,%d", &t.bm, &t.bn, &t.bk);
+    return t;
+  }();
+  return o;
+}
+
 template <class P, int BK, bool TA, bool TB, int EPI>
 int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
-  // These GEMMs are skinny (K <= 1024) and bound by operand streaming + latency, not by MFMA issue: prefer
-  // the largest tile that still yields >= 512 workgroups (2 per CU), otherwise the smallest tile.
-  auto wgs = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (int64_t)splits; };
-  int bm = 64, bn = 64;
-  if (BK <= 64 && g.N > 64 && g.M > 64 && wgs(128, 128) >= 512) { bm = 128; bn = 128; }
-  else if (g.N > 64 && wgs(64, 128) >= 512) { bm = 64; bn = 128; }
-  else if (g.M > 64 && wgs(128, 64) >= 512) { bm = 128; bn = 64; }
+  // These GEMMs are skinny (K <= 1024) and latency-bound, not MFMA-bound. Measured on MI355X at T = 25 600
+  // (scripts/bench_gemm.py): many small workgroups win -- 64x64 tiles with 32-deep slices for the forward /
+  // dX GEMMs (64x128 once N >= 256), 128x128 tiles with 128-deep slices only for the split-K dW GEMMs.
+  int bm = 64, bn = (g.N >= 256 && EPI != EPI_GELU_GRAD) ? 128 : 64;
+  if (EPI == EPI_SPLITK && g.M > 64 && g.N > 64) { bm = 128; bn = 128; }
+  const TileOverride ov = tile_override();
+  if (ov.bm) { bm = ov.bm; bn = ov.bn; }
   dim3 block(256);
   dim3 grid((unsigned)((g.N + bn - 1) / bn), (unsigned)((g.M + bm - 1) / bm), splits);
   if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
   else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
   else if (bm == 64) hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
-  else {
-    if constexpr (BK <= 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
-    else return XFMR_EINVAL;
-  }
+  else hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
 
 template <class P, bool TA, bool TB, int EPI>
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
-  // deep slices (one or four trips through the K loop at K = 128 / 512) when the contraction allows it:
-  // more bytes in flight per barrier. bf16 only (the fp32 LDS images would be twice as large).
+  // deep (128) K slices only pay for the split-K dW GEMMs (see launch_gemm_bk); bf16 only.
   const int kspan = g.k_chunk > 0 ? g.k_chunk : g.K;
-  if constexpr (P::kId == XFMR_PREC_BF16) {
-    if (kspan % 128 == 0) return launch_gemm_bk<P, 128, TA, TB, EPI>(g, splits, st);
+  const TileOverride ov = tile_override();
+  if constexpr (P::kId == XFMR_PREC_BF16 && EPI == EPI_SPLITK) {
+    if (kspan % 128 == 0 && ov.bk != 32) return launch_gemm_bk<P, 128, TA, TB, EPI>(g, splits, st);
+  }
+  if constexpr (P::kId == XFMR_PREC_BF16 && EPI != EPI_SPLITK) {
+    if (kspan % 128 == 0 && ov.bk == 128) return launch_gemm_bk<P, 128, TA, TB, EPI>(g, splits, st);
   }
   return launch_gemm_bk<P, 32, TA, TB, EPI>(g, splits, st);
 }
