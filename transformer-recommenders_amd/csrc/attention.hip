@@ -299,6 +299,239 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   xf_store_tile_T(sc_w, dv, 1.f, a.d_qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, k0, L);
 }
 
+// ================================================================================================================
+// bf16 production kernels: ONE swizzled row image per operand (SwzImg<32>: unpadded 64-byte rows, chunk position
+// c ^ ((row>>2)&3)); row-operand fragments are conflict-free 16-byte reads and the transposed fragments of the
+// O / dQ / dK / dV products come from the SAME image through ds_read_b64_tr_b16 -- no transposed copies (V^T, K^T,
+// Q^T, dO^T) and no scattered transposing stores while staging.
+// ================================================================================================================
+using AI = SwzImg<DH>;
+
+__device__ __forceinline__ void stage_rows_swz(__bf16* img, const float* src, int64_t stride, int row0, int nrows,
+                                               int row_end) {
+  for (int c = threadIdx.x; c < nrows * 8; c += blockDim.x) {
+    const int r = c >> 3, dd = (c & 7) * 4;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * stride + dd);
+    xf_store4<PrecBF16>(img + AI::off(r, dd >> 3) + (dd & 7), v);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
+  const int qblk0 = blockIdx.x * 128;
+  const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
+  __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* sV = sK + nkeys * DH;
+  float* scratch = reinterpret_cast<float*>(sV + nkeys * DH);
+  uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
+
+  const int64_t tok0 = (int64_t)b * L;
+  stage_rows_swz(sK, a.qkv + tok0 * 3 * H + H + h * DH, 3 * H, 0, nkeys, L);
+  stage_rows_swz(sV, a.qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0, nkeys, L);
+  for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
+  __syncthreads();
+
+  const int lane = xf_lane(), wid = threadIdx.x >> 6;
+  const int q0 = qblk0 + wid * 32;
+  if (q0 >= L) return;
+  const int q = q0 + (lane & 31);
+  RegRows<PrecBF16, DH> qreg;
+  qreg.load(a.qkv + (tok0 + q) * 3 * H + h * DH, q < L);
+  const float sc = 0.17677669529663687f * kLog2e;
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
+  const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
+  for (int kb = 0; kb <= kb_end; ++kb) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    AI::tile_nreg(s, sK, kb * 32, qreg.regs());
+    float bmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + xf_acc_row(r, lane);
+      const bool vis = (key <= q) && sMask[key];
+      s[r] = vis ? s[r] * sc : -INFINITY;
+      bmax = fmaxf(bmax, s[r]);
+    }
+    bmax = fmaxf(bmax, xf_half_swap(bmax));
+    const float mnew = fmaxf(m, bmax);
+    if (__all(mnew == -INFINITY)) continue;
+    const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+    const float alpha = xf_exp2(m - msafe);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = xf_exp2(s[r] - msafe);
+      psum += p;
+      s[r] = a.drop.on ? p * xf_keep_scale(a.drop, ebase + (uint32_t)(kb * 32 + xf_acc_row(r, lane))) : p;
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    m = mnew;
+    AI::tile_xb_tr(o, sV, 0, kb * 32, s);
+  }
+  const float ltot = lsum + xf_half_swap(lsum);
+  const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+  xf_store_tile_T(scratch + wid * 32 * 33, o, inv, a.ctx + tok0 * H + h * DH, H, q0, L);
+  if (lane < 32 && q < L)
+    a.lse[((int64_t)blockIdx.y) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
+  const int qblk0 = blockIdx.x * 128;
+  const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
+  __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* sV = sK + nkeys * DH;
+  float* scratch = reinterpret_cast<float*>(sV + nkeys * DH);
+  uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
+
+  const int64_t tok0 = (int64_t)b * L;
+  stage_rows_swz(sK, a.qkv + tok0 * 3 * H + H + h * DH, 3 * H, 0, nkeys, L);
+  stage_rows_swz(sV, a.qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0, nkeys, L);
+  for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
+  __syncthreads();
+
+  const int lane = xf_lane(), wid = threadIdx.x >> 6;
+  const int q0 = qblk0 + wid * 32;
+  if (q0 >= L) return;
+  const int q = q0 + (lane & 31);
+  const bool qv = q < L;
+  RegRows<PrecBF16, DH> qreg, doreg;
+  qreg.load(a.qkv + (tok0 + q) * 3 * H + h * DH, qv);
+  doreg.load(a.d_ctx + (tok0 + q) * H + h * DH, qv);
+  float delta = 0.f;
+  if (qv) {
+    const float* po = a.ctx + (tok0 + q) * H + h * DH + 16 * (lane >> 5);
+    const float* pd = a.d_ctx + (tok0 + q) * H + h * DH + 16 * (lane >> 5);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 x = *reinterpret_cast<const float4*>(po + 4 * u);
+      const float4 y = *reinterpret_cast<const float4*>(pd + 4 * u);
+      delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+  }
+  delta += xf_half_swap(delta);
+  const float lse2 = qv ? a.lse[(int64_t)blockIdx.y * L + q] * kLog2e : INFINITY;
+  const float sc = 0.17677669529663687f * kLog2e;
+  const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
+  f32x16 dq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
+  for (int kb = 0; kb <= kb_end; ++kb) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    AI::tile_nreg(s, sK, kb * 32, qreg.regs());
+    AI::tile_nreg(dp, sV, kb * 32, doreg.regs());
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + xf_acc_row(r, lane);
+      const bool vis = (key <= q) && sMask[key];
+      const float p = vis ? xf_exp2(s[r] * sc - lse2) : 0.f;
+      float dpv = dp[r];
+      if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)key);
+      s[r] = p * (dpv - delta);
+    }
+    AI::tile_xb_tr(dq, sK, 0, kb * 32, s);
+  }
+  xf_store_tile_T(scratch + wid * 32 * 33, dq, 0.17677669529663687f, a.d_qkv + tok0 * 3 * H + h * DH, 3 * H, q0, L);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
+  const int kblk0 = blockIdx.x * 128;
+  const int Lp = ((L + 31) / 32) * 32;
+  const int nq = Lp - kblk0;
+  __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* sDO = sQ + nq * DH;
+  float* scratch = reinterpret_cast<float*>(sDO + nq * DH);
+  float* sLse = scratch + 4 * 32 * 33;
+  float* sDelta = sLse + nq;
+
+  const int64_t tok0 = (int64_t)b * L;
+  const float* dobase = a.d_ctx + tok0 * H + h * DH;
+  const float* obase = a.ctx + tok0 * H + h * DH;
+  stage_rows_swz(sQ, a.qkv + tok0 * 3 * H + h * DH, 3 * H, kblk0, nq, L);
+  stage_rows_swz(sDO, dobase, H, kblk0, nq, L);
+  for (int c = threadIdx.x; c < nq * 8; c += blockDim.x) {
+    const int r = c >> 3, dd = (c & 7) * 4;
+    float part = 0.f;
+    if (kblk0 + r < L) {
+      const float4 x = *reinterpret_cast<const float4*>(obase + (int64_t)(kblk0 + r) * H + dd);
+      const float4 y = *reinterpret_cast<const float4*>(dobase + (int64_t)(kblk0 + r) * H + dd);
+      part = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if ((c & 7) == 0) {
+      sDelta[r] = part;
+      sLse[r] = (kblk0 + r < L) ? a.lse[(int64_t)blockIdx.y * L + kblk0 + r] * kLog2e : INFINITY;
+    }
+  }
+  __syncthreads();
+
+  const int lane = xf_lane(), wid = threadIdx.x >> 6;
+  const int k0 = kblk0 + wid * 32;
+  if (k0 >= L) return;
+  const int key = k0 + (lane & 31);
+  const bool kvis = key < L && a.key_mask[tok0 + (key < L ? key : 0)];
+  RegRows<PrecBF16, DH> kreg, vreg;
+  kreg.load(a.qkv + (tok0 + key) * 3 * H + H + h * DH, key < L);
+  vreg.load(a.qkv + (tok0 + key) * 3 * H + 2 * H + h * DH, key < L);
+  const float sc = 0.17677669529663687f * kLog2e;
+  f32x16 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+  for (int qb = k0 / 32; qb < Lp / 32; ++qb) {
+    const int row0 = qb * 32 - kblk0;
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    AI::tile_nreg(s, sQ, row0, kreg.regs());
+    AI::tile_nreg(dp, sDO, row0, vreg.regs());
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = row0 + xf_acc_row(r, lane);
+      const int q = qi + kblk0;
+      const bool vis = kvis && (key <= q);
+      const float p = vis ? xf_exp2(s[r] * sc - sLse[qi]) : 0.f;
+      float keep = 1.f;
+      if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blockIdx.y * L + q) * L) + (uint32_t)key);
+      s[r] = p * (dp[r] * keep - sDelta[qi]);
+      dp[r] = p * keep;
+    }
+    AI::tile_xb_tr(dv, sDO, 0, row0, dp);
+    AI::tile_xb_tr(dk, sQ, 0, row0, s);
+  }
+  float* sc_w = scratch + wid * 32 * 33;
+  xf_store_tile_T(sc_w, dk, 0.17677669529663687f, a.d_qkv + tok0 * 3 * H + H + h * DH, 3 * H, k0, L);
+  xf_store_tile_T(sc_w, dv, 1.f, a.d_qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, k0, L);
+}
+
+size_t bf16_smem_fwd(int L) {  // K + V images, transposed-store scratch, key mask
+  const int Lp = ((L + 31) / 32) * 32;
+  return (size_t)2 * Lp * DH * 2 + 4 * 32 * 33 * sizeof(float) + Lp;
+}
+size_t bf16_smem_dkv(int L) {  // Q + dO images, scratch, lse + delta
+  const int Lp = ((L + 31) / 32) * 32;
+  return (size_t)2 * Lp * DH * 2 + 4 * 32 * 33 * sizeof(float) + 2 * (size_t)Lp * sizeof(float);
+}
+
 template <class P>
 size_t fwd_smem(int L) {
   using SM = AttnSmem<P>;
@@ -322,28 +555,51 @@ constexpr size_t kLdsLimit = 160 * 1024;
 
 template <class P>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
-  const size_t sm = fwd_smem<P>(a.L);
-  if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
-  if (hipFuncSetAttribute((const void*)attn_fwd_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
-      hipSuccess)
-    return XFMR_EHIP;
-  hipLaunchKernelGGL((attn_fwd_kernel<P>), dim3((a.L + 127) / 128, a.B * a.A), dim3(256), sm, st, a);
+  dim3 grid((a.L + 127) / 128, a.B * a.A);
+  if constexpr (P::kId == XFMR_PREC_BF16) {
+    const size_t sm = bf16_smem_fwd(a.L);
+    if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
+    if (hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
+        hipSuccess)
+      return XFMR_EHIP;
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), sm, st, a);
+  } else {
+    const size_t sm = fwd_smem<P>(a.L);
+    if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
+    if (hipFuncSetAttribute((const void*)attn_fwd_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
+        hipSuccess)
+      return XFMR_EHIP;
+    hipLaunchKernelGGL((attn_fwd_kernel<P>), grid, dim3(256), sm, st, a);
+  }
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
 template <class P>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
-  const size_t s1 = dq_smem<P>(a.L), s2 = dkv_smem<P>(a.L);
-  if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
-  if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s1) !=
-          hipSuccess ||
-      hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2) !=
-          hipSuccess)
-    return XFMR_EHIP;
   dim3 grid((a.L + 127) / 128, a.B * a.A);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<P>), grid, dim3(256), s1, st, a);
-  XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<P>), grid, dim3(256), s2, st, a);
+  if constexpr (P::kId == XFMR_PREC_BF16) {
+    const size_t s1 = bf16_smem_fwd(a.L), s2 = bf16_smem_dkv(a.L);
+    if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
+    if (hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)s1) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)s2) != hipSuccess)
+      return XFMR_EHIP;
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(256), s1, st, a);
+    XF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(256), s2, st, a);
+  } else {
+    const size_t s1 = dq_smem<P>(a.L), s2 = dkv_smem<P>(a.L);
+    if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
+    if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)s1) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)s2) != hipSuccess)
+      return XFMR_EHIP;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<P>), grid, dim3(256), s1, st, a);
+    XF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P>), grid, dim3(256), s2, st, a);
+  }
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }

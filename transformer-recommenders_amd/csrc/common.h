@@ -315,6 +315,7 @@ struct SwzImg {
   // hit four different chunk groups instead of the same one (measured: 53 % of LDS cycles were conflicts with
   // the plain c ^ (r & 15) swizzle).
   __device__ static __forceinline__ int swz(int r) {
+    if (CPR == 4) return (r >> 2) & 3;  // 64-byte rows (attention heads): four rows per 256-B bank row
     if (CPR >= 16) return ((r & 3) << 2) | ((r >> 2) & 3);
     return (((r >> 1) & 1) << 2) | ((r & 1) << 1) | ((r >> 2) & 1);  // CPR == 8: two rows per 256-B bank row
   }
