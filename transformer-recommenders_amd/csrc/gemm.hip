@@ -357,6 +357,11 @@ int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
 
 extern "C" {
 
+// internal (norm.hip): dst[c] = sum over all rows
+int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st) {
+  return launch_rowsum(dst, src, rows, cols, rows, st);
+}
+
 int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
                     int32_t epilogue, const float* residual, float* aux_out, float dropout_p, uint64_t seed,
                     uint32_t site, int32_t precision, void* stream) {

@@ -4,6 +4,9 @@
 // instruction touches 256 contiguous bytes; row statistics are wave reductions, never LDS.
 #include "common.h"
 
+// single-level deterministic column sum dst[c] = sum_r src[r*cols + c] (gemm.hip)
+extern "C" int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st);
+
 namespace {
 
 constexpr int kMaxPerLane = 16;  // H <= 1024
@@ -159,6 +162,131 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   }
 }
 
+// ---- vectorised variants for H = 4 * LPR (LPR = 16, 32, 64 lanes per row): 16 bytes per lane, several rows per
+// wave instruction (a 1-KiB wave load instead of 256 B), row statistics by shuffles inside the LPR-lane group.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR, bool GATHER>
+__global__ __launch_bounds__(256) void ln_fwd_v4_kernel(LnFwdArgs a) {
+  constexpr int H = 4 * LPR, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int sub = lane / LPR, li = lane % LPR, c = li * 4;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wid) * RPW + sub;
+  const bool valid = row < a.rows;
+  float4 v = make_float4(0, 0, 0, 0);
+  if (GATHER) {
+    int nz = 0;
+    if (valid) {
+      int64_t item = a.idx[row];
+      if (item < 0 || item >= a.n_rows) item = 0;
+      const float4 e = *reinterpret_cast<const float4*>(a.table + item * H + c);
+      nz = (e.x != 0.f) | (e.y != 0.f) | (e.z != 0.f) | (e.w != 0.f);
+      const float4 ty = *reinterpret_cast<const float4*>(a.type_emb + c);
+      const float4 pe = *reinterpret_cast<const float4*>(a.pos_emb + (int64_t)(row % a.L) * H + c);
+      v.x = (e.x + ty.x) + pe.x; v.y = (e.y + ty.y) + pe.y; v.z = (e.z + ty.z) + pe.z; v.w = (e.w + ty.w) + pe.w;
+      *reinterpret_cast<float4*>(a.pre + row * H + c) = v;
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) nz |= __shfl_xor(nz, o, 64);
+    if (valid && li == 0) a.key_mask[row] = nz ? 1 : 0;
+  } else if (valid) {
+    v = *reinterpret_cast<const float4*>(a.x + row * H + c);
+  }
+  const float mean = row_sum<LPR>((v.x + v.y) + (v.z + v.w)) / (float)H;
+  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+  const float var = row_sum<LPR>((dx * dx + dy * dy) + (dz * dz + dw * dw)) / (float)H;
+  const float rstd = rsqrtf(var + a.eps);
+  if (!valid) return;
+  if (li == 0) {
+    a.mean[row] = mean;
+    a.rstd[row] = rstd;
+  }
+  const float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
+  const float4 b = *reinterpret_cast<const float4*>(a.beta + c);
+  float4 o;
+  o.x = dx * rstd * g.x + b.x; o.y = dy * rstd * g.y + b.y; o.z = dz * rstd * g.z + b.z; o.w = dw * rstd * g.w + b.w;
+  if (a.drop.on) {
+    const uint32_t e = (uint32_t)(row * H + c);
+    o.x *= xf_keep_scale(a.drop, e); o.y *= xf_keep_scale(a.drop, e + 1);
+    o.z *= xf_keep_scale(a.drop, e + 2); o.w *= xf_keep_scale(a.drop, e + 3);
+  }
+  *reinterpret_cast<float4*>(a.y + row * H + c) = o;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(LnBwdArgs a) {
+  constexpr int H = 4 * LPR, RPW = 64 / LPR;
+  __shared__ float red[4][3][H];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int sub = lane / LPR, li = lane % LPR, c = li * 4;
+  const float4 gam = *reinterpret_cast<const float4*>(a.gamma + c);
+  float4 dgam = make_float4(0, 0, 0, 0), dbet = dgam, dbias = dgam;
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  const int64_t r1 = (r0 + a.rows_per_block < a.rows) ? r0 + a.rows_per_block : a.rows;
+  for (int64_t rb = r0 + wid * RPW; rb < r1; rb += 4 * RPW) {  // wave-uniform trip count
+    const int64_t row = rb + sub;
+    const bool valid = row < r1;
+    float4 dy = make_float4(0, 0, 0, 0), xv = dy;
+    float mean = 0.f, rstd = 0.f;
+    if (valid) {
+      dy = *reinterpret_cast<const float4*>(a.dy + row * H + c);
+      xv = *reinterpret_cast<const float4*>(a.x + row * H + c);
+      mean = a.mean[row];
+      rstd = a.rstd[row];
+      if (a.drop_out.on) {
+        const uint32_t e = (uint32_t)(row * H + c);
+        dy.x *= xf_keep_scale(a.drop_out, e); dy.y *= xf_keep_scale(a.drop_out, e + 1);
+        dy.z *= xf_keep_scale(a.drop_out, e + 2); dy.w *= xf_keep_scale(a.drop_out, e + 3);
+      }
+    }
+    float4 xh, g;
+    xh.x = (xv.x - mean) * rstd; xh.y = (xv.y - mean) * rstd; xh.z = (xv.z - mean) * rstd; xh.w = (xv.w - mean) * rstd;
+    g.x = dy.x * gam.x; g.y = dy.y * gam.y; g.z = dy.z * gam.z; g.w = dy.w * gam.w;
+    dgam.x += dy.x * xh.x; dgam.y += dy.y * xh.y; dgam.z += dy.z * xh.z; dgam.w += dy.w * xh.w;
+    dbet.x += dy.x; dbet.y += dy.y; dbet.z += dy.z; dbet.w += dy.w;
+    const float mg = row_sum<LPR>((g.x + g.y) + (g.z + g.w)) / (float)H;
+    const float mgx = row_sum<LPR>((g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w)) / (float)H;
+    if (valid) {
+      float4 d;
+      d.x = rstd * (g.x - mg - xh.x * mgx); d.y = rstd * (g.y - mg - xh.y * mgx);
+      d.z = rstd * (g.z - mg - xh.z * mgx); d.w = rstd * (g.w - mg - xh.w * mgx);
+      *reinterpret_cast<float4*>(a.dx + row * H + c) = d;
+      float4 dl = d;
+      if (a.drop_lin.on) {
+        const uint32_t e = (uint32_t)(row * H + c);
+        dl.x *= xf_keep_scale(a.drop_lin, e); dl.y *= xf_keep_scale(a.drop_lin, e + 1);
+        dl.z *= xf_keep_scale(a.drop_lin, e + 2); dl.w *= xf_keep_scale(a.drop_lin, e + 3);
+        *reinterpret_cast<float4*>(a.d_lin + row * H + c) = dl;
+      }
+      dbias.x += dl.x; dbias.y += dl.y; dbias.z += dl.z; dbias.w += dl.w;
+    }
+  }
+  // combine the RPW row groups of the wave (lanes with equal li), then the 4 waves, in a fixed order
+  auto fold = [&](float4& v) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+      v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+    }
+  };
+  fold(dgam); fold(dbet); fold(dbias);
+  if (sub == 0) {
+    *reinterpret_cast<float4*>(&red[wid][0][c]) = dgam;
+    *reinterpret_cast<float4*>(&red[wid][1][c]) = dbet;
+    *reinterpret_cast<float4*>(&red[wid][2][c]) = dbias;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 3 * H; o += 256) {
+    const float* r = &red[0][0][0];
+    a.partials[(int64_t)blockIdx.x * 3 * H + o] = (r[o] + r[3 * H + o]) + (r[6 * H + o] + r[9 * H + o]);
+  }
+}
+
 // sums `blocks` partial records [blocks][3][H] into up to three destinations: 64 outputs per workgroup,
 // 4 record groups in flight, fixed combine order (deterministic)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partials, int blocks, int H, float* d_gamma,
@@ -273,7 +401,17 @@ int npl_of(int H) { return (H + 63) / 64; }
 
 template <bool GATHER>
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
+  dim3 block(256);
+  if (a.H == 64 || a.H == 128 || a.H == 256) {
+    const int rpw = 256 / a.H;  // rows per wave
+    dim3 gridv((unsigned)((a.rows + 4 * rpw - 1) / (4 * rpw)));
+    if (a.H == 64) hipLaunchKernelGGL((ln_fwd_v4_kernel<16, GATHER>), gridv, block, 0, st, a);
+    else if (a.H == 128) hipLaunchKernelGGL((ln_fwd_v4_kernel<32, GATHER>), gridv, block, 0, st, a);
+    else hipLaunchKernelGGL((ln_fwd_v4_kernel<64, GATHER>), gridv, block, 0, st, a);
+    XF_LAUNCH_CHECK();
+    return XFMR_OK;
+  }
+  dim3 grid((unsigned)((a.rows + 3) / 4));
   const int npl = npl_of(a.H);
   if (npl <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, GATHER>), grid, block, 0, st, a);
   else if (npl <= 2) hipLaunchKernelGGL((ln_fwd_kernel<2, GATHER>), grid, block, 0, st, a);
@@ -290,7 +428,7 @@ int ln_bwd_blocks(int64_t rows, int* rows_per_block) {
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   int64_t rpb = (rows + blocks - 1) / blocks;
-  rpb = ((rpb + 3) / 4) * 4;
+  rpb = ((rpb + 15) / 16) * 16;  // whole wave-iterations of the vectorised kernel (4 waves x up to 4 rows)
   *rows_per_block = (int)rpb;
   return (int)((rows + rpb - 1) / rpb);
 }
@@ -343,7 +481,10 @@ int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, co
   const size_t shmem = (size_t)12 * H * sizeof(float);
   const int npl = npl_of(H);
   dim3 grid(blocks), block(256);
-  if (npl <= 1) hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, block, shmem, st, a);
+  if (H == 64) hipLaunchKernelGGL((ln_bwd_v4_kernel<16>), grid, block, 0, st, a);
+  else if (H == 128) hipLaunchKernelGGL((ln_bwd_v4_kernel<32>), grid, block, 0, st, a);
+  else if (H == 256) hipLaunchKernelGGL((ln_bwd_v4_kernel<64>), grid, block, 0, st, a);
+  else if (npl <= 1) hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, block, shmem, st, a);
   else if (npl <= 2) hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, block, shmem, st, a);
   else if (npl <= 4) hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, shmem, st, a);
   else if (npl <= 8) hipLaunchKernelGGL((ln_bwd_kernel<8>), grid, block, shmem, st, a);
@@ -368,11 +509,14 @@ int xfmr_embed_param_grads(const float* d_pre, float* d_pos, float* d_type, int3
                            int32_t max_pos, void* stream) {
   if (!d_pre || !d_pos || !d_type || B <= 0 || L <= 0 || H <= 0 || max_pos < L) return XFMR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_pos_grad_kernel, dim3((H + 63) / 64, max_pos), dim3(64), 0, st, d_pre, d_pos, B, L, H,
-                     max_pos);
-  XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(embed_type_grad_kernel, dim3((H + 63) / 64), dim3(64), 0, st, (const float*)d_pos, d_type, L, H);
-  XF_LAUNCH_CHECK();
+  // d_pos (L*H) = column sums of d_pre viewed as [B][L*H]; rows L..max_pos-1 get no gradient
+  if (int rc = xf_rowsum(d_pos, d_pre, B, (int64_t)L * H, st)) return rc;
+  if (max_pos > L &&
+      hipMemsetAsync(d_pos + (int64_t)L * H, 0, (size_t)(max_pos - L) * H * sizeof(float), st) != hipSuccess)
+    return XFMR_EHIP;
+  // d_type[0] = column sums of d_pos viewed as [L][H]; d_type[1] = 0 (token type 1 is never used)
+  if (int rc = xf_rowsum(d_type, d_pos, L, H, st)) return rc;
+  if (hipMemsetAsync(d_type + H, 0, (size_t)H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   return XFMR_OK;
 }
 
