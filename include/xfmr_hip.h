@@ -214,7 +214,8 @@ int xfmr_mean_pool(const float* tok, const uint8_t* key_mask, float* out, int32_
  * num_hard_negatives (losses.py:295-330) is not fused: pass 0.
  *
  * Outputs (all device memory):
- *   losses[7]        summed loss per head (fp64 -> written as fp32), order XFMR_LOSS_*
+ *   losses[14]       [0..6] summed loss per head (accumulated in fp64), order XFMR_LOSS_*;
+ *                    [7..13] the same divided by (Np + 1e-9): the `loss/<Class>Mean` values of trainer.py:263
  *   stats[16]        see XFMR_STAT_*; fp32
  *   d_tok (B*L,H)    dL(train_head)/d tok, rows that are not queries are zero; may be NULL (eval)
  * workspace: xfmr_sampled_loss_workspace(B*L, H, n_rows) bytes. table_bf16: see xfmr_table_prepare (may be NULL).

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
     if (k == 20 || k == 22) v = fmin(fmin(sAcc[0][k], sAcc[1][k]), fmin(sAcc[2][k], sAcc[3][k]));
     else if (k == 21 || k == 23) v = fmax(fmax(sAcc[0][k], sAcc[1][k]), fmax(sAcc[2][k], sAcc[3][k]));
     else v = sAcc[0][k] + sAcc[1][k] + sAcc[2][k] + sAcc[3][k];
-    a.blockpart[(int64_t)blockIdx.x * BP + k] = v;
+    a.blockpart[(int64_t)k * gridDim.x + blockIdx.x] = v;  // [BP][blocks]: the final kernel reads coalesced
   }
 }
 
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(1024) void loss_final_kernel(const double* blockpar
     const bool is_min = (k == 20 || k == 22), is_max = (k == 21 || k == 23);
     double v = is_min ? INFINITY : is_max ? -INFINITY : 0.0;
     for (int b = lane; b < used; b += 64) {
-      const double x = blockpart[(int64_t)b * BP + k];
+      const double x = blockpart[(int64_t)k * nblocks + b];
       v = is_min ? fmin(v, x) : is_max ? fmax(v, x) : v + x;
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -437,7 +437,10 @@ __global__ __launch_bounds__(1024) void loss_final_kernel(const double* blockpar
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 0; k < XFMR_NUM_LOSSES; ++k) losses[k] = (float)tot[k];
+    for (int k = 0; k < XFMR_NUM_LOSSES; ++k) {
+      losses[k] = (float)tot[k];
+      losses[XFMR_NUM_LOSSES + k] = (float)(tot[k] / ((double)Nq + 1e-9));  // loss/<Class>Mean (trainer.py:263)
+    }
     for (int k = 0; k < XFMR_NUM_STATS; ++k) stats[k] = 0.f;
     const double nq = (double)Nq;
     stats[XFMR_STAT_N_VALID] = (float)((mode == XFMR_NEG_CATALOG) ? (int)n_rows : counts[0]);

@@ -198,7 +198,7 @@ def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, a
     lib = N.load()
     cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision)
     n_rows = table.shape[0]
-    losses = _empty((N.NUM_LOSSES,), tok)
+    losses = _empty((2 * N.NUM_LOSSES,), tok)
     stats = _empty((N.NUM_STATS,), tok)
     d_tok = torch.empty_like(tok) if need_grad else None
     nbytes = lib.xfmr_sampled_loss_workspace(T, H, n_rows)
@@ -230,7 +230,7 @@ def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head,
     lib = N.load()
     cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision)
     n_rows = table.shape[0]
-    losses, stats = _empty((N.NUM_LOSSES,), query), _empty((N.NUM_STATS,), query)
+    losses, stats = _empty((2 * N.NUM_LOSSES,), query), _empty((N.NUM_STATS,), query)
     d_q = torch.empty_like(query) if need_grad else None
     nbytes = lib.xfmr_sampled_loss_lists_workspace(Np, Nn, H, n_rows)
     ws = _bytes(nbytes, query)

@@ -180,7 +180,7 @@ class RecommenderLightningModule(_Base):
             val = train_loss if name == c.train_loss else losses[i]
             out[f"loss/{name}"] = val
             if not overlap:
-                out[f"loss/{name}Mean"] = val.detach() / (n_query + 1e-9)
+                out[f"loss/{name}Mean"] = losses[N.NUM_LOSSES + i]  # computed by the final kernel
         if overlap:  # the ...Mean values are derived lazily (after the join) by loss_means()
             out["losses/device"] = losses
         batch_size, seq_len = key_mask.shape
