@@ -415,28 +415,37 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int o) {
   hi = __shfl_xor(hi, o, 64);
   return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(1024) void loss_final_kernel(const double* blockpart, int nblocks, const int* counts,
-                                                          int mode, int64_t n_rows, float* losses, float* stats) {
-  __shared__ double tot[BP];
+// stage 1: block k reduces quantity k over the blocks that carried queries (256 threads, 4 loads in flight each)
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const double* blockpart, int nblocks, const int* counts,
+                                                          double* tot) {
+  __shared__ double red[256];
+  const int k = blockIdx.x;
   const int Nq = counts[1];
-  int used = (Nq + 3) / 4;  // blocks that carried queries
+  int used = (Nq + 3) / 4;
   if (used > nblocks) used = nblocks;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int k = w; k < BP; k += 16) {
-    const bool is_min = (k == 20 || k == 22), is_max = (k == 21 || k == 23);
-    double v = is_min ? INFINITY : is_max ? -INFINITY : 0.0;
-    for (int b = lane; b < used; b += 64) {
-      const double x = blockpart[(int64_t)k * nblocks + b];
-      v = is_min ? fmin(v, x) : is_max ? fmax(v, x) : v + x;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double x = shfl_xor_f64(v, o);
-      v = is_min ? fmin(v, x) : is_max ? fmax(v, x) : v + x;
-    }
-    if (lane == 0) tot[k] = v;
+  const bool is_min = (k == 20 || k == 22), is_max = (k == 21 || k == 23);
+  const double id = is_min ? INFINITY : is_max ? -INFINITY : 0.0;
+  auto op = [&](double x, double y) { return is_min ? fmin(x, y) : is_max ? fmax(x, y) : x + y; };
+  const double* src = blockpart + (int64_t)k * nblocks;
+  double v0 = id, v1 = id, v2 = id, v3 = id;
+  int b = threadIdx.x;
+  for (; b + 768 < used; b += 1024) {
+    v0 = op(v0, src[b]); v1 = op(v1, src[b + 256]); v2 = op(v2, src[b + 512]); v3 = op(v3, src[b + 768]);
   }
+  for (; b < used; b += 256) v0 = op(v0, src[b]);
+  red[threadIdx.x] = op(op(v0, v1), op(v2, v3));
   __syncthreads();
-  if (threadIdx.x == 0) {
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] = op(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tot[k] = red[0];
+}
+// stage 2: one thread turns the 24 totals into the 14 loss values and the statistics
+__global__ void loss_final_kernel(const double* tot, const int* counts, int mode, int64_t n_rows, float* losses,
+                                  float* stats) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int Nq = counts[1];
     for (int k = 0; k < XFMR_NUM_LOSSES; ++k) {
       losses[k] = (float)tot[k];
       losses[XFMR_NUM_LOSSES + k] = (float)(tot[k] / ((double)Nq + 1e-9));  // loss/<Class>Mean (trainer.py:263)
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(1024) void loss_final_kernel(const double* blockpar
 // ---- host side ---------------------------------------------------------------------------------------------
 struct Plan {
   int nsplit;
-  size_t off_part2, off_negrc;
+  size_t off_part2, off_negrc, off_tot;
   size_t off_counts, off_blockcnt, off_neg, off_qrow, off_qpos, off_part, off_partO, off_block, total;
   int nblocks;
 };
@@ -490,6 +499,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows) {
   p.off_part2 = o; o += up256((size_t)ns * T * REC * 4);
   p.off_partO = o; o += up256((size_t)ns * T * H * 4);
   p.off_block = o; o += up256((size_t)p.nblocks * BP * 8);
+  p.off_tot = o; o += 256;
   p.total = o;
   return p;
 }
@@ -595,8 +605,12 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, st, (const double*)c.blockpart, p.nblocks,
-                     (const int*)counts, cfg->mode, n_rows, losses, stats);
+  double* tot = (double*)(ws + p.off_tot);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(BP), dim3(256), 0, st, (const double*)c.blockpart, p.nblocks,
+                     (const int*)counts, tot);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)tot, (const int*)counts, cfg->mode,
+                     n_rows, losses, stats);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }

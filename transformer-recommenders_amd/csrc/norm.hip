@@ -288,25 +288,30 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(LnBwdArgs a) {
 }
 
 // sums `blocks` partial records [blocks][3][H] into up to three destinations: 64 outputs per workgroup,
-// 4 record groups in flight, fixed combine order (deterministic)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partials, int blocks, int H, float* d_gamma,
-                                                            float* d_beta, float* d_bias) {
-  __shared__ float red[4][64];
+// 16 record groups with 4 loads in flight each, fixed combine order (deterministic)
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* partials, int blocks, int H, float* d_gamma,
+                                                             float* d_beta, float* d_bias) {
+  __shared__ float red[16][64];
   const int c64 = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int o = blockIdx.x * 64 + c64;
-  float s0 = 0.f, s1 = 0.f;
+  const int64_t stride = (int64_t)3 * H;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (o < 3 * H) {
     int b = rg;
-    for (; b + 4 < blocks; b += 8) {
-      s0 += partials[(int64_t)b * 3 * H + o];
-      s1 += partials[(int64_t)(b + 4) * 3 * H + o];
+    for (; b + 48 < blocks; b += 64) {
+      s0 += partials[b * stride + o];
+      s1 += partials[(b + 16) * stride + o];
+      s2 += partials[(b + 32) * stride + o];
+      s3 += partials[(b + 48) * stride + o];
     }
-    for (; b < blocks; b += 4) s0 += partials[(int64_t)b * 3 * H + o];
+    for (; b < blocks; b += 16) s0 += partials[b * stride + o];
   }
-  red[rg][c64] = s0 + s1;
+  red[rg][c64] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && o < 3 * H) {
-    const float s = (red[0][c64] + red[1][c64]) + (red[2][c64] + red[3][c64]);
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][c64];
     const int which = o / H, c = o % H;
     float* dst = which == 0 ? d_gamma : which == 1 ? d_beta : d_bias;
     if (dst) dst[c] = s;
@@ -491,7 +496,7 @@ int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, co
   else if (npl <= kMaxPerLane) hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, shmem, st, a);
   else return XFMR_EUNSUPPORTED;
   XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * H + 63) / 64), dim3(256), 0, st, (const float*)partials,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * H + 63) / 64), dim3(1024), 0, st, (const float*)partials,
                      blocks, H, d_gamma, d_beta, d_bias);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
