@@ -9,7 +9,7 @@
 // One workgroup = 4 waves = 128 consecutive rows (queries, or keys for dK/dV) of one (batch, head);
 // the whole K/V (or Q/dO) panel of that head that the causal mask can reach is staged once into LDS
 // (L <= 512 keeps it under 160 KiB), so there is a single barrier per kernel.
-#include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -18,8 +18,8 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 struct AttnArgs {
-  const float* qkv; const uint8_t* key_mask; float* ctx; float* lse;
-  const float* d_ctx; float* d_qkv;
+  const float* qkv; const uint8_t* key_mask; float* ctx; float* lse;  // qkv / ctx / d_ctx / d_qkv: fp32, or bf16
+  const float* d_ctx; float* d_qkv;                                   // behind the same pointers (S16 kernels)
   int B, L, A, H;
   XfDropout drop;
 };
@@ -307,16 +307,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 // ================================================================================================================
 using AI = SwzImg<DH>;
 
-__device__ __forceinline__ void stage_rows_swz(__bf16* img, const float* src, int64_t stride, int row0, int nrows,
-                                               int row_end) {
-  for (int c = threadIdx.x; c < nrows * 8; c += blockDim.x) {
-    const int r = c >> 3, dd = (c & 7) * 4;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * stride + dd);
-    xf_store4<PrecBF16>(img + AI::off(r, dd >> 3) + (dd & 7), v);
+template <bool S16>
+__device__ __forceinline__ void stage_rows_swz(__bf16* img, const void* srcv, int64_t off, int64_t stride, int row0,
+                                               int nrows, int row_end) {
+  if (S16) {  // bf16 storage: 16-byte chunks go to the image as they are
+    const __bf16* src = reinterpret_cast<const __bf16*>(srcv) + off;
+    for (int c = threadIdx.x; c < nrows * 4; c += blockDim.x) {
+      const int r = c >> 2, ch = c & 3;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (row0 + r < row_end) v = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + r) * stride + ch * 8);
+      *reinterpret_cast<uint4*>(img + AI::off(r, ch)) = v;
+    }
+  } else {
+    const float* src = reinterpret_cast<const float*>(srcv) + off;
+    for (int c = threadIdx.x; c < nrows * 8; c += blockDim.x) {
+      const int r = c >> 3, dd = (c & 7) * 4;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * stride + dd);
+      xf_store4<PrecBF16>(img + AI::off(r, dd >> 3) + (dd & 7), v);
+    }
   }
 }
+// sum over 16 consecutive elements of x[i] * y[i]
+template <bool S16>
+__device__ __forceinline__ float dot16(const void* x, const void* y, int64_t off) {
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float4 a = xf_ld4<S16>(x, off + 4 * u), b = xf_ld4<S16>(y, off + 4 * u);
+    acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  return acc;
+}
 
+template <bool S16>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
@@ -329,8 +353,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
 
   const int64_t tok0 = (int64_t)b * L;
-  stage_rows_swz(sK, a.qkv + tok0 * 3 * H + H + h * DH, 3 * H, 0, nkeys, L);
-  stage_rows_swz(sV, a.qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0, nkeys, L);
+  stage_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, 0, nkeys, L);
+  stage_rows_swz<S16>(sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0, nkeys, L);
   for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
   __syncthreads();
 
@@ -339,7 +363,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   if (q0 >= L) return;
   const int q = q0 + (lane & 31);
   RegRows<PrecBF16, DH> qreg;
-  qreg.load(a.qkv + (tok0 + q) * 3 * H + h * DH, q < L);
+  qreg.load_at<S16>(a.qkv, (tok0 + q) * 3 * H + h * DH, q < L);
   const float sc = 0.17677669529663687f * kLog2e;
   float m = -INFINITY, lsum = 0.f;
   f32x16 o;
@@ -380,11 +404,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   }
   const float ltot = lsum + xf_half_swap(lsum);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-  xf_store_tile_T(scratch + wid * 32 * 33, o, inv, a.ctx + tok0 * H + h * DH, H, q0, L);
+  xf_store_tile_T_at<S16>(scratch + wid * 32 * 33, o, inv, a.ctx, tok0 * H + h * DH, H, q0, L);
   if (lane < 32 && q < L)
     a.lse[((int64_t)blockIdx.y) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
 }
 
+template <bool S16>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
@@ -397,8 +422,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
 
   const int64_t tok0 = (int64_t)b * L;
-  stage_rows_swz(sK, a.qkv + tok0 * 3 * H + H + h * DH, 3 * H, 0, nkeys, L);
-  stage_rows_swz(sV, a.qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0, nkeys, L);
+  stage_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, 0, nkeys, L);
+  stage_rows_swz<S16>(sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0, nkeys, L);
   for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
   __syncthreads();
 
@@ -408,19 +433,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   const int q = q0 + (lane & 31);
   const bool qv = q < L;
   RegRows<PrecBF16, DH> qreg, doreg;
-  qreg.load(a.qkv + (tok0 + q) * 3 * H + h * DH, qv);
-  doreg.load(a.d_ctx + (tok0 + q) * H + h * DH, qv);
+  qreg.load_at<S16>(a.qkv, (tok0 + q) * 3 * H + h * DH, qv);
+  doreg.load_at<S16>(a.d_ctx, (tok0 + q) * H + h * DH, qv);
   float delta = 0.f;
-  if (qv) {
-    const float* po = a.ctx + (tok0 + q) * H + h * DH + 16 * (lane >> 5);
-    const float* pd = a.d_ctx + (tok0 + q) * H + h * DH + 16 * (lane >> 5);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float4 x = *reinterpret_cast<const float4*>(po + 4 * u);
-      const float4 y = *reinterpret_cast<const float4*>(pd + 4 * u);
-      delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-    }
-  }
+  if (qv) delta = dot16<S16>(a.ctx, a.d_ctx, (tok0 + q) * H + h * DH + 16 * (lane >> 5));
   delta += xf_half_swap(delta);
   const float lse2 = qv ? a.lse[(int64_t)blockIdx.y * L + q] * kLog2e : INFINITY;
   const float sc = 0.17677669529663687f * kLog2e;
@@ -446,9 +462,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     }
     AI::tile_xb_tr(dq, sK, 0, kb * 32, s);
   }
-  xf_store_tile_T(scratch + wid * 32 * 33, dq, 0.17677669529663687f, a.d_qkv + tok0 * 3 * H + h * DH, 3 * H, q0, L);
+  xf_store_tile_T_at<S16>(scratch + wid * 32 * 33, dq, 0.17677669529663687f, a.d_qkv, tok0 * 3 * H + h * DH, 3 * H, q0,
+                          L);
 }
 
+template <bool S16>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
@@ -463,16 +481,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   float* sDelta = sLse + nq;
 
   const int64_t tok0 = (int64_t)b * L;
-  const float* dobase = a.d_ctx + tok0 * H + h * DH;
-  const float* obase = a.ctx + tok0 * H + h * DH;
-  stage_rows_swz(sQ, a.qkv + tok0 * 3 * H + h * DH, 3 * H, kblk0, nq, L);
-  stage_rows_swz(sDO, dobase, H, kblk0, nq, L);
+  const int64_t hoff = tok0 * H + h * DH;
+  stage_rows_swz<S16>(sQ, a.qkv, tok0 * 3 * H + h * DH, 3 * H, kblk0, nq, L);
+  stage_rows_swz<S16>(sDO, a.d_ctx, hoff, H, kblk0, nq, L);
   for (int c = threadIdx.x; c < nq * 8; c += blockDim.x) {
     const int r = c >> 3, dd = (c & 7) * 4;
     float part = 0.f;
     if (kblk0 + r < L) {
-      const float4 x = *reinterpret_cast<const float4*>(obase + (int64_t)(kblk0 + r) * H + dd);
-      const float4 y = *reinterpret_cast<const float4*>(dobase + (int64_t)(kblk0 + r) * H + dd);
+      const float4 x = xf_ld4<S16>(a.ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
+      const float4 y = xf_ld4<S16>(a.d_ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
       part = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
     }
     part += __shfl_xor(part, 1, 64);
@@ -491,8 +508,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   const int key = k0 + (lane & 31);
   const bool kvis = key < L && a.key_mask[tok0 + (key < L ? key : 0)];
   RegRows<PrecBF16, DH> kreg, vreg;
-  kreg.load(a.qkv + (tok0 + key) * 3 * H + H + h * DH, key < L);
-  vreg.load(a.qkv + (tok0 + key) * 3 * H + 2 * H + h * DH, key < L);
+  kreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + H + h * DH, key < L);
+  vreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + 2 * H + h * DH, key < L);
   const float sc = 0.17677669529663687f * kLog2e;
   f32x16 dk, dv;
 #pragma unroll
@@ -519,8 +536,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
     AI::tile_xb_tr(dk, sQ, 0, row0, s);
   }
   float* sc_w = scratch + wid * 32 * 33;
-  xf_store_tile_T(sc_w, dk, 0.17677669529663687f, a.d_qkv + tok0 * 3 * H + H + h * DH, 3 * H, k0, L);
-  xf_store_tile_T(sc_w, dv, 1.f, a.d_qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, k0, L);
+  xf_store_tile_T_at<S16>(sc_w, dk, 0.17677669529663687f, a.d_qkv, tok0 * 3 * H + H + h * DH, 3 * H, k0, L);
+  xf_store_tile_T_at<S16>(sc_w, dv, 1.f, a.d_qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, k0, L);
 }
 
 size_t bf16_smem_fwd(int L) {  // K + V images, transposed-store scratch, key mask
@@ -553,16 +570,40 @@ size_t dkv_smem(int L) {
 }
 constexpr size_t kLdsLimit = 160 * 1024;
 
+template <bool S16>
+int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
+  dim3 grid((a.L + 127) / 128, a.B * a.A);
+  const size_t sm = bf16_smem_fwd(a.L);
+  if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sm) != hipSuccess)
+    return XFMR_EHIP;
+  hipLaunchKernelGGL((attn_fwd_bf16_kernel<S16>), grid, dim3(256), sm, st, a);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+template <bool S16>
+int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
+  dim3 grid((a.L + 127) / 128, a.B * a.A);
+  const size_t s1 = bf16_smem_fwd(a.L), s2 = bf16_smem_dkv(a.L);
+  if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)s1) != hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)s2) != hipSuccess)
+    return XFMR_EHIP;
+  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<S16>), grid, dim3(256), s1, st, a);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<S16>), grid, dim3(256), s2, st, a);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
 template <class P>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.L + 127) / 128, a.B * a.A);
   if constexpr (P::kId == XFMR_PREC_BF16) {
-    const size_t sm = bf16_smem_fwd(a.L);
-    if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
-    if (hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
-        hipSuccess)
-      return XFMR_EHIP;
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), sm, st, a);
+    return launch_fwd_bf16<false>(a, st);
   } else {
     const size_t sm = fwd_smem<P>(a.L);
     if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
@@ -578,16 +619,7 @@ template <class P>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.L + 127) / 128, a.B * a.A);
   if constexpr (P::kId == XFMR_PREC_BF16) {
-    const size_t s1 = bf16_smem_fwd(a.L), s2 = bf16_smem_dkv(a.L);
-    if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
-    if (hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)s1) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)s2) != hipSuccess)
-      return XFMR_EHIP;
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(256), s1, st, a);
-    XF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(256), s2, st, a);
+    return launch_bwd_bf16<false>(a, st);
   } else {
     const size_t s1 = dq_smem<P>(a.L), s2 = dkv_smem<P>(a.L);
     if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
@@ -614,33 +646,49 @@ int check_shape(int B, int L, int A, int H) {
 
 extern "C" {
 
-int xfmr_attn_fwd(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,
-                  int32_t A, int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision,
-                  void* stream) {
+int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t A,
+                   int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision, bool s16,
+                   hipStream_t st) {
   if (!qkv || !key_mask || !ctx || !lse) return XFMR_EINVAL;
   if (int rc = check_shape(B, L, A, H)) return rc;
   if (!xf_aligned16(qkv) || !xf_aligned16(ctx)) return XFMR_EALIGN;
   AttnArgs a{};
-  a.qkv = qkv; a.key_mask = key_mask; a.ctx = ctx; a.lse = lse; a.B = B; a.L = L; a.A = A; a.H = H;
+  a.qkv = (const float*)qkv; a.key_mask = key_mask; a.ctx = (float*)ctx; a.lse = lse; a.B = B; a.L = L; a.A = A;
+  a.H = H;
   a.drop = xf_make_dropout(dropout_p, seed, site);
-  if (precision == XFMR_PREC_BF16) return launch_fwd<PrecBF16>(a, (hipStream_t)stream);
-  if (precision == XFMR_PREC_F32) return launch_fwd<PrecF32>(a, (hipStream_t)stream);
+  if (precision == XFMR_PREC_BF16) return s16 ? launch_fwd_bf16<true>(a, st) : launch_fwd<PrecBF16>(a, st);
+  if (precision == XFMR_PREC_F32 && !s16) return launch_fwd<PrecF32>(a, st);
+  return XFMR_EINVAL;
+}
+
+int xfmr_attn_fwd(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,
+                  int32_t A, int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision,
+                  void* stream) {
+  return xf_attn_fwd_ex(qkv, key_mask, ctx, lse, B, L, A, H, dropout_p, seed, site, precision, false,
+                        (hipStream_t)stream);
+}
+
+int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* d_ctx,
+                   void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, uint64_t seed,
+                   uint32_t site, int32_t precision, bool s16, hipStream_t st) {
+  if (!qkv || !key_mask || !ctx || !lse || !d_ctx || !d_qkv) return XFMR_EINVAL;
+  if (int rc = check_shape(B, L, A, H)) return rc;
+  if (!xf_aligned16(qkv) || !xf_aligned16(ctx) || !xf_aligned16(d_ctx) || !xf_aligned16(d_qkv)) return XFMR_EALIGN;
+  AttnArgs a{};
+  a.qkv = (const float*)qkv; a.key_mask = key_mask; a.ctx = (float*)const_cast<void*>(ctx);
+  a.lse = const_cast<float*>(lse); a.d_ctx = (const float*)d_ctx; a.d_qkv = (float*)d_qkv;
+  a.B = B; a.L = L; a.A = A; a.H = H;
+  a.drop = xf_make_dropout(dropout_p, seed, site);
+  if (precision == XFMR_PREC_BF16) return s16 ? launch_bwd_bf16<true>(a, st) : launch_bwd<PrecBF16>(a, st);
+  if (precision == XFMR_PREC_F32 && !s16) return launch_bwd<PrecF32>(a, st);
   return XFMR_EINVAL;
 }
 
 int xfmr_attn_bwd(const float* qkv, const uint8_t* key_mask, const float* ctx, const float* lse,
                   const float* d_ctx, float* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p,
                   uint64_t seed, uint32_t site, int32_t precision, void* stream) {
-  if (!qkv || !key_mask || !ctx || !lse || !d_ctx || !d_qkv) return XFMR_EINVAL;
-  if (int rc = check_shape(B, L, A, H)) return rc;
-  if (!xf_aligned16(qkv) || !xf_aligned16(ctx) || !xf_aligned16(d_ctx) || !xf_aligned16(d_qkv)) return XFMR_EALIGN;
-  AttnArgs a{};
-  a.qkv = qkv; a.key_mask = key_mask; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
-  a.d_ctx = d_ctx; a.d_qkv = d_qkv; a.B = B; a.L = L; a.A = A; a.H = H;
-  a.drop = xf_make_dropout(dropout_p, seed, site);
-  if (precision == XFMR_PREC_BF16) return launch_bwd<PrecBF16>(a, (hipStream_t)stream);
-  if (precision == XFMR_PREC_F32) return launch_bwd<PrecF32>(a, (hipStream_t)stream);
-  return XFMR_EINVAL;
+  return xf_attn_bwd_ex(qkv, key_mask, ctx, lse, d_ctx, d_qkv, B, L, A, H, dropout_p, seed, site, precision, false,
+                        (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -143,6 +143,21 @@ struct RegRows<PrecBF16, K> {
       v[s][4] = (__bf16)b.x; v[s][5] = (__bf16)b.y; v[s][6] = (__bf16)b.z; v[s][7] = (__bf16)b.w;
     }
   }
+  __device__ __forceinline__ void load(const __bf16* row, bool valid) {  // bf16 storage: no conversion
+    const int h = xf_lane() >> 5;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      if (valid) v[s] = *reinterpret_cast<const bf16x8*>(row + 16 * s + 8 * h);
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[s][j] = (__bf16)0.f;
+    }
+  }
+  template <bool S16>
+  __device__ __forceinline__ void load_at(const void* base, int64_t idx, bool valid) {
+    if (S16) load(reinterpret_cast<const __bf16*>(base) + idx, valid);
+    else load(reinterpret_cast<const float*>(base) + idx, valid);
+  }
   __device__ __forceinline__ float dot_partial(const RegRows& o) const {  // over this lane's half of K
     float acc = 0.f;
 #pragma unroll
@@ -180,6 +195,44 @@ struct RegRows<PrecF32, K> {
     for (int s = 0; s < K / 2; ++s) img_row[2 * s + h] = v[s];
   }
 };
+
+// ---------------------------------------------------------------------------------------------------
+// Activation storage. Tensors that are only ever consumed as MFMA operands of the bf16 policy (qkv, ctx,
+// gelu output, the gradients flowing into dX / dW GEMMs) may live in HBM as bf16 instead of fp32: the
+// consumer rounds to bf16 on the way into LDS anyway, so the products are bit-identical and the bytes halve.
+// S16 = true selects that storage; pointers are type-erased at the launch boundary.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 xf_bf16x4_to_f32(uint2 raw) {
+  float4 v;
+  v.x = __uint_as_float(raw.x << 16); v.y = __uint_as_float(raw.x & 0xffff0000u);
+  v.z = __uint_as_float(raw.y << 16); v.w = __uint_as_float(raw.y & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ uint2 xf_f32x4_to_bf16(float4 v) {
+  union { bf16x4 b; uint2 u; } o;
+  o.b[0] = (__bf16)v.x; o.b[1] = (__bf16)v.y; o.b[2] = (__bf16)v.z; o.b[3] = (__bf16)v.w;
+  return o.u;
+}
+// 4 consecutive elements starting at element index idx (idx % 4 == 0)
+template <bool S16>
+__device__ __forceinline__ float4 xf_ld4(const void* base, int64_t idx) {
+  if (S16) return xf_bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(base) + idx));
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+}
+template <bool S16>
+__device__ __forceinline__ void xf_st4(void* base, int64_t idx, float4 v) {
+  if (S16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(base) + idx) = xf_f32x4_to_bf16(v);
+  else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v;
+}
+template <bool S16>
+__device__ __forceinline__ const void* xf_at(const void* base, int64_t idx) {
+  return S16 ? (const void*)(reinterpret_cast<const __bf16*>(base) + idx)
+             : (const void*)(reinterpret_cast<const float*>(base) + idx);
+}
+template <bool S16>
+__device__ __forceinline__ void* xf_at(void* base, int64_t idx) {
+  return S16 ? (void*)(reinterpret_cast<__bf16*>(base) + idx) : (void*)(reinterpret_cast<float*>(base) + idx);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // LDS staging from fp32 global memory, converting to the policy's element type.
@@ -292,6 +345,34 @@ __device__ __forceinline__ void xf_store_tile_T(float* scratch, const f32x16& ac
     }
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// same, to bf16 storage (two 16-byte stores per lane)
+__device__ __forceinline__ void xf_store_tile_T(float* scratch, const f32x16& acc, float mul, __bf16* base,
+                                                int64_t stride, int row0, int row_end) {
+  const int lane = xf_lane();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scratch[(lane & 31) * 33 + xf_acc_row(r, lane)] = acc[r] * mul;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  const int j = lane >> 1, half = lane & 1;
+  if (row0 + j < row_end) {
+    __bf16* dst = base + (int64_t)(row0 + j) * stride + 16 * half;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)scratch[j * 33 + 16 * half + 8 * u + e];
+      *reinterpret_cast<bf16x8*>(dst + 8 * u) = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <bool S16>
+__device__ __forceinline__ void xf_store_tile_T_at(float* scratch, const f32x16& acc, float mul, void* base,
+                                                   int64_t off, int64_t stride, int row0, int row_end) {
+  if (S16) xf_store_tile_T(scratch, acc, mul, reinterpret_cast<__bf16*>(base) + off, stride, row0, row_end);
+  else xf_store_tile_T(scratch, acc, mul, reinterpret_cast<float*>(base) + off, stride, row0, row_end);
 }
 
 

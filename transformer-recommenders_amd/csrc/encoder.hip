@@ -3,14 +3,10 @@
 // Host code only (no kernels here): everything is enqueued on the caller's stream, nothing synchronises,
 // so one training step can be captured into a hipGraph.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
-#include "common.h"
-
-// defined in norm.hip (internal, not part of the public header)
-extern "C" int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                          float* dx, float* d_lin, float* d_gamma, float* d_beta, float* d_bias, int64_t rows,
-                          int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials, hipStream_t st);
+#include "internal.h"
 
 namespace {
 
@@ -53,12 +49,20 @@ LayerParams layer_params(const xfmr_encoder_cfg* c, int i) {
   return p;
 }
 
+// Activation storage: with the bf16 MFMA policy the tensors that are only ever MFMA operands are kept in HBM as
+// bf16 ("mixed" storage; bit-identical products, half the bytes): qkv, ctx, the GELU output g, and in backward the
+// gradients d_lin / d_ctx / dQKV / dI that feed the dX and dW GEMMs. The GELU pre-activation f1 is bf16 too (gelu'
+// is evaluated on the rounded value; covered by the bf16 tolerance of the parity tests). Everything that is added,
+// normalised or reduced elementwise (residual streams, LayerNorm inputs, statistics) stays fp32.
+// XFMR_ACT_FP32=1 keeps every activation fp32 (A/B measurements).
 struct LayerActs {
-  float *qkv, *lse, *ctx, *pre1, *mean1, *rstd1, *x1, *f1, *g, *pre2, *mean2, *rstd2, *x2;
+  void *qkv, *ctx, *f1, *g;                                           // bf16 when mixed
+  float *lse, *pre1, *mean1, *rstd1, *x1, *pre2, *mean2, *rstd2, *x2;  // always fp32
 };
 struct Acts {
   float *emb_pre, *emb_mean, *emb_rstd, *x0;
-  float *dA, *dB, *dI, *dQKV;
+  float *dA, *dB;
+  void *dLin, *dCtx, *dI, *dQKV;  // bf16 when mixed
   void* scratch;  // ln-bwd partials / dW slabs / colsum partials (used one at a time)
   size_t scratch_bytes;
   size_t total;
@@ -66,18 +70,30 @@ struct Acts {
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+bool mixed_storage(const xfmr_encoder_cfg* c) {
+  static const bool force_fp32 = [] {
+    const char* e = getenv("XFMR_ACT_FP32");
+    return e && *e && *e != '0';
+  }();
+  return c->precision == XFMR_PREC_BF16 && !force_fp32;
+}
+
 // Carves `base` (may be null: size query). Layer i's activations are returned in *la when i >= 0.
 Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs* la) {
   const size_t T = (size_t)c->batch * c->seq_len, H = c->hidden, I = c->inter, A = c->heads;
+  const size_t es = mixed_storage(c) ? 2 : 4;  // bytes per element of the MFMA-only tensors
   size_t o = 0;
-  auto take = [&](size_t nfloats) -> float* {
-    float* p = base ? reinterpret_cast<float*>(base + o) : nullptr;
-    o += up256(nfloats * sizeof(float));
+  auto take_bytes = [&](size_t bytes) -> void* {
+    void* p = base ? base + o : nullptr;
+    o += up256(bytes);
     return p;
   };
+  auto take = [&](size_t nfloats) -> float* { return reinterpret_cast<float*>(take_bytes(nfloats * sizeof(float))); };
   Acts a{};
   a.emb_pre = take(T * H); a.emb_mean = take(T); a.emb_rstd = take(T); a.x0 = take(T * H);
-  a.dA = take(T * H); a.dB = take(T * H); a.dI = take(T * I); a.dQKV = take(T * 3 * H);
+  a.dA = take(T * H); a.dB = take(T * H);
+  a.dLin = take_bytes(T * H * es); a.dCtx = take_bytes(T * H * es);
+  a.dI = take_bytes(T * I * es); a.dQKV = take_bytes(T * 3 * H * es);
   size_t sc = xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H);
   size_t s2 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)(3 * H), (int32_t)H);
   size_t s3 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)I, (int32_t)H);
@@ -92,9 +108,10 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   o += up256(sc);
   for (int i = 0; i < c->layers; ++i) {
     LayerActs l;
-    l.qkv = take(T * 3 * H); l.lse = take((size_t)c->batch * A * c->seq_len); l.ctx = take(T * H);
+    l.qkv = take_bytes(T * 3 * H * es); l.lse = take((size_t)c->batch * A * c->seq_len);
+    l.ctx = take_bytes(T * H * es);
     l.pre1 = take(T * H); l.mean1 = take(T); l.rstd1 = take(T); l.x1 = take(T * H);
-    l.f1 = take(T * I); l.g = take(T * I);
+    l.f1 = take_bytes(T * I * es); l.g = take_bytes(T * I * es);
     l.pre2 = take(T * H); l.mean2 = take(T); l.rstd2 = take(T); l.x2 = take(T * H);
     if (i == layer && la) *la = l;
   }
@@ -184,6 +201,8 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
   const int B = cfg->batch, L = cfg->seq_len, H = cfg->hidden, I = cfg->inter, A = cfg->heads;
   const int64_t T = (int64_t)B * L;
   const int prec = cfg->precision;
+  const bool mix = mixed_storage(cfg);
+  hipStream_t st = (hipStream_t)stream;
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
   XF_TRY(xfmr_embed_ln_fwd(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
@@ -195,18 +214,18 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     carve(cfg, base, i, &l);
     const LayerParams p = layer_params(cfg, i);
     float* out = (i == cfg->layers - 1) ? tok : l.x2;
-    XF_TRY(xfmr_linear_fwd(x, params + p.wqkv, params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
-                           0.f, 0, 0, prec, stream));
-    XF_TRY(xfmr_attn_fwd(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, cfg->seed, site_attn(i), prec,
-                         stream));
-    XF_TRY(xfmr_linear_fwd(l.ctx, params + p.wo, params + p.bo, l.pre1, T, H, H, XFMR_EPI_BIAS_DROP_RES, x, nullptr,
-                           cfg->hidden_dropout, cfg->seed, site_out(i), prec, stream));
+    XF_TRY(xf_linear_fwd_ex(x, params + p.wqkv, params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
+                            0.f, 0, 0, prec, mix ? XF_S16_C : 0, st));
+    XF_TRY(xf_attn_fwd_ex(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, cfg->seed, site_attn(i), prec,
+                          mix, st));
+    XF_TRY(xf_linear_fwd_ex(l.ctx, params + p.wo, params + p.bo, l.pre1, T, H, H, XFMR_EPI_BIAS_DROP_RES, x, nullptr,
+                            cfg->hidden_dropout, cfg->seed, site_out(i), prec, mix ? XF_S16_A : 0, st));
     XF_TRY(xfmr_layernorm_fwd(l.pre1, params + p.ln1g, params + p.ln1b, l.x1, l.mean1, l.rstd1, T, H, cfg->ln_eps,
                               stream));
-    XF_TRY(xfmr_linear_fwd(l.x1, params + p.w1, params + p.b1, l.g, T, I, H, XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f,
-                           0, 0, prec, stream));
-    XF_TRY(xfmr_linear_fwd(l.g, params + p.w2, params + p.b2, l.pre2, T, H, I, XFMR_EPI_BIAS_DROP_RES, l.x1, nullptr,
-                           cfg->hidden_dropout, cfg->seed, site_ffn(i), prec, stream));
+    XF_TRY(xf_linear_fwd_ex(l.x1, params + p.w1, params + p.b1, l.g, T, I, H, XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f,
+                            0, 0, prec, mix ? XF_S16_C : 0, st));
+    XF_TRY(xf_linear_fwd_ex(l.g, params + p.w2, params + p.b2, l.pre2, T, H, I, XFMR_EPI_BIAS_DROP_RES, l.x1, nullptr,
+                            cfg->hidden_dropout, cfg->seed, site_ffn(i), prec, mix ? XF_S16_A : 0, st));
     XF_TRY(xfmr_layernorm_fwd(l.pre2, params + p.ln2g, params + p.ln2b, out, l.mean2, l.rstd2, T, H, cfg->ln_eps,
                               stream));
     x = out;
@@ -227,6 +246,9 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   const int64_t T = (int64_t)B * L;
   const int prec = cfg->precision;
   const bool hdrop = cfg->hidden_dropout > 0.f;
+  const bool mix = mixed_storage(cfg);
+  const uint32_t sA = mix ? XF_S16_A : 0, sC = mix ? XF_S16_C : 0, sP = mix ? XF_S16_P : 0,
+                 sAB = mix ? (XF_S16_A | XF_S16_B) : 0;
   const XfDropout off = xf_make_dropout(0.f, 0, 0);
   float* dX = d_tok;  // gradient w.r.t. the current layer's output
   for (int i = cfg->layers - 1; i >= 0; --i) {
@@ -239,32 +261,33 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       carve(cfg, base, i - 1, &prev);
       x_in = prev.x2;
     }
-    // LayerNorm 2 -> dA = d(pre2); dlin = gradient of the FFN output Linear
-    XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, hdrop ? a.dB : nullptr,
+    // LayerNorm 2 -> dA = d(pre2); d_lin = gradient of the FFN output Linear (dropout-scaled copy of it)
+    const bool lin_copy = hdrop || mix;  // without dropout and with fp32 storage d_lin IS dx
+    XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, lin_copy ? a.dLin : nullptr, mix,
                                  grads + p.ln2g, grads + p.ln2b, grads + p.b2, T, H, off,
                                  xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_ffn(i)), a.scratch, st));
-    const float* dlin = hdrop ? a.dB : a.dA;
-    XF_TRY(xfmr_linear_bwd_dw(dlin, l.g, grads + p.w2, T, H, I, prec, a.scratch, a.scratch_bytes, stream));
-    XF_TRY(xfmr_linear_bwd_dx(dlin, params + p.w2, a.dI, T, H, I, nullptr, l.f1, prec, stream));
-    XF_TRY(xfmr_colsum(a.dI, grads + p.b1, T, I, a.scratch, stream));
-    XF_TRY(xfmr_linear_bwd_dw(a.dI, l.x1, grads + p.w1, T, I, H, prec, a.scratch, a.scratch_bytes, stream));
-    XF_TRY(xfmr_linear_bwd_dx(a.dI, params + p.w1, a.dA, T, I, H, a.dA, nullptr, prec, stream));  // += d(pre2)
+    const void* dlin = lin_copy ? a.dLin : (const void*)a.dA;
+    XF_TRY(xf_linear_bwd_dw_ex(dlin, l.g, grads + p.w2, T, H, I, prec, a.scratch, a.scratch_bytes, sAB, st));
+    XF_TRY(xf_linear_bwd_dx_ex(dlin, params + p.w2, a.dI, T, H, I, nullptr, l.f1, prec, sA | sC | sP, st));
+    XF_TRY(xf_colsum_ex(a.dI, mix, grads + p.b1, T, I, a.scratch, st));
+    XF_TRY(xf_linear_bwd_dw_ex(a.dI, l.x1, grads + p.w1, T, I, H, prec, a.scratch, a.scratch_bytes, sA, st));
+    XF_TRY(xf_linear_bwd_dx_ex(a.dI, params + p.w1, a.dA, T, I, H, a.dA, nullptr, prec, sA, st));  // += d(pre2)
     // LayerNorm 1 -> dX = d(pre1)
-    XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, hdrop ? a.dB : nullptr,
+    XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, lin_copy ? a.dLin : nullptr, mix,
                                  grads + p.ln1g, grads + p.ln1b, grads + p.bo, T, H, off,
                                  xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_out(i)), a.scratch, st));
-    dlin = hdrop ? a.dB : dX;
-    XF_TRY(xfmr_linear_bwd_dw(dlin, l.ctx, grads + p.wo, T, H, H, prec, a.scratch, a.scratch_bytes, stream));
-    XF_TRY(xfmr_linear_bwd_dx(dlin, params + p.wo, a.dA, T, H, H, nullptr, nullptr, prec, stream));  // d(ctx)
-    XF_TRY(xfmr_attn_bwd(l.qkv, key_mask, l.ctx, l.lse, a.dA, a.dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
-                         site_attn(i), prec, stream));
-    XF_TRY(xfmr_colsum(a.dQKV, grads + p.bqkv, T, 3 * H, a.scratch, stream));
-    XF_TRY(xfmr_linear_bwd_dw(a.dQKV, x_in, grads + p.wqkv, T, 3 * H, H, prec, a.scratch, a.scratch_bytes, stream));
-    XF_TRY(xfmr_linear_bwd_dx(a.dQKV, params + p.wqkv, dX, T, 3 * H, H, dX, nullptr, prec, stream));  // += d(pre1)
+    dlin = lin_copy ? a.dLin : (const void*)dX;
+    XF_TRY(xf_linear_bwd_dw_ex(dlin, l.ctx, grads + p.wo, T, H, H, prec, a.scratch, a.scratch_bytes, sAB, st));
+    XF_TRY(xf_linear_bwd_dx_ex(dlin, params + p.wo, a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC, st));  // d(ctx)
+    XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, a.dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
+                          site_attn(i), prec, mix, st));
+    XF_TRY(xf_colsum_ex(a.dQKV, mix, grads + p.bqkv, T, 3 * H, a.scratch, st));
+    XF_TRY(xf_linear_bwd_dw_ex(a.dQKV, x_in, grads + p.wqkv, T, 3 * H, H, prec, a.scratch, a.scratch_bytes, sA, st));
+    XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, params + p.wqkv, dX, T, 3 * H, H, dX, nullptr, prec, sA, st));  // += d(pre1)
   }
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
-  XF_TRY(xf_layernorm_bwd_impl(dX, a.emb_pre, a.emb_mean, a.emb_rstd, params + pl.eg, a.dA, nullptr, grads + pl.eg,
+  XF_TRY(xf_layernorm_bwd_impl(dX, a.emb_pre, a.emb_mean, a.emb_rstd, params + pl.eg, a.dA, nullptr, false, grads + pl.eg,
                                grads + pl.eb, nullptr, T, H,
                                xf_make_dropout(cfg->hidden_dropout, cfg->seed, SITE_EMB), off, a.scratch, st));
   XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));

@@ -10,21 +10,22 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "common.h"
+#include "internal.h"
 
 namespace {
 
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DROP_RES = 2, EPI_GELU_GRAD = 3, EPI_SPLITK = 4 };
 
 struct GemmArgs {
-  const float* A; const float* B; float* C;
+  const void* A; const void* B; void* C;  // fp32, or bf16 where the storage mask says so
   int64_t lda, ldb, ldc;
   int64_t M; int N; int K;
   int k_chunk;            // split-K: blockIdx.z handles [z*k_chunk, min(K,(z+1)*k_chunk)); 0 = whole K
   const float* bias;      // [N] or null
   const float* R;         // residual / residual-grad [M,ldc] or null
-  const float* P;         // pre-activation for gelu' [M,ldc]
-  float* C2;              // pre-activation output for EPI_GELU
+  const void* P;          // pre-activation for gelu' [M,ldc]
+  void* C2;               // pre-activation output for EPI_GELU
+  uint32_t s16;           // XF_S16_* storage mask (bf16 policy only)
   XfDropout drop;
 };
 
@@ -44,8 +45,32 @@ struct OperandTile {
   static constexpr int IMG_ELEMS = TRANS ? BK * LD : ROWS * LD;
   float4 reg[N4];
 
-  __device__ __forceinline__ void load(const float* src, int64_t ld, int64_t row0, int64_t rows_total, int k0,
+  // bf16 storage (dims are multiples of 4, so there are no partial quads): the raw 8 bytes ride in reg[i].x/.y
+  __device__ __forceinline__ void load16(const __bf16* src, int64_t ld, int64_t row0, int64_t rows_total, int k0,
+                                         int kend) {
+    const int tid = threadIdx.x;
+    constexpr int CH = TRANS ? ROWS / 4 : BK / 4;
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      const int c = tid + i * 256;
+      const int a = c / CH, b4 = (c % CH) * 4;
+      const int64_t gr = row0 + (TRANS ? b4 : a);
+      const int gk = k0 + (TRANS ? a : b4);
+      uint2 raw = make_uint2(0u, 0u);
+      if (gr < rows_total && gk < kend)
+        raw = *reinterpret_cast<const uint2*>(TRANS ? src + (int64_t)gk * ld + gr : src + gr * ld + gk);
+      reg[i].x = __uint_as_float(raw.x);
+      reg[i].y = __uint_as_float(raw.y);
+    }
+  }
+  template <bool S16>
+  __device__ __forceinline__ void load(const void* srcv, int64_t ld, int64_t row0, int64_t rows_total, int k0,
                                        int kend) {
+    if (S16) {
+      load16(reinterpret_cast<const __bf16*>(srcv), ld, row0, rows_total, k0, kend);
+      return;
+    }
+    const float* src = reinterpret_cast<const float*>(srcv);
     const int tid = threadIdx.x;
     if (!TRANS) {
       constexpr int CH = BK / 4;  // 16-byte chunks per row
@@ -81,13 +106,17 @@ struct OperandTile {
       }
     }
   }
+  template <bool S16>
   __device__ __forceinline__ void commit(elem* dst) const {
     const int tid = threadIdx.x;
     constexpr int CH = TRANS ? ROWS / 4 : BK / 4;
 #pragma unroll
     for (int i = 0; i < N4; ++i) {
       const int c = tid + i * 256;
-      xf_store4<P>(dst + (c / CH) * LD + (c % CH) * 4, reg[i]);
+      elem* d = dst + (c / CH) * LD + (c % CH) * 4;
+      if (S16)
+        *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(reg[i].x), __float_as_uint(reg[i].y));
+      else xf_store4<P>(d, reg[i]);
     }
   }
 };
@@ -144,15 +173,23 @@ __device__ __forceinline__ f32x16 xf_mma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI>
+// S = XF_S16_* storage mask (compile time: a runtime switch between the fp32 and bf16 load paths cost the
+// forward / dX GEMMs 15-80 %).
+template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using elem = typename P::elem;
   using TileA = OperandTile<P, BM, BK, TA>;
   using TileB = OperandTile<P, BN, BK, TB>;
   using FA = Frag<P, TA>;
   using FB = Frag<P, TB>;
-  __shared__ __attribute__((aligned(16))) elem sA[TileA::IMG_ELEMS];
-  __shared__ __attribute__((aligned(16))) elem sB[TileB::IMG_ELEMS];
+  constexpr bool a16 = S & XF_S16_A, b16 = S & XF_S16_B, c16 = S & XF_S16_C, p16 = S & XF_S16_P;
+  static_assert(S == 0 || sizeof(elem) == 2, "bf16 storage needs the bf16 policy");
+  constexpr int SCR_LD = 36;  // per-wave 32 x 32 fp32 transposition scratch (rows 16-byte aligned)
+  constexpr size_t OPER_BYTES = (size_t)(TileA::IMG_ELEMS + TileB::IMG_ELEMS) * sizeof(elem);
+  constexpr size_t SCR_BYTES = (size_t)4 * 32 * SCR_LD * sizeof(float);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES > SCR_BYTES ? OPER_BYTES : SCR_BYTES];
+  elem* const sA = reinterpret_cast<elem*>(smem);
+  elem* const sB = sA + TileA::IMG_ELEMS;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -177,33 +214,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   TileB tb;
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
-    ta.load(g.A, g.lda, m0, g.M, kbeg, kend);
-    tb.load(g.B, g.ldb, n0, g.N, kbeg, kend);
-  }
-  // epilogue operands (residual / pre-activation) are fetched up front so their latency hides under the K loop
-  float aux[MI][NI][16];
-  if (EPI == EPI_STORE || EPI == EPI_DROP_RES || EPI == EPI_GELU_GRAD) {
-    const float* src = (EPI == EPI_GELU_GRAD) ? g.P : g.R;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wc * WN + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = m0 + wr * WM + i * 32 + xf_acc_row(r, lane);
-          aux[i][j][r] = (src && n < g.N && m < g.M) ? src[m * g.ldc + n] : 0.f;
-        }
-      }
+    ta.template load<a16>(g.A, g.lda, m0, g.M, kbeg, kend);
+    tb.template load<b16>(g.B, g.ldb, n0, g.N, kbeg, kend);
   }
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
-    ta.commit(sA);
-    tb.commit(sB);
+    ta.template commit<a16>(sA);
+    tb.template commit<b16>(sB);
     __syncthreads();
     if (kt + 1 < nk) {  // next slice in flight while this one is multiplied
-      ta.load(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend);
-      tb.load(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend);
+      ta.template load<a16>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend);
+      tb.template load<b16>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend);
     }
 #pragma unroll
     for (int k0 = 0; k0 < BK; k0 += FA::KS) {
@@ -220,36 +241,66 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
 
-  // ---- epilogue --------------------------------------------------------------------------------
-  float* C = g.C;
-  if (EPI == EPI_SPLITK) C += (int64_t)blockIdx.z * g.M * g.ldc;
+  // ---- epilogue ----------------------------------------------------------------------------------------------
+  // Each 32 x 32 accumulator tile goes through a per-wave LDS transposition so that every global access of the
+  // epilogue (C, residual, pre-activation) is a 16-byte (8-byte for bf16) row-contiguous piece: one wave
+  // instruction covers 8 rows x 128 B instead of 2 rows x 32 scattered 4-byte (or 2-byte) elements.
+  __syncthreads();  // everyone is done with the operand images the scratch aliases
+  float* const scr = reinterpret_cast<float*>(smem) + wid * (32 * SCR_LD);
+  const int64_t zoff = (EPI == EPI_SPLITK) ? (int64_t)blockIdx.z * g.M * g.ldc : 0;
+  const int prow = lane >> 3, c4 = (lane & 7) * 4;
+  const float* aux_src = reinterpret_cast<const float*>((EPI == EPI_GELU_GRAD) ? g.P : (const void*)g.R);
+  constexpr bool aux16 = (EPI == EPI_GELU_GRAD) && p16;
+  constexpr bool has_aux = (EPI == EPI_STORE || EPI == EPI_DROP_RES || EPI == EPI_GELU_GRAD);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wc * WN + j * 32 + (lane & 31);
-      if (n >= g.N) continue;
-      const float bias = (EPI != EPI_SPLITK && EPI != EPI_GELU_GRAD && g.bias) ? g.bias[n] : 0.f;
+      const int n = n0 + wc * WN + j * 32 + c4;
+      const int64_t mb = m0 + wr * WM + i * 32;
+      const bool ncol = n < g.N;
+      // issue the epilogue operand loads first: their latency hides under the LDS round trip
+      float4 aux[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wr * WM + i * 32 + xf_acc_row(r, lane);
-        if (m >= g.M) continue;
-        const int64_t o = m * g.ldc + n;
-        float v = acc[i][j][r] + bias;
-        if (EPI == EPI_STORE) {
-          C[o] = v + aux[i][j][r];
-        } else if (EPI == EPI_GELU) {
-          g.C2[o] = v;
-          C[o] = xf_gelu(v);
-        } else if (EPI == EPI_DROP_RES) {
-          if (g.drop.on) v *= xf_keep_scale(g.drop, (uint32_t)(m * g.N + n));
-          C[o] = v + aux[i][j][r];
-        } else if (EPI == EPI_GELU_GRAD) {
-          C[o] = v * xf_gelu_grad(aux[i][j][r]);
-        } else {
-          C[o] = v;
-        }
+      for (int ps = 0; ps < 4; ++ps) {
+        aux[ps] = make_float4(0, 0, 0, 0);
+        const int64_t m = mb + prow + 8 * ps;
+        if (has_aux && aux_src && ncol && m < g.M) aux[ps] = xf_ld4<aux16>(aux_src, m * g.ldc + n);
       }
+      float4 bias = make_float4(0, 0, 0, 0);
+      if (EPI != EPI_SPLITK && EPI != EPI_GELU_GRAD && g.bias && ncol) bias = *reinterpret_cast<const float4*>(g.bias + n);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[xf_acc_row(r, lane) * SCR_LD + (lane & 31)] = acc[i][j][r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave re-reads its own writes
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = prow + 8 * ps;
+        const int64_t m = mb + row;
+        if (!ncol || m >= g.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        const int64_t o = m * g.ldc + n;
+        if (EPI == EPI_STORE) {
+          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
+        } else if (EPI == EPI_GELU) {
+          xf_st4<c16>(g.C2, o, v);
+          v.x = xf_gelu(v.x); v.y = xf_gelu(v.y); v.z = xf_gelu(v.z); v.w = xf_gelu(v.w);
+        } else if (EPI == EPI_DROP_RES) {
+          if (g.drop.on) {
+            const uint32_t e = (uint32_t)(m * g.N + n);
+            v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
+            v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
+          }
+          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
+        } else if (EPI == EPI_GELU_GRAD) {
+          v.x *= xf_gelu_grad(aux[ps].x); v.y *= xf_gelu_grad(aux[ps].y);
+          v.z *= xf_gelu_grad(aux[ps].z); v.w *= xf_gelu_grad(aux[ps].w);
+        }
+        xf_st4<(c16 && EPI != EPI_SPLITK)>(g.C, zoff + o, v);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();  // the next tile overwrites the scratch
     }
   }
 }
@@ -258,7 +309,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // of 64 columns with 4 row groups in flight (each wave instruction reads 256 contiguous bytes), combines the
 // groups through LDS in a fixed order and writes dst[y*cols + col]. Used for bias gradients (two levels) and
 // for the split-K slab reduction (rows = slabs, cols = elements of the weight).
-__global__ __launch_bounds__(256) void rowsum_kernel(float* dst, const float* src, int64_t rows, int64_t cols,
+template <class T>
+__global__ __launch_bounds__(256) void rowsum_kernel(float* dst, const T* src, int64_t rows, int64_t cols,
                                                      int64_t rows_per) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -269,22 +321,23 @@ __global__ __launch_bounds__(256) void rowsum_kernel(float* dst, const float* sr
   if (col < cols) {
     int64_t r = r0 + rg;
     for (; r + 12 < r1; r += 16) {
-      s0 += src[r * cols + col];
-      s1 += src[(r + 4) * cols + col];
-      s2 += src[(r + 8) * cols + col];
-      s3 += src[(r + 12) * cols + col];
+      s0 += (float)src[r * cols + col];
+      s1 += (float)src[(r + 4) * cols + col];
+      s2 += (float)src[(r + 8) * cols + col];
+      s3 += (float)src[(r + 12) * cols + col];
     }
-    for (; r < r1; r += 4) s0 += src[r * cols + col];
+    for (; r < r1; r += 4) s0 += (float)src[r * cols + col];
   }
   red[rg][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && col < cols) dst[(int64_t)blockIdx.y * cols + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
-int launch_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, int64_t rows_per, hipStream_t st) {
+template <class T>
+int launch_rowsum(float* dst, const T* src, int64_t rows, int64_t cols, int64_t rows_per, hipStream_t st) {
   const int64_t ny = (rows + rows_per - 1) / rows_per;
-  hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)ny), dim3(256), 0, st, dst, src, rows,
-                     cols, rows_per);
+  hipLaunchKernelGGL((rowsum_kernel<T>), dim3((unsigned)((cols + 63) / 64), (unsigned)ny), dim3(256), 0, st, dst, src,
+                     rows, cols, rows_per);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
@@ -300,7 +353,7 @@ static TileOverride tile_override() {
   return o;
 }
 
-template <class P, int BK, bool TA, bool TB, int EPI>
+template <class P, int BK, bool TA, bool TB, int EPI, uint32_t S>
 int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   // These GEMMs are skinny (K <= 1024) and latency-bound, not MFMA-bound. Measured on MI355X at T = 25 600
   // (scripts/bench_gemm.py): many small workgroups win -- 64x64 tiles with 32-deep slices for the forward /
@@ -311,33 +364,34 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   if (ov.bm) { bm = ov.bm; bn = ov.bn; }
   dim3 block(256);
   dim3 grid((unsigned)((g.N + bn - 1) / bn), (unsigned)((g.M + bm - 1) / bm), splits);
-  if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
-  else if (bm == 64) hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI>), grid, block, 0, st, g);
+  if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI, S>), grid, block, 0, st, g);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI, S>), grid, block, 0, st, g);
+  else if (bm == 64) hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI, S>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI, S>), grid, block, 0, st, g);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
 
-template <class P, bool TA, bool TB, int EPI>
+template <class P, bool TA, bool TB, int EPI, uint32_t S>
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   // deep (128) K slices only pay for the split-K dW GEMMs (see launch_gemm_bk); bf16 only.
   const int kspan = g.k_chunk > 0 ? g.k_chunk : g.K;
   const TileOverride ov = tile_override();
   if constexpr (P::kId == XFMR_PREC_BF16 && EPI == EPI_SPLITK) {
-    if (kspan % 128 == 0 && ov.bk != 32) return launch_gemm_bk<P, 128, TA, TB, EPI>(g, splits, st);
+    if (kspan % 128 == 0 && ov.bk != 32) return launch_gemm_bk<P, 128, TA, TB, EPI, S>(g, splits, st);
   }
-  if constexpr (P::kId == XFMR_PREC_BF16 && EPI != EPI_SPLITK) {
-    if (kspan % 128 == 0 && ov.bk == 128) return launch_gemm_bk<P, 128, TA, TB, EPI>(g, splits, st);
-  }
-  return launch_gemm_bk<P, 32, TA, TB, EPI>(g, splits, st);
+  return launch_gemm_bk<P, 32, TA, TB, EPI, S>(g, splits, st);
 }
 
-template <bool TA, bool TB, int EPI>
+// S16 lists the storage masks this (TA, TB, EPI) combination is ever launched with besides 0 (all fp32).
+template <bool TA, bool TB, int EPI, uint32_t... S16>
 int dispatch_gemm(const GemmArgs& g, int splits, int precision, hipStream_t st) {
-  if (precision == XFMR_PREC_BF16) return launch_gemm<PrecBF16, TA, TB, EPI>(g, splits, st);
-  if (precision == XFMR_PREC_F32) return launch_gemm<PrecF32, TA, TB, EPI>(g, splits, st);
-  return XFMR_EINVAL;
+  if (precision == XFMR_PREC_F32) return g.s16 ? XFMR_EINVAL : launch_gemm<PrecF32, TA, TB, EPI, 0>(g, splits, st);
+  if (precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if (g.s16 == 0) return launch_gemm<PrecBF16, TA, TB, EPI, 0>(g, splits, st);
+  int rc = XFMR_EINVAL;
+  (void)((g.s16 == S16 ? (rc = launch_gemm<PrecBF16, TA, TB, EPI, S16>(g, splits, st), true) : false) || ...);
+  return rc;
 }
 
 int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
@@ -362,45 +416,60 @@ int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStrea
   return launch_rowsum(dst, src, rows, cols, rows, st);
 }
 
-int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
-                    int32_t epilogue, const float* residual, float* aux_out, float dropout_p, uint64_t seed,
-                    uint32_t site, int32_t precision, void* stream) {
+int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, int64_t M, int32_t N, int32_t K,
+                     int32_t epilogue, const float* residual, void* aux_out, float dropout_p, uint64_t seed,
+                     uint32_t site, int32_t precision, uint32_t s16, hipStream_t st) {
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(x) || !xf_aligned16(w) || !xf_aligned16(y)) return XFMR_EALIGN;
+  if (s16 && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   GemmArgs g{};
   g.A = x; g.B = w; g.C = y; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K; g.k_chunk = 0;
-  g.bias = bias; g.R = residual; g.C2 = aux_out; g.P = nullptr;
+  g.bias = bias; g.R = residual; g.C2 = aux_out; g.P = nullptr; g.s16 = s16 & (XF_S16_A | XF_S16_C);
   g.drop = xf_make_dropout(dropout_p, seed, site);
-  hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
     case XFMR_EPI_BIAS:
       g.R = nullptr;
-      return dispatch_gemm<false, false, EPI_STORE>(g, 1, precision, st);
+      return dispatch_gemm<false, false, EPI_STORE, XF_S16_C>(g, 1, precision, st);
     case XFMR_EPI_BIAS_GELU:
       if (!aux_out) return XFMR_EINVAL;
-      return dispatch_gemm<false, false, EPI_GELU>(g, 1, precision, st);
+      return dispatch_gemm<false, false, EPI_GELU, XF_S16_C>(g, 1, precision, st);
     case XFMR_EPI_BIAS_DROP_RES:
       if (!residual) return XFMR_EINVAL;
-      return dispatch_gemm<false, false, EPI_DROP_RES>(g, 1, precision, st);
+      return dispatch_gemm<false, false, EPI_DROP_RES, XF_S16_A>(g, 1, precision, st);
     default:
       return XFMR_EINVAL;
   }
 }
 
-int xfmr_linear_bwd_dx(const float* dy, const float* w, float* dx, int64_t M, int32_t N, int32_t K,
-                       const float* residual_grad, const float* gelu_pre, int32_t precision, void* stream) {
+int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
+                    int32_t epilogue, const float* residual, float* aux_out, float dropout_p, uint64_t seed,
+                    uint32_t site, int32_t precision, void* stream) {
+  return xf_linear_fwd_ex(x, w, bias, y, M, N, K, epilogue, residual, aux_out, dropout_p, seed, site, precision, 0,
+                          (hipStream_t)stream);
+}
+
+int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int32_t N, int32_t K,
+                        const float* residual_grad, const void* gelu_pre, int32_t precision, uint32_t s16,
+                        hipStream_t st) {
   if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(w) || !xf_aligned16(dx)) return XFMR_EALIGN;
+  if (s16 && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   // dx[M,K] = dy[M,N] * w[N,K]: contraction over N; B' [K rows][N] = w^T -> w is stored [N][K] = K-major
   GemmArgs g{};
   g.A = dy; g.B = w; g.C = dx; g.lda = N; g.ldb = K; g.ldc = K; g.M = M; g.N = K; g.K = N; g.k_chunk = 0;
   g.bias = nullptr; g.R = residual_grad; g.P = gelu_pre; g.C2 = nullptr;
+  g.s16 = s16 & (XF_S16_A | XF_S16_C | XF_S16_P);
   g.drop = xf_make_dropout(0.f, 0, 0);
-  hipStream_t st = (hipStream_t)stream;
-  if (gelu_pre) return dispatch_gemm<false, true, EPI_GELU_GRAD>(g, 1, precision, st);
-  return dispatch_gemm<false, true, EPI_STORE>(g, 1, precision, st);
+  if (gelu_pre)
+    return dispatch_gemm<false, true, EPI_GELU_GRAD, (XF_S16_A | XF_S16_C | XF_S16_P)>(g, 1, precision, st);
+  return dispatch_gemm<false, true, EPI_STORE, XF_S16_A, (XF_S16_A | XF_S16_C)>(g, 1, precision, st);
+}
+
+int xfmr_linear_bwd_dx(const float* dy, const float* w, float* dx, int64_t M, int32_t N, int32_t K,
+                       const float* residual_grad, const float* gelu_pre, int32_t precision, void* stream) {
+  return xf_linear_bwd_dx_ex(dy, w, dx, M, N, K, residual_grad, gelu_pre, precision, 0, (hipStream_t)stream);
 }
 
 size_t xfmr_linear_bwd_dw_workspace(int64_t M, int32_t N, int32_t K) {
@@ -409,25 +478,30 @@ size_t xfmr_linear_bwd_dw_workspace(int64_t M, int32_t N, int32_t K) {
   return (size_t)splits * (size_t)N * (size_t)K * sizeof(float);
 }
 
-int xfmr_linear_bwd_dw(const float* dy, const float* x, float* dw, int64_t M, int32_t N, int32_t K,
-                       int32_t precision, void* workspace, size_t workspace_bytes, void* stream) {
+int xf_linear_bwd_dw_ex(const void* dy, const void* x, float* dw, int64_t M, int32_t N, int32_t K, int32_t precision,
+                        void* workspace, size_t workspace_bytes, uint32_t s16, hipStream_t st) {
   if (!dy || !x || !dw || !workspace || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(workspace)) return XFMR_EALIGN;
   if (workspace_bytes < xfmr_linear_bwd_dw_workspace(M, N, K)) return XFMR_EWORKSPACE;
+  if (s16 && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   // dw[N,K] = dy^T[N,M] * x[M,K]: contraction over M. A' = dy^T (dy stored [M][N]), B'[K rows][M] = x^T.
   int k_chunk;
   int splits = dw_split_plan(M, N, K, &k_chunk);
   GemmArgs g{};
-  g.A = dy; g.B = x; g.C = (float*)workspace; g.lda = N; g.ldb = K; g.ldc = K;
+  g.A = dy; g.B = x; g.C = workspace; g.lda = N; g.ldb = K; g.ldc = K;
   g.M = N; g.N = K; g.K = (int)M; g.k_chunk = k_chunk;
-  g.bias = nullptr; g.R = nullptr; g.P = nullptr; g.C2 = nullptr;
+  g.bias = nullptr; g.R = nullptr; g.P = nullptr; g.C2 = nullptr; g.s16 = s16 & (XF_S16_A | XF_S16_B);
   g.drop = xf_make_dropout(0.f, 0, 0);
-  hipStream_t st = (hipStream_t)stream;
-  int rc = dispatch_gemm<true, true, EPI_SPLITK>(g, splits, precision, st);
+  int rc = dispatch_gemm<true, true, EPI_SPLITK, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, splits, precision, st);
   if (rc) return rc;
   const int64_t n = (int64_t)N * K;
   return launch_rowsum(dw, (const float*)workspace, splits, n, splits, st);
+}
+
+int xfmr_linear_bwd_dw(const float* dy, const float* x, float* dw, int64_t M, int32_t N, int32_t K,
+                       int32_t precision, void* workspace, size_t workspace_bytes, void* stream) {
+  return xf_linear_bwd_dw_ex(dy, x, dw, M, N, K, precision, workspace, workspace_bytes, 0, (hipStream_t)stream);
 }
 
 static int colsum_plan(int64_t M, int* rows_per) {
@@ -443,13 +517,17 @@ size_t xfmr_colsum_workspace(int64_t M, int32_t N) {
   int rows_per;
   return (size_t)colsum_plan(M, &rows_per) * (size_t)N * sizeof(float);
 }
-int xfmr_colsum(const float* a, float* out, int64_t M, int32_t N, void* workspace, void* stream) {
+int xf_colsum_ex(const void* a, bool a16, float* out, int64_t M, int32_t N, void* workspace, hipStream_t st) {
   if (!a || !out || !workspace || M <= 0 || N <= 0) return XFMR_EINVAL;
   int rows_per;
   const int blocks = colsum_plan(M, &rows_per);
-  hipStream_t st = (hipStream_t)stream;
-  if (int rc = launch_rowsum((float*)workspace, a, M, N, rows_per, st)) return rc;
+  int rc = a16 ? launch_rowsum((float*)workspace, (const __bf16*)a, M, N, rows_per, st)
+               : launch_rowsum((float*)workspace, (const float*)a, M, N, rows_per, st);
+  if (rc) return rc;
   return launch_rowsum(out, (const float*)workspace, blocks, N, blocks, st);
+}
+int xfmr_colsum(const float* a, float* out, int64_t M, int32_t N, void* workspace, void* stream) {
+  return xf_colsum_ex(a, false, out, M, N, workspace, (hipStream_t)stream);
 }
 
 }  // extern "C"

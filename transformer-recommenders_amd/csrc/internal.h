@@ -1,0 +1,37 @@
+// Entry points shared between the translation units of libxfmr_hip.so but NOT part of the public C ABI
+// (include/xfmr_hip.h): the same operators with type-erased activation pointers and a storage mask, used by the
+// whole-encoder launch sequences to keep MFMA-only intermediates in HBM as bf16 (see common.h "Activation
+// storage"). The public functions are these with mask 0.
+#pragma once
+#include "common.h"
+
+enum : uint32_t {
+  XF_S16_A = 1u,    // GEMM operand A (activations / incoming gradient)
+  XF_S16_B = 2u,    // GEMM operand B when it is an activation (dW)
+  XF_S16_C = 4u,    // GEMM output (and the pre-activation side output of the GELU epilogue)
+  XF_S16_P = 8u,    // pre-activation input of the gelu' epilogue
+};
+
+extern "C" {
+int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, int64_t M, int32_t N, int32_t K,
+                     int32_t epilogue, const float* residual, void* aux_out, float dropout_p, uint64_t seed,
+                     uint32_t site, int32_t precision, uint32_t s16, hipStream_t st);
+int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int32_t N, int32_t K,
+                        const float* residual_grad, const void* gelu_pre, int32_t precision, uint32_t s16,
+                        hipStream_t st);
+int xf_linear_bwd_dw_ex(const void* dy, const void* x, float* dw, int64_t M, int32_t N, int32_t K, int32_t precision,
+                        void* workspace, size_t workspace_bytes, uint32_t s16, hipStream_t st);
+int xf_colsum_ex(const void* a, bool a16, float* out, int64_t M, int32_t N, void* workspace, hipStream_t st);
+int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st);
+int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t A,
+                   int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision, bool s16,
+                   hipStream_t st);
+int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* d_ctx,
+                   void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, uint64_t seed,
+                   uint32_t site, int32_t precision, bool s16, hipStream_t st);
+// d_lin (optional): the gradient of the Linear output feeding this LayerNorm (dropout-scaled dx), bf16 if lin16
+int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          float* dx, void* d_lin, bool lin16, float* d_gamma, float* d_beta, float* d_bias,
+                          int64_t rows, int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials,
+                          hipStream_t st);
+}

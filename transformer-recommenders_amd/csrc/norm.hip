@@ -2,10 +2,9 @@
 // embedding-parameter gradients, masked mean pooling, AdamW, per-item inverse norms.
 // One wavefront owns one row (H <= 1024): lanes stride the row in 4-byte steps, so every wave
 // instruction touches 256 contiguous bytes; row statistics are wave reductions, never LDS.
-#include "common.h"
+#include "internal.h"
 
 // single-level deterministic column sum dst[c] = sum_r src[r*cols + c] (gemm.hip)
-extern "C" int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st);
 
 namespace {
 
@@ -89,8 +88,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
 // dy is the gradient of the (possibly dropped-out, embedding site only) LayerNorm output.
 struct LnBwdArgs {
   const float* dy; const float* x; const float* mean; const float* rstd; const float* gamma;
-  float* dx; float* d_lin; float* partials;  // partials [blocks][3][H]
-  int64_t rows; int H; int rows_per_block;
+  float* dx; void* d_lin; float* partials;  // partials [blocks][3][H]; d_lin optional, bf16 if lin16
+  int64_t rows; int H; int rows_per_block; int lin16;
   XfDropout drop_out;  // dropout that was applied to y itself (embedding site); off otherwise
   XfDropout drop_lin;  // dropout of the Linear output feeding this LayerNorm's input
 };
@@ -138,9 +137,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         const float d = rstd * (g[i] - mg - xh[i] * mgx);
         a.dx[row * H + c] = d;
         float dl = d;
-        if (a.drop_lin.on) {
-          dl = d * xf_keep_scale(a.drop_lin, (uint32_t)(row * H + c));
-          a.d_lin[row * H + c] = dl;
+        if (a.drop_lin.on) dl = d * xf_keep_scale(a.drop_lin, (uint32_t)(row * H + c));
+        if (a.d_lin) {
+          if (a.lin16) reinterpret_cast<__bf16*>(a.d_lin)[row * H + c] = (__bf16)dl;
+          else reinterpret_cast<float*>(a.d_lin)[row * H + c] = dl;
         }
         dbias[i] += dl;
       }
@@ -261,7 +261,10 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(LnBwdArgs a) {
         const uint32_t e = (uint32_t)(row * H + c);
         dl.x *= xf_keep_scale(a.drop_lin, e); dl.y *= xf_keep_scale(a.drop_lin, e + 1);
         dl.z *= xf_keep_scale(a.drop_lin, e + 2); dl.w *= xf_keep_scale(a.drop_lin, e + 3);
-        *reinterpret_cast<float4*>(a.d_lin + row * H + c) = dl;
+      }
+      if (a.d_lin) {
+        if (a.lin16) xf_st4<true>(a.d_lin, row * H + c, dl);
+        else xf_st4<false>(a.d_lin, row * H + c, dl);
       }
       dbias.x += dl.x; dbias.y += dl.y; dbias.z += dl.z; dbias.w += dl.w;
     }
@@ -474,13 +477,14 @@ size_t xfmr_layernorm_bwd_workspace(int64_t rows, int32_t H) {
 
 // Internal variant that also takes the dropout applied to the LayerNorm OUTPUT (embedding site).
 int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                          float* dx, float* d_lin, float* d_gamma, float* d_beta, float* d_bias, int64_t rows,
-                          int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials, hipStream_t st) {
+                          float* dx, void* d_lin, bool lin16, float* d_gamma, float* d_beta, float* d_bias,
+                          int64_t rows, int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials,
+                          hipStream_t st) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !partials || rows <= 0 || H <= 0) return XFMR_EINVAL;
   if (drop_lin.on && !d_lin) return XFMR_EINVAL;
   LnBwdArgs a{};
   a.dy = dy; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.dx = dx; a.d_lin = d_lin;
-  a.partials = (float*)partials; a.rows = rows; a.H = H;
+  a.partials = (float*)partials; a.rows = rows; a.H = H; a.lin16 = lin16 ? 1 : 0;
   const int blocks = ln_bwd_blocks(rows, &a.rows_per_block);
   a.drop_out = drop_out; a.drop_lin = drop_lin;
   const size_t shmem = (size_t)12 * H * sizeof(float);
@@ -505,8 +509,9 @@ int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, co
 int xfmr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* d_lin, float* d_gamma, float* d_beta, float* d_bias, int64_t rows,
                        int32_t H, float dropout_p, uint64_t seed, uint32_t site, void* partials, void* stream) {
-  return xf_layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, d_lin, d_gamma, d_beta, d_bias, rows, H,
-                               xf_make_dropout(0.f, 0, 0), xf_make_dropout(dropout_p, seed, site), partials,
+  // public contract: d_lin is written only when dropout is on (otherwise it equals dx)
+  return xf_layernorm_bwd_impl(dy, x, mean, rstd, gamma, dx, dropout_p > 0.f ? d_lin : nullptr, false, d_gamma, d_beta,
+                               d_bias, rows, H, xf_make_dropout(0.f, 0, 0), xf_make_dropout(dropout_p, seed, site), partials,
                                (hipStream_t)stream);
 }
 
