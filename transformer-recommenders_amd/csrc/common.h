@@ -143,6 +143,24 @@ struct RegRows<PrecBF16, K> {
       v[s][4] = (__bf16)b.x; v[s][5] = (__bf16)b.y; v[s][6] = (__bf16)b.z; v[s][7] = (__bf16)b.w;
     }
   }
+  // `row` must be dereferenceable even when !valid (the result is then zero): every load is issued up front,
+  // without the per-piece branches (and the chain of exposed load latencies) of load()
+  __device__ __forceinline__ void load_safe(const float* row, bool valid) {
+    const int h = xf_lane() >> 5;
+    float4 a[K / 16], b[K / 16];
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      a[s] = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h);
+      b[s] = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h + 4);
+    }
+    const float z = valid ? 1.f : 0.f;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      v[s][0] = (__bf16)(a[s].x * z); v[s][1] = (__bf16)(a[s].y * z); v[s][2] = (__bf16)(a[s].z * z);
+      v[s][3] = (__bf16)(a[s].w * z); v[s][4] = (__bf16)(b[s].x * z); v[s][5] = (__bf16)(b[s].y * z);
+      v[s][6] = (__bf16)(b[s].z * z); v[s][7] = (__bf16)(b[s].w * z);
+    }
+  }
   __device__ __forceinline__ void load(const __bf16* row, bool valid) {  // bf16 storage: no conversion
     const int h = xf_lane() >> 5;
 #pragma unroll
@@ -456,4 +474,17 @@ struct SwzImg {
 __device__ __forceinline__ void xf_glds16(const void* gsrc, void* lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+// The same instruction issued from an asm statement, i.e. outside hipcc's s_waitcnt bookkeeping: while a
+// builtin-issued LDS-DMA is in flight hipcc puts s_waitcnt vmcnt(0) in front of LDS reads it cannot prove disjoint
+// from the DMA target (here: every read of per-negative side data, twice per 32 x 32 sub-block), which drains the
+// prefetch. The caller owns the ordering: s_waitcnt vmcnt(N) + barrier before anyone reads the destination.
+// M0 (the LDS destination base) is compiler-reserved: it is saved, set and restored inside the one statement.
+__device__ __forceinline__ void xf_glds16_raw(const void* gsrc, void* lds_base) {
+  const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_base;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
 }

@@ -14,6 +14,8 @@ constexpr float kLn2 = 0.6931471805599453f;
 enum { R_CNTD = 0, R_M, R_L, R_NCE, R_HINGE, R_LOGI, R_CNTC, R_CONTR, R_SSUM, R_SSQ, R_SMIN, R_SMAX, R_SW,
        R_POSDOT, R_RQ, R_QQ };
 constexpr int BP = 24;        // doubles per block-partial record
+// kernel-template head code of the InfoNCE gradient pass with false-negative masking (the lean epilogue below)
+constexpr int HEAD_INFONCE_MASKED = XFMR_NUM_LOSSES;
 
 struct LossArgs {
   const float* tok; const float* table; const float* rnorm; int64_t n_rows;
@@ -147,6 +149,31 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
     // keep the scheduler from interleaving the four runs (it otherwise holds all 16 elements' temporaries
     // live at once and spills at 2 waves/SIMD)
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The common case of the gradient pass, stripped to what it needs: InfoNCE head, false-negative masking on, every
+// column of the sub-block a real negative. With masking the running maximum is pinned at the positive's logit
+// (m = scale * pos), a counted logit is one with s < pos (an exact tie by item id is not), the gradient weight IS the
+// softmax term (sum of weights == l) and the count is an integer add-with-carry: ~8 issue slots per element
+// instead of ~23 (VALU issue, not the matrix pipe, bounds this kernel).
+template <bool CHECK_VALID>
+__device__ __forceinline__ void loss_epilogue_infonce_masked(f32x16& s, float& l, int& cnt, float pos_dot, float sc2,
+                                                             float m, int pos_item, const int* nid_sb, int hh) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[8 * g + 4 * hh]);
+    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * g + u;
+      bool counted = (s[r] < pos_dot) & (nn[u] != pos_item);
+      if (CHECK_VALID) counted &= nn[u] >= 0;  // only the last tile of the range can hold past-the-end columns
+      cnt += counted ? 1 : 0;
+      const float e = xf_exp2(counted ? fmaf(s[r], sc2, -m) : -INFINITY);
+      l += e;
+      s[r] = e;
+    }
   }
 }
 

@@ -13,7 +13,9 @@ int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, 
     case XFMR_LOSS_CONTRASTIVE:
       hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_INFONCE:
-      hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_INFONCE>), grid, block, 0, st, a, tbf); break;
+      if (a.mask_fn) hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_INFONCE_MASKED>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_INFONCE>), grid, block, 0, st, a, tbf);
+      break;
     case XFMR_LOSS_NCE:
       hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_NCE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_PAIRWISE_HINGE:

@@ -8,12 +8,14 @@ computes with PyTorch instead.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 
 import torch
 
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libxfmr_hip.so"
+# XFMR_HIP_LIB points at another build of the same library (kernel experiments); the default is the in-tree one
+LIB_PATH = pathlib.Path(os.environ["XFMR_HIP_LIB"]) if os.environ.get("XFMR_HIP_LIB") else _HERE / "libxfmr_hip.so"
 
 PREC_F32, PREC_BF16 = 0, 1
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
