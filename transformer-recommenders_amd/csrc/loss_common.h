@@ -87,6 +87,7 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
   }
   // Every head's row reductions and the train head's gradient weight (left in s[r] for the second MFMA).
   // Branch-free per element; the `head` switches are wave-uniform.
+  float pn = 1.f, pl = 1.f;  // products of (1 + exp(-|x|)) of the counted elements: NCE and pairwise-logistic
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl0 = 8 * g + 4 * hh;
@@ -115,7 +116,10 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
       }
       if (ALL || head == XFMR_LOSS_NCE) {
         const float t = xf_exp2(-fabsf(sv) * kLog2e);                    // exp(-|x|)
-        nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // softplus(x)
+        // softplus(x) = max(x, 0) + log(1 + exp(-|x|)); the log terms of the sub-block's 16 elements are taken as
+        // ONE log of their product (each factor is in [1, 2]): 2 transcendental issues per 16 elements, not 32
+        nce = fmaf(fmaxf(sv, 0.f), md, nce);
+        pn *= fmaf(t, md, 1.f);
         if (head == XFMR_LOSS_NCE) w = md * xf_rcp(1.f + t) * (sv >= 0.f ? 1.f : t);  // sigmoid(x)
       }
       if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
@@ -124,7 +128,8 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
         if (head == XFMR_LOSS_PAIRWISE_HINGE) w = d > 0.f ? md : 0.f;
         if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
           const float t = xf_exp2(-fabsf(d) * kLog2e);
-          logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
+          logi = fmaf(fmaxf(d, 0.f), md, logi);
+          pl *= fmaf(t, md, 1.f);
           if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md * xf_rcp(1.f + t) * (d >= 0.f ? 1.f : t);
         }
       }
@@ -150,6 +155,8 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
     // live at once and spills at 2 waves/SIMD)
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (ALL || head == XFMR_LOSS_NCE) nce = fmaf(kLn2, xf_log2(pn), nce);
+  if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) logi = fmaf(kLn2, xf_log2(pl), logi);
 }
 
 // The common case of the gradient pass, stripped to what it needs: InfoNCE head, false-negative masking on, every
