@@ -13,8 +13,8 @@ encoder backward -> flat-gradient all-reduce (N > 1) -> AdamW, dropout 0.1 ON, o
 sequences already resident in HBM (the batch is 3 x B x 200 int64 = 0.6 MB at B=128; the PCIe-inclusive rate
 is noted in DESIGN.md). Rank 0 prints ONE JSON line; see the task contract for the fields. Extra objects:
 
-  roofline     dominant kernel = loss_main_kernel (the negative-scoring logit GEMM with its fused epilogue and
-               the dQ GEMM): algorithmic flops per launch = 4 * Np * N * H / average
+  roofline     dominant kernel = loss_main_dma_kernel, gradient pass (the negative-scoring logit GEMM with its fused
+               epilogue and the dQ GEMM): algorithmic flops per launch = 4 * Np * N * H / average
                launch duration measured with HIP events recorded on the launch stream around that kernel
                inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
   cpu_baseline the CPU oracle (oracle/, a restatement of the reference: 'port') timed on this host's cores
@@ -256,7 +256,7 @@ def main():
                 "final_loss": round(float(loss.detach()), 4),
             },
             "roofline": {
-                "kernel": "loss_main_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "kernel": "loss_main_dma_kernel (gradient pass of the fused sampled loss)", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
                 "avg_launch_ms": round(kern_avg, 4), "algorithmic_flops_per_launch": flops,
                 "launches_timed": len(kern_ms),

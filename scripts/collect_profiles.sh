@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the judged measurement artefacts of one round on the GPU box (run through gpurun):
+#   scripts/collect_profiles.sh <tag>            e.g. r01
+# writes under gpurun_out/<tag>/: bench.json (the bench line incl. cpu_baseline), kernel-trace stats of the same
+# bench command, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) over scripts/bench_loss.py for the HBM
+# traffic of the dominant kernel. Copy the summaries into profiles/ with scripts/summarize_profiles.py.
+set -eo pipefail
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+timeout -k 10 420 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- \
+  python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-overlap > "$OUT/trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_overlap" -o bench -- \
+  python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/trace_overlap.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o loss -- \
+    python3 "$ROOT/scripts/bench_loss.py" --reps 4 > "$OUT/pmc_$c.log" 2>&1
+done
+echo done > "$OUT/DONE"
