@@ -211,7 +211,8 @@ int xfmr_mean_pool(const float* tok, const uint8_t* key_mask, float* out, int32_
  *                    neg_idx is ignored; the positive's own column is not a negative.
  * Ties: a negative that is the row's positive item has, in the reference, a logit bit-identical to the
  * positive's (same vectors through the same bmm) -- the kernel reproduces that by item id.
- * num_hard_negatives (losses.py:295-330) is not fused: pass 0.
+ * num_hard_negatives (losses.py:295-330): see xfmr_loss_cfg; supported by xfmr_dense_loss, the fused entry
+ * points return XFMR_EUNSUPPORTED for a non-zero value.
  *
  * Outputs (all device memory):
  *   losses[14]       [0..6] summed loss per head (accumulated in fp64), order XFMR_LOSS_*;
@@ -239,7 +240,7 @@ typedef struct xfmr_loss_cfg {
   int32_t precision;            /* XFMR_PREC_*                                                      */
   float scale;                  /* LossConfig.scale  (losses.py:29)                                 */
   float margin;                 /* LossConfig.margin (losses.py:30)                                 */
-  int32_t reserved;
+  int32_t num_hard_negatives;   /* LossConfig.num_hard_negatives (losses.py:28, :295-330); 0 = off    */
 } xfmr_loss_cfg;
 size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows);
 int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
@@ -256,6 +257,19 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
                             const int64_t* neg_items, int64_t n_query, int64_t n_neg, const float* table,
                             const float* table_rnorm, const void* table_bf16, int64_t n_rows, int32_t H,
                             float* losses, float* stats, float* d_query, void* workspace, size_t workspace_bytes, void* stream);
+/* Dense-candidate form: EmbedLoss.forward(query_embed (N,H), candidate_embed (N,C,H), target) exactly as the
+ * reference declares it (xfmr_rec/losses.py:128-155), for candidate tensors that exist in memory (C <= 8192,
+ * H <= 256, H % 4 == 0): dot / cosine logits (:179-208), target from target_position "first" / "diagonal" or an
+ * explicit `target` (N) of column indices (:211-261), false-negative mask (:263-293), top-k hard negatives
+ * (:295-330, ties at the k-th logit share the remaining weight), the seven heads + LogitsStatistics, and
+ * d_query (N,H) = dL(train_head)/dquery (may be NULL). Candidates are treated as constants (the reference's
+ * candidates are rows of the frozen table). cfg->mode and cfg->precision are ignored (fp32 vector arithmetic).
+ * losses[14] / stats[16] as for xfmr_sampled_loss, with N_VALID = C and N_QUERY = N. */
+enum { XFMR_TARGET_FIRST = 0, XFMR_TARGET_DIAGONAL = 1, XFMR_TARGET_EXPLICIT = 2 };
+size_t xfmr_dense_loss_workspace(int64_t N, int32_t C, int32_t H);
+int xfmr_dense_loss(const xfmr_loss_cfg* cfg, const float* query, const float* cand, const int64_t* target,
+                    int32_t target_mode, int64_t N, int32_t C, int32_t H, float* losses, float* stats, float* d_query,
+                    void* workspace, size_t workspace_bytes, void* stream);
 /* Measurement hook (bench.py): the next xfmr_sampled_loss[_lists] call made by THIS host thread records the two
  * hipEvent_t (passed as void*) on its stream immediately before and after the dominant kernel
  * (loss_main_kernel), then forgets them. Pass NULL, NULL to cancel. Has no effect on results. */

@@ -29,6 +29,10 @@ int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* l
 int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* d_ctx,
                    void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, uint64_t seed,
                    uint32_t site, int32_t precision, bool s16, hipStream_t st);
+// loss.hip: deterministic totals of per-block fp64 records [24][nblocks] (each block = rows_per_block queries) ->
+// losses[14], stats[16]; counts = device {n_valid, n_query}; tot = 24 doubles of scratch
+int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, const int* counts, int mode,
+                     int64_t n_rows, float* losses, float* stats, double* tot, hipStream_t st);
 // d_lin (optional): the gradient of the Linear output feeding this LayerNorm (dropout-scaled dx), bf16 if lin16
 int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           float* dx, void* d_lin, bool lin16, float* d_gamma, float* d_beta, float* d_bias,

@@ -15,6 +15,7 @@
 //   * the negatives axis is split across workgroups (grid.y) to fill 256 CUs; a combine kernel merges the
 //     split partials per query, finishes the seven row losses and the gradient row, and a final
 //     single-workgroup kernel reduces them deterministically.
+#include "internal.h"
 #include "loss_common.h"
 
 namespace {
@@ -416,12 +417,12 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int o) {
   return __hiloint2double(hi, lo);
 }
 // stage 1: block k reduces quantity k over the blocks that carried queries (256 threads, 4 loads in flight each)
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const double* blockpart, int nblocks, const int* counts,
-                                                          double* tot) {
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const double* blockpart, int nblocks, int rows_per_block,
+                                                          const int* counts, double* tot) {
   __shared__ double red[256];
   const int k = blockIdx.x;
   const int Nq = counts[1];
-  int used = (Nq + 3) / 4;
+  int used = (Nq + rows_per_block - 1) / rows_per_block;
   if (used > nblocks) used = nblocks;
   const bool is_min = (k == 20 || k == 22), is_max = (k == 21 || k == 23);
   const double id = is_min ? INFINITY : is_max ? -INFINITY : 0.0;
@@ -538,6 +539,16 @@ thread_local hipEvent_t g_prof_stop = nullptr;
 
 extern "C" {
 
+int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, const int* counts, int mode,
+                     int64_t n_rows, float* losses, float* stats, double* tot, hipStream_t st) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(BP), dim3(256), 0, st, blockpart, nblocks, rows_per_block, counts, tot);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)tot, counts, mode, n_rows, losses,
+                     stats);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
 int xfmr_sampled_loss_profile_next(void* start_event, void* stop_event) {
   g_prof_start = (hipEvent_t)start_event;
   g_prof_stop = (hipEvent_t)stop_event;
@@ -605,21 +616,16 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
-  double* tot = (double*)(ws + p.off_tot);
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(BP), dim3(256), 0, st, (const double*)c.blockpart, p.nblocks,
-                     (const int*)counts, tot);
-  XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)tot, (const int*)counts, cfg->mode,
-                     n_rows, losses, stats);
-  XF_LAUNCH_CHECK();
-  return XFMR_OK;
+  return xf_loss_finalize(c.blockpart, p.nblocks, 4, counts, cfg->mode, n_rows, losses, stats,
+                          (double*)(ws + p.off_tot), st);
 }
 
 static int check_loss_args(const xfmr_loss_cfg* cfg, const float* tok, const float* table, const float* rnorm,
                            float* losses, float* stats, void* workspace, float* d_tok, int64_t rows, int64_t n_rows) {
   if (!cfg || !tok || !table || !rnorm || !losses || !stats || !workspace) return XFMR_EINVAL;
   if (rows <= 0 || n_rows <= 0 || rows > (1 << 30) || n_rows > (1 << 30)) return XFMR_EINVAL;
-  if (cfg->train_head < 0 || cfg->train_head >= XFMR_NUM_LOSSES) return XFMR_EINVAL;
+  if (cfg->train_head < 0 || cfg->train_head >= XFMR_NUM_LOSSES || cfg->num_hard_negatives < 0) return XFMR_EINVAL;
+  if (cfg->num_hard_negatives > 0) return XFMR_EUNSUPPORTED;  // losses.py:295-330: xfmr_dense_loss only (so far)
   if (!xf_aligned16(tok) || !xf_aligned16(table) || !xf_aligned16(workspace) || (d_tok && !xf_aligned16(d_tok)))
     return XFMR_EALIGN;
   return XFMR_OK;

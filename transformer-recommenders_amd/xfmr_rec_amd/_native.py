@@ -50,9 +50,11 @@ class LossCfg(C.Structure):
     _fields_ = [
         ("train_head", C.c_int32), ("all_heads", C.c_int32), ("mask_false_negatives", C.c_int32),
         ("mode", C.c_int32), ("precision", C.c_int32), ("scale", C.c_float), ("margin", C.c_float),
-        ("reserved", C.c_int32),
+        ("num_hard_negatives", C.c_int32),
     ]
 
+
+TARGET_FIRST, TARGET_DIAGONAL, TARGET_EXPLICIT = 0, 1, 2
 
 _P = C.c_void_p
 _SIGNATURES = {
@@ -88,6 +90,9 @@ _SIGNATURES = {
     "xfmr_sampled_loss_lists_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int64]),
     "xfmr_sampled_loss_lists": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64,
                                           C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "xfmr_dense_loss_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "xfmr_dense_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P,
+                                  _P, _P, C.c_size_t, _P]),
     "xfmr_sampled_loss_profile_next": (C.c_int, [_P, _P]),
     "xfmr_table_rnorm": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "xfmr_table_prepare": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),

@@ -131,7 +131,8 @@ class EmbedLoss(torch.nn.Module, abc.ABC):
         c = self.config
         if c.num_hard_negatives > 0:
             raise NotImplementedError(
-                "num_hard_negatives > 0 (losses.py:295-330) is not fused into the gfx950 loss kernel yet"
+                "num_hard_negatives > 0 (losses.py:295-330) is implemented for dense (N,C,H) candidates "
+                "(xfmr_dense_loss); it is not fused into the structured shared-negative / catalogue kernel yet"
             )
         return dict(
             train_head=self.kind if self.kind in N.LOSS_IDS else "InfoNCELoss", all_heads=all_heads,
@@ -161,11 +162,19 @@ class EmbedLoss(torch.nn.Module, abc.ABC):
             return ops.SampledLossListsFunction.apply(
                 q, target.contiguous(), None, candidate_embed.table, candidate_embed.table_rnorm, opts
             )
-        raise NotImplementedError(
-            "dense (N, C, H) candidate tensors are not on the MI355X hot path: pass the structured "
-            "SharedNegatives / CatalogCandidates that RecommenderModel.compute_embeds returns "
-            "(use .materialize() only to feed the CPU oracle)"
+        # the reference's own calling convention: a dense (N,C,H) tensor (xfmr_dense_loss, C <= 8192). The training
+        # path never builds it -- compute_embeds returns the structured forms above.
+        if candidate_embed.requires_grad:
+            raise NotImplementedError("gradients w.r.t. dense candidates are not produced (the reference's candidates "
+                                      "are rows of the frozen item table)")
+        c = self.config
+        opts = dict(
+            target_position=c.target_position, train_head=self.kind if self.kind in N.LOSS_IDS else "InfoNCELoss",
+            all_heads=all_heads, mask_false_negatives=c.mask_false_negatives,
+            num_hard_negatives=c.num_hard_negatives, scale=c.scale, margin=c.margin,
         )
+        tgt = None if target is None else target.contiguous().to(torch.int64)
+        return ops.DenseLossFunction.apply(q, candidate_embed.contiguous().to(torch.float32), tgt, opts)
 
     def forward(self, query_embed, candidate_embed, target=None):
         """Summed loss over the batch (``losses.py:128-155``)."""

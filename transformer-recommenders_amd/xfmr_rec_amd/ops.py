@@ -213,12 +213,36 @@ def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, a
     return losses, stats, d_tok
 
 
-def _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision) -> N.LossCfg:
+def _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision,
+              num_hard_negatives=0) -> N.LossCfg:
     return N.LossCfg(
         train_head=N.LOSS_IDS[train_head] if isinstance(train_head, str) else int(train_head),
         all_heads=int(all_heads), mask_false_negatives=int(mask_false_negatives), mode=mode,
-        precision=N.precision_id(precision), scale=float(scale), margin=float(margin), reserved=0,
+        precision=N.precision_id(precision), scale=float(scale), margin=float(margin),
+        num_hard_negatives=int(num_hard_negatives),
     )
+
+
+def dense_loss(query, cand, target=None, *, target_position="first", train_head, all_heads=False,
+               mask_false_negatives=True, num_hard_negatives=0, scale=1.0, margin=0.5, need_grad=True):
+    """``EmbedLoss.forward`` on a dense (N,C,H) candidate tensor (``losses.py:128-155``):
+    returns (losses[14], stats[16], d_query or None)."""
+    Nq, H = query.shape
+    Cn = cand.shape[1]
+    mode = {"first": N.TARGET_FIRST, "diagonal": N.TARGET_DIAGONAL, None: N.TARGET_EXPLICIT}[target_position]
+    lib = N.load()
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, N.NEG_SHARED, scale, margin, "fp32",
+                    num_hard_negatives)
+    losses, stats = _empty((2 * N.NUM_LOSSES,), query), _empty((N.NUM_STATS,), query)
+    d_q = torch.empty_like(query) if need_grad else None
+    nbytes = lib.xfmr_dense_loss_workspace(Nq, Cn, H)
+    ws = _bytes(nbytes, query)
+    N.check(
+        lib.xfmr_dense_loss(C.byref(cfg), N.ptr(query), N.ptr(cand), N.ptr(target), mode, Nq, Cn, H, N.ptr(losses),
+                            N.ptr(stats), N.ptr(d_q), N.ptr(ws), nbytes, N.stream()),
+        "xfmr_dense_loss",
+    )
+    return losses, stats, d_q
 
 
 def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head, all_heads=False,
@@ -350,3 +374,26 @@ class SampledLossListsFunction(torch.autograd.Function):
         N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(d_q), d_q.numel(), N.ptr(g), N.stream()),
                 "xfmr_scale_by_device_scalar")
         return d_q, None, None, None, None, None
+
+
+class DenseLossFunction(torch.autograd.Function):
+    """``EmbedLoss.forward`` on dense candidates; gradient w.r.t. the query only (candidates are constants)."""
+
+    @staticmethod
+    def forward(ctx, query, cand, target, opts):
+        need = query.requires_grad
+        losses, stats, d_q = dense_loss(query, cand, target, need_grad=need, **opts)
+        head = opts["train_head"]
+        head = N.LOSS_IDS[head] if isinstance(head, str) else head
+        if need:
+            ctx.save_for_backward(d_q)
+        ctx.mark_non_differentiable(losses, stats)
+        return losses[head].clone(), losses, stats
+
+    @staticmethod
+    def backward(ctx, g, _gl, _gs):
+        (d_q,) = ctx.saved_tensors
+        g = g.contiguous().to(f32)
+        N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(d_q), d_q.numel(), N.ptr(g), N.stream()),
+                "xfmr_scale_by_device_scalar")
+        return d_q, None, None, None
