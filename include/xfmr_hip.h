@@ -211,8 +211,10 @@ int xfmr_mean_pool(const float* tok, const uint8_t* key_mask, float* out, int32_
  *                    neg_idx is ignored; the positive's own column is not a negative.
  * Ties: a negative that is the row's positive item has, in the reference, a logit bit-identical to the
  * positive's (same vectors through the same bmm) -- the kernel reproduces that by item id.
- * num_hard_negatives (losses.py:295-330): see xfmr_loss_cfg; supported by xfmr_dense_loss, the fused entry
- * points return XFMR_EUNSUPPORTED for a non-zero value.
+ * num_hard_negatives (losses.py:295-330) > 0 keeps, per row, only the k counted negatives with the largest
+ * logits (cosine logits for the cosine heads): the logits are then dumped once (positions x columns fp32 in the
+ * workspace: size it with the *_workspace_cfg functions), per-row thresholds come from a radix select, and the loss
+ * pass weights every negative by its top-k weight (ties at the threshold share the remaining weight).
  *
  * Outputs (all device memory):
  *   losses[14]       [0..6] summed loss per head (accumulated in fp64), order XFMR_LOSS_*;
@@ -242,7 +244,8 @@ typedef struct xfmr_loss_cfg {
   float margin;                 /* LossConfig.margin (losses.py:30)                                 */
   int32_t num_hard_negatives;   /* LossConfig.num_hard_negatives (losses.py:28, :295-330); 0 = off    */
 } xfmr_loss_cfg;
-size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows);
+size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows);            /* num_hard_negatives == 0 */
+size_t xfmr_sampled_loss_workspace_cfg(const xfmr_loss_cfg* cfg, int64_t positions, int32_t H, int64_t n_rows);
 int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
                       const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
                       int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
@@ -253,6 +256,8 @@ int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t*
  *   query (Np,H); pos_items (Np) item id of each row's positive; neg_items (N) item ids of the shared negative
  *   columns (ignored in XFMR_NEG_CATALOG mode); d_query (Np,H) or NULL. Every row of d_query is written. */
 size_t xfmr_sampled_loss_lists_workspace(int64_t n_query, int64_t n_neg, int32_t H, int64_t n_rows);
+size_t xfmr_sampled_loss_lists_workspace_cfg(const xfmr_loss_cfg* cfg, int64_t n_query, int64_t n_neg, int32_t H,
+                                             int64_t n_rows);
 int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const int64_t* pos_items,
                             const int64_t* neg_items, int64_t n_query, int64_t n_neg, const float* table,
                             const float* table_rnorm, const void* table_bf16, int64_t n_rows, int32_t H,

@@ -161,6 +161,69 @@ def test_loss_heads_match_reference_golden(X, golden_dir, prec):
             assert got[k] == pytest.approx(v, rel=3e-2 if prec == "bf16" else 2e-4, abs=2e-2 if prec == "bf16" else 1e-5), k
 
 
+@pytest.mark.parametrize("mask_fn", [True, False])
+@pytest.mark.parametrize("k", [1, 5, 40])
+def test_hard_negatives_on_structured_candidates_vs_oracle(X, golden_dir, k, mask_fn):
+    """losses.py:295-330 on the fused path: per-row top-k thresholds over never-materialised logits. Negatives
+    repeat items (ties at the threshold), the oracle materialises the (Np,1+N,H) tensor and runs torch.topk."""
+    from oracle import losses as OL
+    from xfmr_rec_amd import losses as XL
+    from xfmr_rec_amd import ops
+
+    g4 = np.load(golden_dir / "g4_shared_negatives.npz")
+    tab_c, pos_c, q_c = _t(g4["table"]), _t(g4["pos"]), _t(g4["q"])
+    gen = torch.Generator().manual_seed(5)
+    neg_c = torch.randint(101, 201, (150,), generator=gen)  # 100 distinct items drawn 150 times: duplicates
+    table = tab_c.to(DEV)
+    rnorm = ops.table_rnorm(table)
+    cfgd = dict(mask_false_negatives=mask_fn, num_hard_negatives=k, scale=4.0, margin=0.4)
+    cand_c = torch.cat([tab_c[pos_c][:, None], tab_c[neg_c][None].expand(q_c.shape[0], -1, -1)], 1)
+    for cls in XL.LOSS_CLASSES:
+        name = cls.__name__
+        qo = q_c.clone().requires_grad_(True)
+        want = OL.embed_loss(name, qo, cand_c, **cfgd)
+        want.backward()
+        q = q_c.to(DEV).requires_grad_(True)
+        got = cls(XL.LossConfig(**cfgd), precision="fp32")(q, XL.SharedNegatives(table, rnorm, pos_c.to(DEV), neg_c.to(DEV)))
+        assert abs(got.item() - want.item()) <= TOL["fp32"]["loss_rel"] * max(1.0, abs(want.item())), (name, got.item(), want.item())
+        got.backward()
+        assert rel_l2(q.grad, qo.grad) <= TOL["fp32"]["grad_l2"], name
+    want = OL.logits_statistics(q_c, cand_c, **cfgd)
+    got = XL.LogitsStatistics(XL.LossConfig(**cfgd), precision="fp32")(
+        q_c.to(DEV), XL.SharedNegatives(table, rnorm, pos_c.to(DEV), neg_c.to(DEV)))
+    assert got.keys() == want.keys()
+    for key, v in want.items():
+        assert got[key] == pytest.approx(v, rel=2e-4, abs=1e-5), key
+    # bf16 MFMA policy: the selected set may differ by elements at the threshold -> loose tolerance
+    for cls in (XL.InfoNCELoss, XL.PairwiseLogisticLoss, XL.AlignmentContrastiveLoss):
+        want = OL.embed_loss(cls.__name__, q_c, cand_c, **cfgd).item()
+        got = cls(XL.LossConfig(**cfgd), precision="bf16")(
+            q_c.to(DEV), XL.SharedNegatives(table, rnorm, pos_c.to(DEV), neg_c.to(DEV))).item()
+        assert abs(got - want) <= 3 * TOL["bf16"]["loss_rel"] * max(1.0, abs(want)), (cls.__name__, got, want)
+
+
+def test_hard_negatives_full_catalogue_vs_oracle(X, golden_dir):
+    from oracle import losses as OL
+    from xfmr_rec_amd import losses as XL
+    from xfmr_rec_amd import ops
+
+    g4 = np.load(golden_dir / "g4_shared_negatives.npz")
+    tab_c, pos_c, q_c = _t(g4["table"]), _t(g4["pos"]), _t(g4["q"])
+    table = tab_c.to(DEV)
+    rnorm = ops.table_rnorm(table)
+    cfgd = dict(target_position=None, mask_false_negatives=False, num_hard_negatives=7)
+    cand_c = tab_c[None].expand(q_c.shape[0], -1, -1)
+    for cls in XL.LOSS_CLASSES:
+        qo = q_c.clone().requires_grad_(True)
+        want = OL.embed_loss(cls.__name__, qo, cand_c, pos_c, **cfgd)
+        want.backward()
+        q = q_c.to(DEV).requires_grad_(True)
+        got = cls(XL.LossConfig(**cfgd), precision="fp32")(q, XL.CatalogCandidates(table, rnorm, q.shape[0]), pos_c.to(DEV))
+        assert abs(got.item() - want.item()) <= TOL["fp32"]["loss_rel"] * max(1.0, abs(want.item())), cls.__name__
+        got.backward()
+        assert rel_l2(q.grad, qo.grad) <= TOL["fp32"]["grad_l2"], cls.__name__
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_full_catalogue_softmax_matches_reference_golden(X, golden_dir, prec):
     """EmbedLoss.forward(q, table[None].expand, target=pos) == CE(Q E^T) (BASELINE config 4 mode)."""
@@ -196,8 +259,8 @@ def test_loss_api_errors_mirror_reference(X):
         fn(torch.zeros(5, 64, device=DEV), cand)  # batch mismatch (losses.py:172)
     with pytest.raises(AssertionError):
         fn(torch.zeros(4, 64, device=DEV), cand, torch.zeros(4, dtype=torch.int64, device=DEV))  # both target and position
-    with pytest.raises(NotImplementedError):
-        XL.InfoNCELoss(XL.LossConfig(num_hard_negatives=3))(torch.zeros(4, 64, device=DEV), cand)
+    with pytest.raises(NotImplementedError):  # gradients w.r.t. dense candidates are not produced
+        fn(torch.zeros(4, 64, device=DEV), torch.zeros(4, 7, 64, device=DEV, requires_grad=True))
 
 
 # ------------------------------------------------------------------------------------------ fused loss, positions form

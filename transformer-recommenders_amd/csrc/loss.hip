@@ -170,7 +170,14 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   const bool do_grad = a.need_grad && head != XFMR_LOSS_ALIGNMENT;
 
   RowState st{0.f, z2pos, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, INFINITY, -INFINITY, 0.f};
-  const RowConst kc{pos_dot, cpos, chinge, sc2, rq, a.margin, pos_item, head, mask_fn, catalog, cos_head};
+  RowConst kc{pos_dot, cpos, chinge, sc2, rq, a.margin, pos_item, head, mask_fn, catalog, cos_head};
+  kc.hard = a.tau != nullptr;
+  if (kc.hard) {
+    const float4 th = a.tau[qvalid ? qi : 0];
+    kc.tau_d = th.x; kc.rho_d = th.y; kc.tau_c = th.z; kc.rho_c = th.w;
+  }
+  const bool dump = a.dump != nullptr;
+  if (dump && split == 0 && lane < 32 && qvalid) a.qinfo[qi] = make_float2(pos_dot, rq);
   f32x16 o[H / 32];
 #pragma unroll
   for (int i = 0; i < H / 32; ++i)
@@ -242,6 +249,16 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
       if (Q_IN_LDS) P::tile_nt(s, sE, LDE, sb * 32, sQ, LDE, wid * 32, H);
       else P::tile_nreg(s, sE, LDE, sb * 32, qreg.regs(), H);
 
+      if (dump) {  // logits of this sub-block, as the epilogue would see them (tie resolution happens in the reader)
+        if (qvalid) {
+          float* drow = a.dump + (int64_t)qi * a.dump_ld + tile * BN + sb * 32 + 4 * hh;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (tile * BN + sb * 32 + 8 * g + 4 * hh < a.dump_ld)
+              *reinterpret_cast<float4*>(drow + 8 * g) = make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+        }
+        continue;
+      }
       loss_epilogue<ALL, true>(s, st, o, kc, &sNid[sb * 32], &sRc[sb * 32], hh);
       if (do_grad) {
 #pragma unroll
@@ -250,6 +267,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
     }
   }
 
+  if (dump) return;
   // ---- write the (split, query) partial -----------------------------------------------------------
   write_partial(st, a.part + ((int64_t)split * a.T + qi) * REC, lane < 32 && qvalid, pos_dot, rq, qq);
   if (do_grad) {
@@ -276,6 +294,105 @@ __global__ void table_prepare_kernel(const float* table, float* rnorm, __bf16* t
   if (lane == 0 && rnorm) rnorm[row] = 1.f / fmaxf(sqrtf(s), 1e-8f);
 }
 
+// ---- num_hard_negatives: per-row top-k thresholds from the dumped logits ------------------------------------
+// One workgroup per query. The k-th largest counted logit is found by a 4-pass, 8-bits-per-pass radix select over
+// order-preserving keys (LDS histogram); elements equal to the threshold share the weight rho = (k - #greater) /
+// #equal -- the loss depends on the multiset of selected logits only, so this equals any tie-breaking of torch.topk
+// (in-batch negatives repeat items, i.e. ties are the rule, not the exception).
+__device__ __forceinline__ unsigned hard_key(float f) {
+  const unsigned b = __float_as_uint(f);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float hard_unkey(unsigned k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+template <class F>
+__device__ void radix_select(F get, int N, int k, unsigned* hist, int* sh, float& tau, float& rho) {
+  // get(j, &value) -> counted?
+  const int tid = threadIdx.x;
+  if (tid == 0) sh[3] = 0;
+  __syncthreads();
+  int n = 0;
+  for (int j = tid; j < N; j += 256) {
+    float v;
+    n += get(j, v) ? 1 : 0;
+  }
+  if (n) atomicAdd(&sh[3], n);
+  __syncthreads();
+  if (sh[3] <= k) {  // fewer counted negatives than k: all of them stay (losses.py:318-329)
+    tau = -INFINITY; rho = 1.f;
+    return;
+  }
+  unsigned prefix = 0;
+  int need = k;
+  for (int p = 3; p >= 0; --p) {
+    hist[tid] = 0;
+    __syncthreads();
+    const int shift = 8 * p;
+    for (int j = tid; j < N; j += 256) {
+      float v;
+      if (!get(j, v)) continue;
+      const unsigned key = hard_key(v);
+      if (p == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, d = 255;
+      for (; d > 0; --d) {
+        if (cum + (int)hist[d] >= need) break;
+        cum += (int)hist[d];
+      }
+      sh[0] = d; sh[1] = need - cum; sh[2] = (int)hist[d];
+    }
+    __syncthreads();
+    prefix |= (unsigned)sh[0] << shift;
+    need = sh[1];
+    __syncthreads();
+  }
+  tau = hard_unkey(prefix);
+  rho = (float)need / (float)sh[2];
+}
+
+struct SelectArgs {
+  const float* dump; int64_t dump_ld; const float2* qinfo; const int* counts; const int* neg_item;
+  const float* neg_rc; const float* rnorm; const int* qpos; float4* tau;
+  int mode, mask_fn, k; int64_t n_rows;
+};
+__global__ __launch_bounds__(256) void hard_select_kernel(SelectArgs a) {
+  __shared__ unsigned hist[256];
+  __shared__ int sh[4];
+  const int qi = blockIdx.x;
+  if (qi >= a.counts[1]) return;
+  const bool catalog = a.mode == XFMR_NEG_CATALOG;
+  const int N = catalog ? (int)a.n_rows : a.counts[0];
+  float4 out = make_float4(-INFINITY, 1.f, -INFINITY, 1.f);
+  if (a.k > 0 && a.k < N + 1) {  // losses.py:312-316: k >= number of columns (1 + N) switches the restriction off
+    const int pos_item = a.qpos[qi];
+    const float2 qf = a.qinfo[qi];
+    const float pos_dot = qf.x, rq = qf.y;
+    const float cpos = pos_dot * rq * a.rnorm[pos_item];
+    const float* row = a.dump + (int64_t)qi * a.dump_ld;
+    const bool mask_fn = a.mask_fn != 0;
+    auto get_d = [&](int j, float& v) {
+      const int it = catalog ? j : a.neg_item[j];
+      const bool same = it == pos_item;
+      v = same ? pos_dot : row[j];
+      return !(catalog && same) && (mask_fn ? v < pos_dot : true);
+    };
+    auto get_c = [&](int j, float& v) {
+      const int it = catalog ? j : a.neg_item[j];
+      const bool same = it == pos_item;
+      const float sv = same ? pos_dot : row[j];
+      v = same ? cpos : sv * rq * (catalog ? a.rnorm[j] : a.neg_rc[j]);
+      return !(catalog && same) && (mask_fn ? v < cpos : true);
+    };
+    radix_select(get_d, N, a.k, hist, sh, out.x, out.y);
+    __syncthreads();
+    radix_select(get_c, N, a.k, hist, sh, out.z, out.w);
+  }
+  if (threadIdx.x == 0) a.tau[qi] = out;
+}
+
 // ---- combine: one wave per query -----------------------------------------------------------------------
 struct CombineArgs {
   const float* tok; const float* table; const float* rnorm;
@@ -286,6 +403,7 @@ struct CombineArgs {
   float* d_tok; double* blockpart;
   int T, H, nsplit, train_head, need_grad, mode; int64_t n_rows;
   float scale, margin;
+  int k_hard;
 };
 
 __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
@@ -337,7 +455,8 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       acc[XFMR_LOSS_NCE] = xf_softplus(-pos_dot) + V.nce * inv_dv;
       acc[XFMR_LOSS_PAIRWISE_HINGE] = V.hinge * inv_dv;
       acc[XFMR_LOSS_PAIRWISE_LOGISTIC] = V.logi * inv_dv;
-      acc[8] = (double)V.cnt_d / ((double)N + 1e-9);  // density term
+      const int num_neg = (a.k_hard > 0 && a.k_hard < N) ? a.k_hard : N;  // losses.py:387-390
+      acc[8] = (double)V.cnt_d / ((double)num_neg + 1e-9);  // density term
       acc[9] = pos_dot; acc[10] = (double)pos_dot * pos_dot;
       acc[11] = V.ssum; acc[12] = V.ssq; acc[13] = V.cnt_d; acc[14] = 1.0;
       acc[20] = pos_dot; acc[21] = pos_dot; acc[22] = V.smin; acc[23] = V.smax;
@@ -474,11 +593,12 @@ __global__ void loss_final_kernel(const double* tot, const int* counts, int mode
 struct Plan {
   int nsplit;
   size_t off_part2, off_negrc, off_tot;
+  size_t off_dump, off_tau, off_qinfo; int64_t dump_ld;  // num_hard_negatives only
   size_t off_counts, off_blockcnt, off_neg, off_qrow, off_qpos, off_part, off_partO, off_block, total;
   int nblocks;
 };
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
-Plan make_plan(int64_t T, int H, int64_t n_rows) {
+Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   Plan p;
   const int64_t qblocks = (T + QB - 1) / QB;
   const int64_t cols = T > n_rows ? T : n_rows;
@@ -501,6 +621,13 @@ Plan make_plan(int64_t T, int H, int64_t n_rows) {
   p.off_partO = o; o += up256((size_t)ns * T * H * 4);
   p.off_block = o; o += up256((size_t)p.nblocks * BP * 8);
   p.off_tot = o; o += 256;
+  p.off_dump = p.off_tau = p.off_qinfo = 0;
+  p.dump_ld = ((cols + BN - 1) / BN) * BN;  // whole tiles: the dump writes 16-byte runs
+  if (hard) {
+    p.off_tau = o; o += up256((size_t)T * sizeof(float4));
+    p.off_qinfo = o; o += up256((size_t)T * sizeof(float2));
+    p.off_dump = o; o += up256((size_t)T * (size_t)p.dump_ld * sizeof(float));
+  }
   p.total = o;
   return p;
 }
@@ -559,6 +686,10 @@ size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows)
   if (positions <= 0 || H <= 0) return 0;
   return make_plan(positions, H, n_rows).total;
 }
+size_t xfmr_sampled_loss_workspace_cfg(const xfmr_loss_cfg* cfg, int64_t positions, int32_t H, int64_t n_rows) {
+  if (!cfg || positions <= 0 || H <= 0) return 0;
+  return make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0).total;
+}
 
 static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* table, const float* table_rnorm,
                     const void* table_bf16, int64_t n_rows, int T, int32_t H, float* losses, float* stats, float* d_tok, unsigned char* ws,
@@ -579,7 +710,26 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
   g_prof_start = g_prof_stop = nullptr;  // one-shot
   const float* part_loss = nullptr;  // records the loss VALUES are read from (null: the same as the gradient's)
-  if (cfg->precision == XFMR_PREC_BF16 && table_bf16) {
+  const bool hard = cfg->num_hard_negatives > 0;
+  if (hard) {
+    // top-k hard negatives (losses.py:295-330), generic kernel for both precisions: (1) the same kernel dumps its
+    // logits (bit-identical to what the loss pass will see), (2) per-row thresholds by radix select, (3) the loss
+    // pass with every counted negative weighted by its top-k weight.
+    LossArgs d = a;
+    d.dump = (float*)(ws + p.off_dump); d.dump_ld = p.dump_ld; d.qinfo = (float2*)(ws + p.off_qinfo); d.need_grad = 0;
+    if (cfg->precision == XFMR_PREC_BF16) rc = launch_main_h<PrecBF16>(d, H, false, grid, st);
+    else if (cfg->precision == XFMR_PREC_F32) rc = launch_main_h<PrecF32>(d, H, false, grid, st);
+    else rc = XFMR_EINVAL;
+    if (rc) return rc;
+    SelectArgs s{};
+    s.dump = d.dump; s.dump_ld = p.dump_ld; s.qinfo = d.qinfo; s.counts = counts; s.neg_item = neg_item;
+    s.neg_rc = a.neg_rc; s.rnorm = table_rnorm; s.qpos = qpos; s.tau = (float4*)(ws + p.off_tau);
+    s.mode = cfg->mode; s.mask_fn = cfg->mask_false_negatives; s.k = cfg->num_hard_negatives; s.n_rows = n_rows;
+    hipLaunchKernelGGL(hard_select_kernel, dim3((unsigned)T), dim3(256), 0, st, s);
+    XF_LAUNCH_CHECK();
+    a.tau = (const float4*)(ws + p.off_tau);
+  }
+  if (!hard && cfg->precision == XFMR_PREC_BF16 && table_bf16) {
     // bf16 production path: the gradient pass of the train head (skipped for AlignmentLoss, whose gradient has
     // no negative term) and, when every head is wanted or no gradient is, the values-only logging pass.
     const bool all = cfg->all_heads != 0;
@@ -614,6 +764,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   c.part = a.part; c.part_loss = part_loss ? part_loss : a.part; c.partO = a.partO; c.d_tok = d_tok; c.blockpart = (double*)(ws + p.off_block);
   c.T = T; c.H = H; c.nsplit = p.nsplit; c.train_head = cfg->train_head; c.need_grad = d_tok != nullptr;
   c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
+  c.k_hard = cfg->num_hard_negatives;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
   return xf_loss_finalize(c.blockpart, p.nblocks, 4, counts, cfg->mode, n_rows, losses, stats,
@@ -625,7 +776,6 @@ static int check_loss_args(const xfmr_loss_cfg* cfg, const float* tok, const flo
   if (!cfg || !tok || !table || !rnorm || !losses || !stats || !workspace) return XFMR_EINVAL;
   if (rows <= 0 || n_rows <= 0 || rows > (1 << 30) || n_rows > (1 << 30)) return XFMR_EINVAL;
   if (cfg->train_head < 0 || cfg->train_head >= XFMR_NUM_LOSSES || cfg->num_hard_negatives < 0) return XFMR_EINVAL;
-  if (cfg->num_hard_negatives > 0) return XFMR_EUNSUPPORTED;  // losses.py:295-330: xfmr_dense_loss only (so far)
   if (!xf_aligned16(tok) || !xf_aligned16(table) || !xf_aligned16(workspace) || (d_tok && !xf_aligned16(d_tok)))
     return XFMR_EALIGN;
   return XFMR_OK;
@@ -639,7 +789,7 @@ int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t*
     return rc;
   if (!key_mask || !pos_idx) return XFMR_EINVAL;
   if (cfg->mode == XFMR_NEG_SHARED && !neg_idx) return XFMR_EINVAL;
-  const Plan p = make_plan(positions, H, n_rows);
+  const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0);
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
@@ -663,6 +813,12 @@ size_t xfmr_sampled_loss_lists_workspace(int64_t n_query, int64_t n_neg, int32_t
   if (rows <= 0 || H <= 0) return 0;
   return make_plan(rows, H, n_rows).total;
 }
+size_t xfmr_sampled_loss_lists_workspace_cfg(const xfmr_loss_cfg* cfg, int64_t n_query, int64_t n_neg, int32_t H,
+                                             int64_t n_rows) {
+  const int64_t rows = n_query > n_neg ? n_query : n_neg;
+  if (!cfg || rows <= 0 || H <= 0) return 0;
+  return make_plan(rows, H, n_rows, cfg->num_hard_negatives > 0).total;
+}
 
 int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const int64_t* pos_items,
                             const int64_t* neg_items, int64_t n_query, int64_t n_neg, const float* table,
@@ -673,7 +829,7 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
     return rc;
   if (!pos_items || n_query <= 0) return XFMR_EINVAL;
   if (cfg->mode == XFMR_NEG_SHARED && (!neg_items || n_neg <= 0)) return XFMR_EINVAL;
-  const Plan p = make_plan(rows, H, n_rows);
+  const Plan p = make_plan(rows, H, n_rows, cfg->num_hard_negatives > 0);
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;

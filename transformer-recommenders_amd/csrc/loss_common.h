@@ -24,6 +24,10 @@ struct LossArgs {
   const float* neg_rc;    // [N] inverse norm of each negative's row (shared mode)
   const int* qrow; const int* qpos;
   float* part; float* partO;
+  // num_hard_negatives (losses.py:295-330), generic kernel only: `dump` != null turns the launch into a logits dump
+  // (dump[qi * dump_ld + j] = S^T tile values, qinfo[qi] = {pos_dot, 1/|q|}); `tau` != null restricts the negatives of
+  // row qi to those at / above its thresholds tau[qi] = {tau_dot, rho_dot, tau_cos, rho_cos}
+  float* dump; int64_t dump_ld; float2* qinfo; const float4* tau;
   int T; int nsplit;
   int train_head, mask_fn, mode, need_grad;
   float scale, margin;
@@ -39,9 +43,12 @@ struct RowConst {
   float pos_dot, cpos, chinge, sc2, rq, margin;
   int pos_item, head;
   bool mask_fn, catalog, cos_head;
+  bool hard;                             // top-k restriction active (per-row thresholds below)
+  float tau_d, rho_d, tau_c, rho_c;
 };
 // HC: the train head as a compile-time constant (its gradient weight is produced), or -1 = values only.
-template <bool ALL, int HC, int NO>
+// HARD: weight every counted negative by its top-k weight (1 above the row's threshold, rho at it, 0 below).
+template <bool ALL, int HC, int NO, bool HARD = false>
 __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
                                                 const int* nid_sb, const float* rc_sb, int hh) {
   float& cnt_d = st.cnt_d; float& m = st.m; float& l = st.l; float& nce = st.nce; float& hinge = st.hinge;
@@ -67,8 +74,9 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bool same = nn[u] == pos_item;
-        const bool md = (nn[u] >= 0) & !(catalog & same);
-        bmax = fmaxf(bmax, md ? (same ? pos_dot : s[4 * g + u]) * sc2 : m);
+        const float svp = same ? pos_dot : s[4 * g + u];
+        const bool md = (nn[u] >= 0) & !(catalog & same) & (HARD ? svp >= k.tau_d : true);
+        bmax = fmaxf(bmax, md ? svp * sc2 : m);
       }
     }
     bmax = fmaxf(bmax, xf_half_swap(bmax));
@@ -105,7 +113,8 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
       const bool same = nn[u] == pos_item;  // exact tie: the negative IS the positive item
       const float sv = same ? pos_dot : s[r];
       const bool excl = catalog & same;
-      const float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? 1.f : 0.f;
+      float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? 1.f : 0.f;
+      if (HARD) md *= sv > k.tau_d ? 1.f : (sv == k.tau_d ? k.rho_d : 0.f);
       float w = 0.f;
       cnt_d += md;
       if (want_lse) {
@@ -118,8 +127,11 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
         const float t = xf_exp2(-fabsf(sv) * kLog2e);                    // exp(-|x|)
         // softplus(x) = max(x, 0) + log(1 + exp(-|x|)); the log terms of the sub-block's 16 elements are taken as
         // ONE log of their product (each factor is in [1, 2]): 2 transcendental issues per 16 elements, not 32
-        nce = fmaf(fmaxf(sv, 0.f), md, nce);
-        pn *= fmaf(t, md, 1.f);
+        if (HARD) nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // md may be fractional
+        else {
+          nce = fmaf(fmaxf(sv, 0.f), md, nce);
+          pn *= fmaf(t, md, 1.f);
+        }
         if (head == XFMR_LOSS_NCE) w = md * xf_rcp(1.f + t) * (sv >= 0.f ? 1.f : t);  // sigmoid(x)
       }
       if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
@@ -128,14 +140,18 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
         if (head == XFMR_LOSS_PAIRWISE_HINGE) w = d > 0.f ? md : 0.f;
         if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
           const float t = xf_exp2(-fabsf(d) * kLog2e);
-          logi = fmaf(fmaxf(d, 0.f), md, logi);
-          pl *= fmaf(t, md, 1.f);
+          if (HARD) logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
+          else {
+            logi = fmaf(fmaxf(d, 0.f), md, logi);
+            pl *= fmaf(t, md, 1.f);
+          }
           if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md * xf_rcp(1.f + t) * (d >= 0.f ? 1.f : t);
         }
       }
       if (ALL || cos_head) {
         const float c = same ? cpos : sv * rq * rc[u];
-        const float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? 1.f : 0.f;
+        float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? 1.f : 0.f;
+        if (HARD) mc *= c > k.tau_c ? 1.f : (c == k.tau_c ? k.rho_c : 0.f);
         cnt_c += mc;
         const float d = c - 1.f + k.margin;
         contr = fmaf(fmaxf(d, 0.f), mc, contr);
@@ -185,24 +201,32 @@ __device__ __forceinline__ void loss_epilogue_infonce_masked(f32x16& s, float& l
 }
 
 // runtime head -> compile-time head (one wave-uniform switch per sub-block instead of ~6 per element)
-template <bool ALL, bool GRAD, int NO>
-__device__ __forceinline__ void loss_epilogue(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
-                                              const int* nid_sb, const float* rc_sb, int hh) {
+template <bool ALL, bool GRAD, int NO, bool HARD = false>
+__device__ __forceinline__ void loss_epilogue_h(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
+                                                const int* nid_sb, const float* rc_sb, int hh) {
   if (!GRAD) {
-    if (ALL) return loss_epilogue_t<true, -1>(s, st, o, k, nid_sb, rc_sb, hh);
+    if (ALL) return loss_epilogue_t<true, -1, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
     // values of ONE head: its accumulators are selected by the head, no weights needed -> reuse the
     // weighted variants (the weight computation is dead code without the second product)
   }
   switch (k.head) {
-    case XFMR_LOSS_ALIGNMENT: return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_ALIGNMENT: return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
     case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:
-      return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>(s, st, o, k, nid_sb, rc_sb, hh);
-    case XFMR_LOSS_CONTRASTIVE: return loss_epilogue_t<ALL, XFMR_LOSS_CONTRASTIVE>(s, st, o, k, nid_sb, rc_sb, hh);
-    case XFMR_LOSS_INFONCE: return loss_epilogue_t<ALL, XFMR_LOSS_INFONCE>(s, st, o, k, nid_sb, rc_sb, hh);
-    case XFMR_LOSS_NCE: return loss_epilogue_t<ALL, XFMR_LOSS_NCE>(s, st, o, k, nid_sb, rc_sb, hh);
-    case XFMR_LOSS_PAIRWISE_HINGE: return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_HINGE>(s, st, o, k, nid_sb, rc_sb, hh);
-    default: return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_LOGISTIC>(s, st, o, k, nid_sb, rc_sb, hh);
+      return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT_CONTRASTIVE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_CONTRASTIVE:
+      return loss_epilogue_t<ALL, XFMR_LOSS_CONTRASTIVE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_INFONCE: return loss_epilogue_t<ALL, XFMR_LOSS_INFONCE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_NCE: return loss_epilogue_t<ALL, XFMR_LOSS_NCE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_PAIRWISE_HINGE:
+      return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_HINGE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+    default: return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_LOGISTIC, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
   }
+}
+template <bool ALL, bool GRAD, int NO>
+__device__ __forceinline__ void loss_epilogue(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
+                                              const int* nid_sb, const float* rc_sb, int hh) {
+  if (k.hard) loss_epilogue_h<ALL, GRAD, NO, true>(s, st, o, k, nid_sb, rc_sb, hh);
+  else loss_epilogue_h<ALL, GRAD, NO, false>(s, st, o, k, nid_sb, rc_sb, hh);
 }
 
 // halves of a lane pair (l, l^32) hold disjoint negatives of the same query: combine, then one lane writes

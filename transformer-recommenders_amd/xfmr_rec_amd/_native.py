@@ -85,9 +85,12 @@ _SIGNATURES = {
     "xfmr_encoder_bwd": (C.c_int, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "xfmr_mean_pool": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "xfmr_sampled_loss_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int64]),
+    "xfmr_sampled_loss_workspace_cfg": (C.c_size_t, [C.POINTER(LossCfg), C.c_int64, C.c_int32, C.c_int64]),
     "xfmr_sampled_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32,
                                     _P, _P, _P, _P, C.c_size_t, _P]),
     "xfmr_sampled_loss_lists_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int64]),
+    "xfmr_sampled_loss_lists_workspace_cfg": (C.c_size_t, [C.POINTER(LossCfg), C.c_int64, C.c_int64, C.c_int32,
+                                                           C.c_int64]),
     "xfmr_sampled_loss_lists": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64,
                                           C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
     "xfmr_dense_loss_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

@@ -129,15 +129,10 @@ class EmbedLoss(torch.nn.Module, abc.ABC):
 
     def _opts(self, mode: int, *, all_heads: bool = False) -> dict:
         c = self.config
-        if c.num_hard_negatives > 0:
-            raise NotImplementedError(
-                "num_hard_negatives > 0 (losses.py:295-330) is implemented for dense (N,C,H) candidates "
-                "(xfmr_dense_loss); it is not fused into the structured shared-negative / catalogue kernel yet"
-            )
         return dict(
             train_head=self.kind if self.kind in N.LOSS_IDS else "InfoNCELoss", all_heads=all_heads,
             mask_false_negatives=c.mask_false_negatives, mode=mode, scale=c.scale, margin=c.margin,
-            precision=self.precision,
+            precision=self.precision, num_hard_negatives=c.num_hard_negatives,
         )
 
     def _run(self, query_embed, candidate_embed, target, *, all_heads: bool = False):

@@ -191,17 +191,17 @@ def adamw_(params, grads, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, ep
 
 def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, all_heads=True,
                  mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
-                 need_grad=True, table_bf16=None):
+                 need_grad=True, table_bf16=None, num_hard_negatives=0):
     """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H)."""
     H = tok.shape[-1]
     T = tok.numel() // H
     lib = N.load()
-    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision)
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives)
     n_rows = table.shape[0]
     losses = _empty((2 * N.NUM_LOSSES,), tok)
     stats = _empty((N.NUM_STATS,), tok)
     d_tok = torch.empty_like(tok) if need_grad else None
-    nbytes = lib.xfmr_sampled_loss_workspace(T, H, n_rows)
+    nbytes = lib.xfmr_sampled_loss_workspace_cfg(C.byref(cfg), T, H, n_rows)
     ws = _bytes(nbytes, tok)
     N.check(
         lib.xfmr_sampled_loss(C.byref(cfg), N.ptr(tok), N.ptr(key_mask), N.ptr(pos_idx), N.ptr(neg_idx),
@@ -247,16 +247,16 @@ def dense_loss(query, cand, target=None, *, target_position="first", train_head,
 
 def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head, all_heads=False,
                        mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
-                       need_grad=True, table_bf16=None):
+                       need_grad=True, table_bf16=None, num_hard_negatives=0):
     """List form (compacted queries): returns (losses[7], stats[16], d_query or None)."""
     Np, H = query.shape
     Nn = 0 if neg_items is None else neg_items.numel()
     lib = N.load()
-    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision)
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives)
     n_rows = table.shape[0]
     losses, stats = _empty((2 * N.NUM_LOSSES,), query), _empty((N.NUM_STATS,), query)
     d_q = torch.empty_like(query) if need_grad else None
-    nbytes = lib.xfmr_sampled_loss_lists_workspace(Np, Nn, H, n_rows)
+    nbytes = lib.xfmr_sampled_loss_lists_workspace_cfg(C.byref(cfg), Np, Nn, H, n_rows)
     ws = _bytes(nbytes, query)
     N.check(
         lib.xfmr_sampled_loss_lists(C.byref(cfg), N.ptr(query), N.ptr(pos_items), N.ptr(neg_items), Np, Nn,
