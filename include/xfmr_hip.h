@@ -188,10 +188,23 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
 int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* grads, float* d_tok,
                      const uint8_t* key_mask, void* acts, size_t acts_bytes, void* stream);
 
-/* masked mean pooling: sentence_embedding[b] = sum_t tok[b,t]*m[b,t] / max(sum_t m[b,t], 1e-9)
- * (sentence-transformers Pooling(mean) as wired at xfmr_rec/models.py:143-145). */
+/* Pooling over the token axis: sentence-transformers Pooling(pooling_mode) as wired at xfmr_rec/models.py:143-145
+ * for the modes ModelConfig.pooling_mode allows (models.py:47): mean = sum_t tok*m / max(sum_t m, 1e-9);
+ * max = max_t (m ? tok : -1e9); cls = tok[:,0]; lasttoken = the last token with m != 0 (zero if none).
+ * Forward only: sentence_embedding is not on the training path (the loss reads token_embeddings). */
+enum { XFMR_POOL_MEAN = 0, XFMR_POOL_MAX = 1, XFMR_POOL_CLS = 2, XFMR_POOL_LASTTOKEN = 3 };
+int xfmr_pool(const float* tok, const uint8_t* key_mask, float* out, int32_t B, int32_t L, int32_t H, int32_t mode,
+              void* stream);
 int xfmr_mean_pool(const float* tok, const uint8_t* key_mask, float* out, int32_t B, int32_t L, int32_t H,
                    void* stream);
+
+/* Row-wise L2 normalisation y = x / max(|x|, eps) and its backward: torch.nn.functional.normalize on the query
+ * embeddings when ModelConfig.is_normalized (xfmr_rec/models.py:393-394, eps 1e-12) and the sentence-transformers
+ * Normalize module on sentence_embedding (models.py:146-147). inv_norm (rows) is saved by fwd for bwd (may be NULL
+ * in fwd when no backward follows). */
+int xfmr_l2_normalize_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int32_t H, float eps, void* stream);
+int xfmr_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int32_t H,
+                          float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8-K17: fused in-batch sampled loss (all seven heads + LogitsStatistics + dL/dquery in ONE pass over

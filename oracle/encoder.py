@@ -157,6 +157,28 @@ def mean_pool(token_embeddings, key_mask):
     return (token_embeddings * m).sum(1) / m.sum(1).clamp(min=1e-9)
 
 
+def pool(token_embeddings, key_mask, mode: str = "mean"):
+    """sentence-transformers ``Pooling(pooling_mode)`` for the modes ``ModelConfig.pooling_mode`` allows
+    (``models.py:47, 143-145``). sentence-transformers 5.7.0 is not importable here: restated from its
+    published behaviour -- mean: masked sum / clamp(mask sum, 1e-9); max: masked positions set to -1e9, then max;
+    cls: token 0; lasttoken: the last position with mask 1 (position 0 when the row has none), times its mask.
+    Parity of max / cls / lasttoken is therefore UNPINNED (no reference output exists for them in this container)."""
+    if mode == "mean":
+        return mean_pool(token_embeddings, key_mask)
+    m = key_mask.to(torch.bool)
+    if mode == "cls":
+        return token_embeddings[:, 0]
+    if mode == "max":
+        return token_embeddings.masked_fill(~m[..., None], -1e9).max(1).values
+    if mode == "lasttoken":
+        L = key_mask.shape[1]
+        values, indices = key_mask.long().flip(1).max(1)
+        indices = torch.where(values == 0, torch.full_like(indices, L - 1), indices)
+        gather = (L - indices - 1)[:, None, None].expand(-1, 1, token_embeddings.shape[-1])
+        return torch.gather(token_embeddings * m[..., None].to(token_embeddings.dtype), 1, gather)[:, 0]
+    raise ValueError(mode)
+
+
 def algorithmic_flops_per_sequence(L, H, I, n_layers, n_neg_cols) -> float:
     """3*nL*(8LH^2 + 4LHI + 2L(L+1)H) + 4*L*M*H."""
     enc = 8 * L * H * H + 4 * L * H * I + 2 * L * (L + 1) * H

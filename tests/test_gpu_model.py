@@ -358,6 +358,52 @@ def test_compute_losses_matches_reference_golden(X, golden_dir, prec):
     assert_close("query_embed", e["query_embed"], _t(g3["query_embed"]), prec)
 
 
+@pytest.mark.parametrize("train_loss", ["InfoNCELoss", "AlignmentContrastiveLoss"])
+def test_normalized_queries_and_hard_negatives_in_the_training_step_vs_oracle(X, golden_dir, train_loss):
+    """ModelConfig.is_normalized (models.py:393-394) and LossConfig.num_hard_negatives (losses.py:295-330) through
+    compute_losses + backward, on the G3 inputs, against the CPU oracle (fp32 policy, ties resolved by item id)."""
+    from oracle import model as OM
+
+    g3 = np.load(golden_dir / "g3_step.npz")
+    cfg = json.loads(str(g3["cfg"]))
+    conf = X.LightningConfig(hidden_size=cfg["H"], num_attention_heads=cfg["A"], intermediate_size=cfg["I"],
+                             num_hidden_layers=cfg["nL"], max_seq_length=cfg["L"], train_loss=train_loss,
+                             precision="fp32", is_normalized=True, num_hard_negatives=4, scale=3.0)
+    mod = X.RecommenderLightningModule(conf)
+    mod.configure_model()
+    state = {k[len("param0/"):]: _t(g3[k]) for k in g3.files if k.startswith("param0/")}
+    mod.model.load_encoder_state_dict(state)
+    mod.model.set_table(_t(g3["table"]).to(DEV))
+    mod = mod.to(DEV).eval()
+    batch = {"history_item_idx": _t(g3["hist"]), "pos_item_idx": _t(g3["pos"]), "neg_item_idx": _t(g3["neg"])}
+    out = mod.compute_losses(batch)
+    loss_cfg = dict(target_position="first", mask_false_negatives=True, num_hard_negatives=4, scale=3.0, margin=0.5)
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    want = OM.compute_losses(params, _t(g3["table"]), batch, num_heads=cfg["A"], max_seq_length=cfg["L"],
+                             loss_cfg=loss_cfg, is_normalized=True, resolve_ties=True)
+    for cls in X.LOSS_CLASSES:
+        k = f"loss/{cls.__name__}"
+        w = float(want[k])
+        assert abs(float(out[k]) - w) <= TOL["fp32"]["loss_rel"] * max(1.0, abs(w)), (k, float(out[k]), w)
+    for k in ("logits/neg/density", "logits/neg/mean", "logits/pos/mean", "logits/neg/max"):
+        assert out[k] == pytest.approx(want[k], rel=2e-4, abs=1e-5), k
+    out[f"loss/{train_loss}"].backward()
+    want[f"loss/{train_loss}"].backward()
+    from xfmr_rec_amd.models import flat_layout
+
+    flat_g = mod.model.flat.grad
+    names, shapes, offsets, _total = flat_layout(cfg["H"], cfg["I"], cfg["L"], cfg["nL"])
+    checked = 0
+    for name, shape, off in zip(names, shapes, offsets):
+        if name not in params or "key.bias" in name:  # d/d(key.bias) is exactly 0: rounding noise only
+            continue
+        n = int(np.prod(shape))
+        g = flat_g[off:off + n].view(shape).cpu()
+        assert rel_l2(g, params[name].grad) <= 5e-4, name
+        checked += 1
+    assert checked >= 10
+
+
 @pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"])
 def test_three_adamw_steps_match_reference_golden(X, golden_dir, train_loss):
     """zero_grad -> training_step -> backward -> AdamW, three times, fp32 MFMA path, dropout off (eval):

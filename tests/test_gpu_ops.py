@@ -238,3 +238,41 @@ def test_errors_are_loud(ops):
     qkv = torch.zeros(1, 8, 3 * 48, device=DEV)
     with pytest.raises(RuntimeError, match="not supported"):
         ops.attn_fwd(qkv, torch.ones(1, 8, dtype=torch.uint8, device=DEV), 1)  # head size 48
+
+
+@pytest.mark.parametrize("mode", ["mean", "max", "cls", "lasttoken"])
+def test_pooling_modes_vs_oracle(ops, mode):
+    """ModelConfig.pooling_mode (models.py:47). Only 'mean' is pinned by a reference run (G3 sentence path); the
+    other modes follow the oracle's restatement of sentence-transformers Pooling (parity unpinned, see oracle)."""
+    from oracle import encoder as enc
+
+    g = torch.Generator().manual_seed(3)
+    B, L, H = 5, 17, 64
+    tok = torch.randn(B, L, H, generator=g)
+    lens = torch.tensor([17, 1, 9, 0, 12])
+    mask = (torch.arange(L)[None, :] < lens[:, None])
+    mask[2, 3] = False  # an interior padding position
+    got = ops.pool(tok.to(DEV), mask.to(torch.uint8).to(DEV), mode).cpu()
+    want = enc.pool(tok, mask.long(), mode)
+    if mode == "max":  # rows with no visible token: -1e9 in both
+        assert torch.equal(got[3], want[3])
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+
+
+def test_l2_normalize_fwd_bwd_vs_torch(ops):
+    """torch.nn.functional.normalize (models.py:393-394), including a zero row (norm clamped at eps)."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(37, 128, generator=g)
+    x[5] = 0
+    dy = torch.randn(37, 128, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.normalize(xr, dim=-1)
+    yr.backward(dy)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = ops.l2_normalize(xd)
+    yd.backward(dy.to(DEV))
+    torch.testing.assert_close(yd.detach().cpu(), yr.detach(), rtol=1e-6, atol=1e-6)
+    ok = torch.ones(37, dtype=torch.bool)
+    ok[5] = False  # d/dx of x / eps is 1e12 * dy: compare on a relative scale
+    torch.testing.assert_close(xd.grad.cpu()[ok], xr.grad[ok], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xd.grad.cpu()[5], xr.grad[5], rtol=1e-5, atol=0)

@@ -340,17 +340,70 @@ __global__ void embed_type_grad_kernel(const float* d_pos, float* d_type, int L,
   d_type[H + c] = 0.f;
 }
 
-__global__ void mean_pool_kernel(const float* tok, const uint8_t* mask, float* out, int L, int H) {
+// sentence-transformers Pooling over the token axis (modes the reference's ModelConfig.pooling_mode allows,
+// models.py:47). One thread per (sequence, column).
+//   mean:      sum_t tok*m / max(sum_t m, 1e-9)
+//   max:       max_t (m ? tok : -1e9)
+//   cls:       tok[0]
+//   lasttoken: tok[last t with m != 0] (t = 0 when the row has none), times its mask value
+__global__ void pool_kernel(const float* tok, const uint8_t* mask, float* out, int L, int H, int mode) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= H) return;
-  float s = 0.f, n = 0.f;
-  for (int t = 0; t < L; ++t) {
-    const float m = mask[(int64_t)b * L + t] ? 1.f : 0.f;
-    s += tok[((int64_t)b * L + t) * H + c] * m;
-    n += m;
+  const float* x = tok + (int64_t)b * L * H + c;
+  const uint8_t* m = mask + (int64_t)b * L;
+  float r;
+  if (mode == XFMR_POOL_MEAN) {
+    float s = 0.f, n = 0.f;
+    for (int t = 0; t < L; ++t) {
+      const float w = m[t] ? 1.f : 0.f;
+      s += x[(int64_t)t * H] * w;
+      n += w;
+    }
+    r = s / fmaxf(n, 1e-9f);
+  } else if (mode == XFMR_POOL_MAX) {
+    r = -INFINITY;
+    for (int t = 0; t < L; ++t) r = fmaxf(r, m[t] ? x[(int64_t)t * H] : -1e9f);
+  } else if (mode == XFMR_POOL_CLS) {
+    r = x[0];
+  } else {
+    int last = -1;
+    for (int t = 0; t < L; ++t)
+      if (m[t]) last = t;
+    r = last >= 0 ? x[(int64_t)last * H] : 0.f;
   }
-  out[(int64_t)b * H + c] = s / fmaxf(n, 1e-9f);
+  out[(int64_t)b * H + c] = r;
+}
+
+// y = x / max(|x|, eps) per row (torch.nn.functional.normalize, models.py:393-394; sentence-transformers
+// Normalize, models.py:146-147). One wave per row.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* y, float* inv_norm, int64_t rows, int H,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < H; c += 64) {
+    const float v = x[row * H + c];
+    s += v * v;
+  }
+  s = xf_wave_sum(s);
+  const float inv = 1.f / fmaxf(sqrtf(s), eps);
+  for (int c = lane; c < H; c += 64) y[row * H + c] = x[row * H + c] * inv;
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+}
+// dx = inv * (dy - y (y . dy)); with the norm clamped at eps the map is linear: dx = dy / eps
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* dy, const float* y, const float* inv_norm,
+                                                         float* dx, int64_t rows, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float inv = inv_norm[row];
+  const bool clamped = inv * eps >= 1.f;
+  float d = 0.f;
+  for (int c = lane; c < H; c += 64) d += y[row * H + c] * dy[row * H + c];
+  d = clamped ? 0.f : xf_wave_sum(d);
+  for (int c = lane; c < H; c += 64) dx[row * H + c] = inv * (dy[row * H + c] - y[row * H + c] * d);
 }
 
 __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
@@ -530,11 +583,32 @@ int xfmr_embed_param_grads(const float* d_pre, float* d_pos, float* d_type, int3
   return XFMR_OK;
 }
 
+int xfmr_pool(const float* tok, const uint8_t* key_mask, float* out, int32_t B, int32_t L, int32_t H, int32_t mode,
+              void* stream) {
+  if (!tok || !key_mask || !out || B <= 0 || L <= 0 || H <= 0) return XFMR_EINVAL;
+  if (mode < XFMR_POOL_MEAN || mode > XFMR_POOL_LASTTOKEN) return XFMR_EINVAL;
+  hipLaunchKernelGGL(pool_kernel, dim3((H + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, tok, key_mask, out, L, H,
+                     mode);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
 int xfmr_mean_pool(const float* tok, const uint8_t* key_mask, float* out, int32_t B, int32_t L, int32_t H,
                    void* stream) {
-  if (!tok || !key_mask || !out || B <= 0 || L <= 0 || H <= 0) return XFMR_EINVAL;
-  hipLaunchKernelGGL(mean_pool_kernel, dim3((H + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, tok, key_mask, out,
-                     L, H);
+  return xfmr_pool(tok, key_mask, out, B, L, H, XFMR_POOL_MEAN, stream);
+}
+
+int xfmr_l2_normalize_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int32_t H, float eps, void* stream) {
+  if (!x || !y || rows <= 0 || H <= 0 || !(eps > 0.f)) return XFMR_EINVAL;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     inv_norm, rows, H, eps);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+int xfmr_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int32_t H,
+                          float eps, void* stream) {
+  if (!dy || !y || !inv_norm || !dx || rows <= 0 || H <= 0 || !(eps > 0.f)) return XFMR_EINVAL;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, y,
+                     inv_norm, dx, rows, H, eps);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }

@@ -55,6 +55,7 @@ class LossCfg(C.Structure):
 
 
 TARGET_FIRST, TARGET_DIAGONAL, TARGET_EXPLICIT = 0, 1, 2
+POOL_MODES = {"mean": 0, "max": 1, "cls": 2, "lasttoken": 3}
 
 _P = C.c_void_p
 _SIGNATURES = {
@@ -84,6 +85,9 @@ _SIGNATURES = {
     "xfmr_encoder_fwd": (C.c_int, [C.POINTER(EncoderCfg), _P, _P, _P, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "xfmr_encoder_bwd": (C.c_int, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "xfmr_mean_pool": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "xfmr_pool": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "xfmr_l2_normalize_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "xfmr_l2_normalize_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "xfmr_sampled_loss_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int64]),
     "xfmr_sampled_loss_workspace_cfg": (C.c_size_t, [C.POINTER(LossCfg), C.c_int64, C.c_int32, C.c_int64]),
     "xfmr_sampled_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32,

@@ -259,12 +259,10 @@ class RecommenderModel(torch.nn.Module):
     def forward(self, item_idx=None, *, item_embeds=None) -> dict[str, torch.Tensor]:
         """``models.py:306-345``: returns token_embeddings (B,L,H), sentence_embedding (B,H), attention_mask."""
         tok, key_mask = self._encode_tokens(item_idx, item_embeds)
-        if self.config.pooling_mode != "mean":
-            raise NotImplementedError("only pooling_mode='mean' (the reference default) is built")
-        with torch.no_grad():
-            sent = ops.mean_pool(tok.detach(), key_mask)
-        if self.config.is_normalized:
-            raise NotImplementedError("is_normalized=True is not built yet")
+        with torch.no_grad():  # sentence_embedding is not on the training path (models.py:143-147)
+            sent = ops.pool(tok.detach(), key_mask, self.config.pooling_mode)
+            if self.config.is_normalized:
+                sent = ops.l2_normalize(sent)
         return {"token_embeddings": tok, "sentence_embedding": sent, "attention_mask": key_mask.long()}
 
     def encode(self, item_ids: list[str]) -> torch.Tensor:
@@ -280,14 +278,14 @@ class RecommenderModel(torch.nn.Module):
     def compute_embeds(self, history_item_idx, pos_item_idx, neg_item_idx) -> dict:
         """``models.py:366-419``. ``query_embed`` is the compacted ``(Np, H)`` tensor (this needs the row count
         on the host, as the reference's boolean indexing does); ``candidate_embed`` is structured."""
-        if self.config.is_normalized:
-            raise NotImplementedError("is_normalized=True is not built yet")
         tok, key_mask = self._encode_tokens(history_item_idx)
         am = key_mask.bool()
         pos = pos_item_idx.to(self.device)[am]
         neg = neg_item_idx.to(self.device)[am]
         keep = pos != 0
         query = tok[am][keep]
+        if self.config.is_normalized:  # models.py:393-394 (normalising before or after the row selection is the same)
+            query = ops.l2_normalize(query)
         cand = SharedNegatives(self.embeddings, self.table_rnorm, pos[keep], neg, table_bf16=self.table_bf16)
         return {"query_embed": query, "candidate_embed": cand, "attention_mask": am, "positive_mask": keep}
 

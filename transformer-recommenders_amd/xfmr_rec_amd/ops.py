@@ -180,6 +180,44 @@ def mean_pool(tok, key_mask):
     return out
 
 
+def pool(tok, key_mask, mode: str = "mean"):
+    """sentence-transformers Pooling(pooling_mode) over (B,L,H) tokens; forward only."""
+    B, L, H = tok.shape
+    out = _empty((B, H), tok)
+    N.check(N.load().xfmr_pool(N.ptr(tok), N.ptr(key_mask), N.ptr(out), B, L, H, N.POOL_MODES[mode], N.stream()),
+            "xfmr_pool")
+    return out
+
+
+class L2NormalizeFunction(torch.autograd.Function):
+    """``torch.nn.functional.normalize(x, dim=-1)`` (``models.py:393-394``) on (rows, H)."""
+
+    @staticmethod
+    def forward(ctx, x, eps=1e-12):
+        x = x.contiguous().to(f32)
+        rows, H = x.numel() // x.shape[-1], x.shape[-1]
+        y, inv = torch.empty_like(x), _empty((rows,), x)
+        N.check(N.load().xfmr_l2_normalize_fwd(N.ptr(x), N.ptr(y), N.ptr(inv), rows, H, eps, N.stream()),
+                "xfmr_l2_normalize_fwd")
+        ctx.save_for_backward(y, inv)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dy = dy.contiguous().to(f32)
+        dx = torch.empty_like(y)
+        rows, H = y.numel() // y.shape[-1], y.shape[-1]
+        N.check(N.load().xfmr_l2_normalize_bwd(N.ptr(dy), N.ptr(y), N.ptr(inv), N.ptr(dx), rows, H, ctx.eps, N.stream()),
+                "xfmr_l2_normalize_bwd")
+        return dx, None
+
+
+def l2_normalize(x, eps: float = 1e-12):
+    return L2NormalizeFunction.apply(x, eps)
+
+
 def adamw_(params, grads, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=1,
            grad_scale=1.0):
     N.check(

@@ -135,21 +135,21 @@ class RecommenderLightningModule(_Base):
         """
         assert self.model is not None
         m, c = self.model, self.config
-        if c.num_hard_negatives > 0:
-            raise NotImplementedError("num_hard_negatives > 0 is not fused into the gfx950 loss kernel yet")
         if c.target_position != "first":
             raise ValueError("the training path scores [positive | shared negatives]: target_position='first'")
         dev = m.device
         hist = batch["history_item_idx"]
         tok, key_mask = m._encode_tokens(hist)
+        if m.config.is_normalized:  # models.py:393-394: the queries are the L2-normalised token embeddings
+            tok = ops.l2_normalize(tok)
         L = tok.shape[1]
         pos = batch["pos_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
         neg = batch["neg_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
         opts = dict(train_head=c.train_loss, all_heads=c.log_all_losses, mask_false_negatives=c.mask_false_negatives,
                     mode=N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision,
-                    table_bf16=m.table_bf16)
+                    table_bf16=m.table_bf16, num_hard_negatives=c.num_hard_negatives)
         overlap = (defer_logging and c.log_all_losses and tok.requires_grad and torch.is_grad_enabled()
-                   and m.table_bf16 is not None and c.precision == "bf16")
+                   and m.table_bf16 is not None and c.precision == "bf16" and c.num_hard_negatives == 0)
         if overlap:
             # The six logging heads + statistics do not feed the gradient: evaluate them on a side stream so the
             # (VALU-bound) logging pass runs underneath the (latency-bound) encoder backward. The caller joins
