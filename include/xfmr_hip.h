@@ -249,7 +249,9 @@ enum {
 typedef struct xfmr_loss_cfg {
   int32_t train_head;           /* XFMR_LOSS_*: the head whose gradient is produced               */
   int32_t all_heads;            /* 1: evaluate all seven heads + statistics (trainer.py:250-264);
-                                   0: only train_head (others are returned as 0)                   */
+                                   0: only train_head (others are returned as 0);
+                                   2: (d_tok == NULL only) all heads EXCEPT train_head, which is returned as 0 --
+                                      the logging half of a step whose gradient half already produced it        */
   int32_t mask_false_negatives; /* LossConfig.mask_false_negatives (losses.py:27)                   */
   int32_t mode;                 /* XFMR_NEG_*                                                       */
   int32_t precision;            /* XFMR_PREC_*                                                      */

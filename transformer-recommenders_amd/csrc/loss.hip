@@ -403,7 +403,7 @@ struct CombineArgs {
   float* d_tok; double* blockpart;
   int T, H, nsplit, train_head, need_grad, mode; int64_t n_rows;
   float scale, margin;
-  int k_hard;
+  int k_hard, skip_train_head;
 };
 
 __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
@@ -456,6 +456,11 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       acc[XFMR_LOSS_PAIRWISE_HINGE] = V.hinge * inv_dv;
       acc[XFMR_LOSS_PAIRWISE_LOGISTIC] = V.logi * inv_dv;
       const int num_neg = (a.k_hard > 0 && a.k_hard < N) ? a.k_hard : N;  // losses.py:387-390
+      if (a.skip_train_head) {  // all_heads == 2 (compile-time indices: a runtime index would put acc[] in scratch)
+#pragma unroll
+        for (int k = 0; k < XFMR_NUM_LOSSES; ++k)
+          if (k == a.train_head) acc[k] = 0.0;
+      }
       acc[8] = (double)V.cnt_d / ((double)num_neg + 1e-9);  // density term
       acc[9] = pos_dot; acc[10] = (double)pos_dot * pos_dot;
       acc[11] = V.ssum; acc[12] = V.ssq; acc[13] = V.cnt_d; acc[14] = 1.0;
@@ -745,7 +750,10 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       if (grad_pass) b.part = (float*)(ws + p.off_part2);
       b.need_grad = 0;
       if (!grad_pass && ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
-      rc = launch_dma_h(b, table_bf16, H, -1, grid, st);
+      // all_heads == 2: the train head's value is not wanted from this call (the caller has it from the gradient
+      // pass of the same step): for InfoNCE that drops the log-sum-exp from the per-logit work
+      const int code = (cfg->all_heads == 2 && cfg->train_head == XFMR_LOSS_INFONCE && !grad_pass) ? -2 : -1;
+      rc = launch_dma_h(b, table_bf16, H, code, grid, st);
       if (rc) return rc;
       if (!grad_pass && ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
       if (grad_pass) part_loss = b.part;
@@ -765,6 +773,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   c.T = T; c.H = H; c.nsplit = p.nsplit; c.train_head = cfg->train_head; c.need_grad = d_tok != nullptr;
   c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
   c.k_hard = cfg->num_hard_negatives;
+  c.skip_train_head = (cfg->all_heads == 2 && d_tok == nullptr) ? 1 : 0;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
   return xf_loss_finalize(c.blockpart, p.nblocks, 4, counts, cfg->mode, n_rows, losses, stats,

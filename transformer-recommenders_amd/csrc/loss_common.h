@@ -62,7 +62,8 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
   constexpr int H = NO * 32;  // only used to walk the gradient accumulators
   // The lane's 16 accumulator rows (r&3) + 8*(r>>2) + 4*hh are four runs of 4 consecutive negatives:
   // per-negative side data (item id, inverse norm) comes as one 16-byte LDS read per run and array.
-  const bool want_lse = ALL || head == XFMR_LOSS_INFONCE;
+  // HC == -2: the logging pass of a step whose InfoNCE value already comes from the gradient pass (all_heads = 2)
+  const bool want_lse = (ALL && HC != -2) || head == XFMR_LOSS_INFONCE;
   if (want_lse && !mask_fn) {
     // online log-sum-exp: without false-negative masking a counted logit may exceed the running max
     // (with masking every counted logit is < the positive's, and m = scale * pos stays fixed)

@@ -8,6 +8,7 @@ int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, 
   dim3 block(256);
   switch (head) {
     case -1: hipLaunchKernelGGL((loss_main_dma_kernel<256, -1>), grid, block, 0, st, a, tbf); break;
+    case -2: hipLaunchKernelGGL((loss_main_dma_kernel<256, -2>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:
       hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_CONTRASTIVE:

@@ -161,8 +161,10 @@ class RecommenderLightningModule(_Base):
             )
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                # all_heads=2: every head except the train head (its value comes from the launch above)
                 losses, stats, _ = ops.sampled_loss(
-                    tok.detach(), key_mask, pos, neg, m.embeddings, m.table_rnorm, need_grad=False, **opts
+                    tok.detach(), key_mask, pos, neg, m.embeddings, m.table_rnorm, need_grad=False,
+                    **(opts | {"all_heads": 2})
                 )
             for tns in (tok, key_mask, pos, neg):
                 tns.record_stream(side)
@@ -181,7 +183,7 @@ class RecommenderLightningModule(_Base):
             out[f"loss/{name}"] = val
             if not overlap:
                 out[f"loss/{name}Mean"] = losses[N.NUM_LOSSES + i]  # computed by the final kernel
-        if overlap:  # the ...Mean values are derived lazily (after the join) by loss_means()
+        if overlap:  # raw device vector of the side-stream pass (train head entry = 0): see logged_values()
             out["losses/device"] = losses
         batch_size, seq_len = key_mask.shape
         numel = key_mask.numel()
@@ -198,6 +200,34 @@ class RecommenderLightningModule(_Base):
         else:
             out["stats/device"] = stats
         return out
+
+    def logged_values(self, out: dict) -> dict[str, float]:
+        """Host-side view of a ``compute_losses(..., defer_logging=True)`` result: joins the side stream and
+        returns every ``loss/<Class>``, ``loss/<Class>Mean``, ``batch/*`` and ``logits/*`` entry as floats
+        (one device->host sync), exactly the keys the reference logs (``trainer.py:241-263``)."""
+        self.sync_logging()
+        c = self.config
+        if "stats/device" not in out:
+            return {k: float(v) for k, v in out.items() if not k.endswith("/device")}
+        s = out["stats/device"].tolist()
+        attn_nz, pos_nz = int(s[N.STAT["n_valid"]]), int(s[N.STAT["n_query"]])
+        res: dict[str, float] = {}
+        dev = out.get("losses/device")
+        vals = dev.tolist() if dev is not None else None
+        for i, cls in enumerate(LOSS_CLASSES):
+            k = f"loss/{cls.__name__}"
+            if k not in out:
+                continue
+            v = float(out[k]) if (vals is None or cls.__name__ == c.train_loss) else vals[i]
+            res[k] = v
+            res[k + "Mean"] = v / (pos_nz + 1e-9)
+        res |= {
+            "batch/attention_non_zero": attn_nz, "batch/positive_non_zero": pos_nz,
+            "batch/positive_density": pos_nz / (attn_nz + 1e-9),
+        }
+        if c.log_all_losses:
+            res |= stats_to_dict(s)
+        return res
 
     def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         loss_dict = self.compute_losses(batch)
