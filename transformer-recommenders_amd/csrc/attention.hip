@@ -307,24 +307,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 // ================================================================================================================
 using AI = SwzImg<DH>;
 
+// Stages TWO row panels (K and V, or Q and dO) into swizzled images. All of a thread's global loads of a batch
+// (2 panels x 4 pieces) are issued before the first LDS store: the plain load -> store loop exposed one global
+// latency per piece (4-7 round trips per workgroup before the first MFMA).
 template <bool S16>
-__device__ __forceinline__ void stage_rows_swz(__bf16* img, const void* srcv, int64_t off, int64_t stride, int row0,
-                                               int nrows, int row_end) {
-  if (S16) {  // bf16 storage: 16-byte chunks go to the image as they are
-    const __bf16* src = reinterpret_cast<const __bf16*>(srcv) + off;
-    for (int c = threadIdx.x; c < nrows * 4; c += blockDim.x) {
-      const int r = c >> 2, ch = c & 3;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (row0 + r < row_end) v = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + r) * stride + ch * 8);
-      *reinterpret_cast<uint4*>(img + AI::off(r, ch)) = v;
+__device__ __forceinline__ void stage2_rows_swz(__bf16* imgA, const void* srcAv, int64_t offA, int64_t strideA,
+                                                __bf16* imgB, const void* srcBv, int64_t offB, int64_t strideB,
+                                                int row0, int nrows, int row_end) {
+  constexpr int U = 4;
+  if (S16) {  // bf16 storage: 16-byte chunks go to the image as they are (4 chunks per 32-wide row)
+    const __bf16* srcA = reinterpret_cast<const __bf16*>(srcAv) + offA;
+    const __bf16* srcB = reinterpret_cast<const __bf16*>(srcBv) + offB;
+    const int total = nrows * 4;
+    for (int c0 = threadIdx.x; c0 < total; c0 += (int)blockDim.x * U) {
+      uint4 va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * (int)blockDim.x, r = c >> 2, ch = c & 3;
+        va[u] = vb[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (c < total && row0 + r < row_end) {
+          va[u] = *reinterpret_cast<const uint4*>(srcA + (int64_t)(row0 + r) * strideA + ch * 8);
+          vb[u] = *reinterpret_cast<const uint4*>(srcB + (int64_t)(row0 + r) * strideB + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * (int)blockDim.x, r = c >> 2, ch = c & 3;
+        if (c < total) {
+          *reinterpret_cast<uint4*>(imgA + AI::off(r, ch)) = va[u];
+          *reinterpret_cast<uint4*>(imgB + AI::off(r, ch)) = vb[u];
+        }
+      }
     }
   } else {
-    const float* src = reinterpret_cast<const float*>(srcv) + off;
-    for (int c = threadIdx.x; c < nrows * 8; c += blockDim.x) {
-      const int r = c >> 3, dd = (c & 7) * 4;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * stride + dd);
-      xf_store4<PrecBF16>(img + AI::off(r, dd >> 3) + (dd & 7), v);
+    const float* srcA = reinterpret_cast<const float*>(srcAv) + offA;
+    const float* srcB = reinterpret_cast<const float*>(srcBv) + offB;
+    const int total = nrows * 8;
+    for (int c0 = threadIdx.x; c0 < total; c0 += (int)blockDim.x * U) {
+      float4 va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * (int)blockDim.x, r = c >> 3, dd = (c & 7) * 4;
+        va[u] = vb[u] = make_float4(0, 0, 0, 0);
+        if (c < total && row0 + r < row_end) {
+          va[u] = *reinterpret_cast<const float4*>(srcA + (int64_t)(row0 + r) * strideA + dd);
+          vb[u] = *reinterpret_cast<const float4*>(srcB + (int64_t)(row0 + r) * strideB + dd);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * (int)blockDim.x, r = c >> 3, dd = (c & 7) * 4;
+        if (c < total) {
+          xf_store4<PrecBF16>(imgA + AI::off(r, dd >> 3) + (dd & 7), va[u]);
+          xf_store4<PrecBF16>(imgB + AI::off(r, dd >> 3) + (dd & 7), vb[u]);
+        }
+      }
     }
   }
 }
@@ -353,8 +390,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
 
   const int64_t tok0 = (int64_t)b * L;
-  stage_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, 0, nkeys, L);
-  stage_rows_swz<S16>(sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0, nkeys, L);
+  stage2_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0,
+                       nkeys, L);
   for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
   __syncthreads();
 
@@ -422,8 +459,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
 
   const int64_t tok0 = (int64_t)b * L;
-  stage_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, 0, nkeys, L);
-  stage_rows_swz<S16>(sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0, nkeys, L);
+  stage2_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0,
+                       nkeys, L);
   for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
   __syncthreads();
 
@@ -482,22 +519,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
 
   const int64_t tok0 = (int64_t)b * L;
   const int64_t hoff = tok0 * H + h * DH;
-  stage_rows_swz<S16>(sQ, a.qkv, tok0 * 3 * H + h * DH, 3 * H, kblk0, nq, L);
-  stage_rows_swz<S16>(sDO, a.d_ctx, hoff, H, kblk0, nq, L);
-  for (int c = threadIdx.x; c < nq * 8; c += blockDim.x) {
-    const int r = c >> 3, dd = (c & 7) * 4;
-    float part = 0.f;
-    if (kblk0 + r < L) {
-      const float4 x = xf_ld4<S16>(a.ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
-      const float4 y = xf_ld4<S16>(a.d_ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
-      part = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+  stage2_rows_swz<S16>(sQ, a.qkv, tok0 * 3 * H + h * DH, 3 * H, sDO, a.d_ctx, hoff, H, kblk0, nq, L);
+  // delta[r] = rowsum(dO * O), lse[r]: loads of a batch of 4 pieces issued together (see stage2_rows_swz)
+  for (int c0 = threadIdx.x; c0 < nq * 8; c0 += (int)blockDim.x * 4) {
+    float4 x[4], y[4];
+    float ls[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * (int)blockDim.x, r = c >> 3, dd = (c & 7) * 4;
+      x[u] = y[u] = make_float4(0, 0, 0, 0);
+      ls[u] = INFINITY;
+      if (c < nq * 8 && kblk0 + r < L) {
+        x[u] = xf_ld4<S16>(a.ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
+        y[u] = xf_ld4<S16>(a.d_ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
+        if ((c & 7) == 0) ls[u] = a.lse[(int64_t)blockIdx.y * L + kblk0 + r] * kLog2e;
+      }
     }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    if ((c & 7) == 0) {
-      sDelta[r] = part;
-      sLse[r] = (kblk0 + r < L) ? a.lse[(int64_t)blockIdx.y * L + kblk0 + r] * kLog2e : INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * (int)blockDim.x, r = c >> 3;
+      float part = x[u].x * y[u].x + x[u].y * y[u].y + x[u].z * y[u].z + x[u].w * y[u].w;
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      if (c < nq * 8 && (c & 7) == 0) {
+        sDelta[r] = part;
+        sLse[r] = ls[u];
+      }
     }
   }
   __syncthreads();
