@@ -306,6 +306,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 // Q^T, dO^T) and no scattered transposing stores while staging.
 // ================================================================================================================
 using AI = SwzImg<DH>;
+// bytes of the two staged row panels of a (batch, head), or of the 4 x 32 x 33 fp32 output-transposition scratch
+// that later aliases them, whichever is larger (16-byte multiple)
+__host__ __device__ inline size_t bf16_panel_bytes(int L) {
+  const size_t Lp = ((size_t)L + 31) / 32 * 32;
+  const size_t img = 2 * Lp * DH * 2, scr = 4 * 32 * 33 * sizeof(float);
+  return ((img > scr ? img : scr) + 15) & ~(size_t)15;
+}
 
 // Stages TWO row panels (K and V, or Q and dO) into swizzled images. All of a thread's global loads of a batch
 // (2 panels x 4 pieces) are issued before the first LDS store: the plain load -> store loop exposed one global
@@ -386,8 +393,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sV = sK + nkeys * DH;
-  float* scratch = reinterpret_cast<float*>(sV + nkeys * DH);
-  uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
+  // the output-transposition scratch ALIASES the K / V images (used after a barrier, once every wave is done with
+  // them): 46 KB -> 29 KB per workgroup at L = 200, so all 4 workgroups per CU of the (2, B x A) grid are resident
+  // at once instead of 3 plus a one-third-full second round
+  float* scratch = reinterpret_cast<float*>(smem_raw);
+  uint8_t* sMask = smem_raw + bf16_panel_bytes(L);
 
   const int64_t tok0 = (int64_t)b * L;
   stage2_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0,
@@ -397,17 +407,17 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
 
   const int lane = xf_lane(), wid = threadIdx.x >> 6;
   const int q0 = qblk0 + wid * 32;
-  if (q0 >= L) return;
+  const bool active = q0 < L;  // (wave-uniform) inactive waves still take part in the barrier below
   const int q = q0 + (lane & 31);
   RegRows<PrecBF16, DH> qreg;
-  qreg.load_at<S16>(a.qkv, (tok0 + q) * 3 * H + h * DH, q < L);
+  qreg.load_at<S16>(a.qkv, (tok0 + q) * 3 * H + h * DH, active && q < L);
   const float sc = 0.17677669529663687f * kLog2e;
   float m = -INFINITY, lsum = 0.f;
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
-  const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
+  const int kb_end = active ? min((q0 + 31) / 32, nkeys / 32 - 1) : -1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s;
 #pragma unroll
@@ -441,6 +451,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   }
   const float ltot = lsum + xf_half_swap(lsum);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+  __syncthreads();  // every wave is done with the K / V images the scratch aliases
+  if (!active) return;
   xf_store_tile_T_at<S16>(scratch + wid * 32 * 33, o, inv, a.ctx, tok0 * H + h * DH, H, q0, L);
   if (lane < 32 && q < L)
     a.lse[((int64_t)blockIdx.y) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
@@ -455,8 +467,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sV = sK + nkeys * DH;
-  float* scratch = reinterpret_cast<float*>(sV + nkeys * DH);
-  uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
+  // the output-transposition scratch ALIASES the K / V images (used after a barrier, once every wave is done with
+  // them): 46 KB -> 29 KB per workgroup at L = 200, so all 4 workgroups per CU of the (2, B x A) grid are resident
+  // at once instead of 3 plus a one-third-full second round
+  float* scratch = reinterpret_cast<float*>(smem_raw);
+  uint8_t* sMask = smem_raw + bf16_panel_bytes(L);
 
   const int64_t tok0 = (int64_t)b * L;
   stage2_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0,
@@ -466,9 +481,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 
   const int lane = xf_lane(), wid = threadIdx.x >> 6;
   const int q0 = qblk0 + wid * 32;
-  if (q0 >= L) return;
+  const bool active = q0 < L;
   const int q = q0 + (lane & 31);
-  const bool qv = q < L;
+  const bool qv = active && q < L;
   RegRows<PrecBF16, DH> qreg, doreg;
   qreg.load_at<S16>(a.qkv, (tok0 + q) * 3 * H + h * DH, qv);
   doreg.load_at<S16>(a.d_ctx, (tok0 + q) * H + h * DH, qv);
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   f32x16 dq;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-  const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
+  const int kb_end = active ? min((q0 + 31) / 32, nkeys / 32 - 1) : -1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s, dp;
 #pragma unroll
@@ -499,6 +514,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     }
     AI::tile_xb_tr(dq, sK, 0, kb * 32, s);
   }
+  __syncthreads();  // the scratch aliases the K / V images
+  if (!active) return;
   xf_store_tile_T_at<S16>(scratch + wid * 32 * 33, dq, 0.17677669529663687f, a.d_qkv, tok0 * 3 * H + h * DH, 3 * H, q0,
                           L);
 }
@@ -513,8 +530,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   const int nq = Lp - kblk0;
   __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sDO = sQ + nq * DH;
-  float* scratch = reinterpret_cast<float*>(sDO + nq * DH);
-  float* sLse = scratch + 4 * 32 * 33;
+  float* scratch = reinterpret_cast<float*>(smem_raw);  // aliases the Q / dO images: see attn_fwd_bf16_kernel
+  float* sLse = reinterpret_cast<float*>(smem_raw + bf16_panel_bytes(L));
   float* sDelta = sLse + nq;
 
   const int64_t tok0 = (int64_t)b * L;
@@ -552,17 +569,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
 
   const int lane = xf_lane(), wid = threadIdx.x >> 6;
   const int k0 = kblk0 + wid * 32;
-  if (k0 >= L) return;
+  const bool active = k0 < L;
   const int key = k0 + (lane & 31);
-  const bool kvis = key < L && a.key_mask[tok0 + (key < L ? key : 0)];
+  const bool kvis = active && key < L && a.key_mask[tok0 + (key < L ? key : 0)];
   RegRows<PrecBF16, DH> kreg, vreg;
-  kreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + H + h * DH, key < L);
-  vreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + 2 * H + h * DH, key < L);
+  kreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + H + h * DH, active && key < L);
+  vreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + 2 * H + h * DH, active && key < L);
   const float sc = 0.17677669529663687f * kLog2e;
   f32x16 dk, dv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
-  for (int qb = k0 / 32; qb < Lp / 32; ++qb) {
+  for (int qb = active ? k0 / 32 : Lp / 32; qb < Lp / 32; ++qb) {
     const int row0 = qb * 32 - kblk0;
     f32x16 s, dp;
 #pragma unroll
@@ -583,18 +600,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
     AI::tile_xb_tr(dv, sDO, 0, row0, dp);
     AI::tile_xb_tr(dk, sQ, 0, row0, s);
   }
+  __syncthreads();  // the scratch aliases the Q / dO images
+  if (!active) return;
   float* sc_w = scratch + wid * 32 * 33;
   xf_store_tile_T_at<S16>(sc_w, dk, 0.17677669529663687f, a.d_qkv, tok0 * 3 * H + H + h * DH, 3 * H, k0, L);
   xf_store_tile_T_at<S16>(sc_w, dv, 1.f, a.d_qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, k0, L);
 }
 
-size_t bf16_smem_fwd(int L) {  // K + V images, transposed-store scratch, key mask
+size_t bf16_smem_fwd(int L) {  // K + V images (aliased by the transposed-store scratch), key mask
   const int Lp = ((L + 31) / 32) * 32;
-  return (size_t)2 * Lp * DH * 2 + 4 * 32 * 33 * sizeof(float) + Lp;
+  return bf16_panel_bytes(L) + Lp;
 }
-size_t bf16_smem_dkv(int L) {  // Q + dO images, scratch, lse + delta
+size_t bf16_smem_dkv(int L) {  // Q + dO images (aliased by the scratch), lse + delta
   const int Lp = ((L + 31) / 32) * 32;
-  return (size_t)2 * Lp * DH * 2 + 4 * 32 * 33 * sizeof(float) + 2 * (size_t)Lp * sizeof(float);
+  return bf16_panel_bytes(L) + 2 * (size_t)Lp * sizeof(float);
 }
 
 template <class P>
