@@ -373,6 +373,20 @@ __device__ __forceinline__ void stage2_rows_swz(__bf16* imgA, const void* srcAv,
   }
 }
 // sum over 16 consecutive elements of x[i] * y[i]
+// key-padding mask of the (batch, head)'s keys as one bit per key (word kb = keys 32 kb .. 32 kb + 31): the score
+// loops test a register bit instead of reading one LDS byte per score
+__device__ __forceinline__ void stage_key_bits(uint32_t* bits, const uint8_t* key_mask, int nkeys, int L) {
+  for (int t0 = 0; t0 < nkeys; t0 += (int)blockDim.x) {
+    const int tt = t0 + (int)threadIdx.x;
+    const bool f = tt < L && key_mask[tt] != 0;
+    const unsigned long long bal = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && tt < nkeys) {
+      bits[tt >> 5] = (uint32_t)bal;
+      bits[(tt >> 5) + 1] = (uint32_t)(bal >> 32);  // (one word of slack is allocated)
+    }
+  }
+}
+
 template <bool S16>
 __device__ __forceinline__ float dot16(const void* x, const void* y, int64_t off) {
   float acc = 0.f;
@@ -397,12 +411,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   // them): 46 KB -> 29 KB per workgroup at L = 200, so all 4 workgroups per CU of the (2, B x A) grid are resident
   // at once instead of 3 plus a one-third-full second round
   float* scratch = reinterpret_cast<float*>(smem_raw);
-  uint8_t* sMask = smem_raw + bf16_panel_bytes(L);
+  uint32_t* sBits = reinterpret_cast<uint32_t*>(smem_raw + bf16_panel_bytes(L));  // key mask, one bit per key
 
   const int64_t tok0 = (int64_t)b * L;
   stage2_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0,
                        nkeys, L);
-  for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
+  stage_key_bits(sBits, a.key_mask + tok0, nkeys, L);
   __syncthreads();
 
   const int lane = xf_lane(), wid = threadIdx.x >> 6;
@@ -424,10 +438,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     AI::tile_nreg(s, sK, kb * 32, qreg.regs());
     float bmax = -INFINITY;
+    const uint32_t kbits = sBits[kb] >> (4 * (lane >> 5));  // this half-wave's keys: bit (r&3) + 8*(r>>2)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kb * 32 + xf_acc_row(r, lane);
-      const bool vis = (key <= q) && sMask[key];
+      const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
       s[r] = vis ? s[r] * sc : -INFINITY;
       bmax = fmaxf(bmax, s[r]);
     }
@@ -471,12 +486,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   // them): 46 KB -> 29 KB per workgroup at L = 200, so all 4 workgroups per CU of the (2, B x A) grid are resident
   // at once instead of 3 plus a one-third-full second round
   float* scratch = reinterpret_cast<float*>(smem_raw);
-  uint8_t* sMask = smem_raw + bf16_panel_bytes(L);
+  uint32_t* sBits = reinterpret_cast<uint32_t*>(smem_raw + bf16_panel_bytes(L));  // key mask, one bit per key
 
   const int64_t tok0 = (int64_t)b * L;
   stage2_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0,
                        nkeys, L);
-  for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
+  stage_key_bits(sBits, a.key_mask + tok0, nkeys, L);
   __syncthreads();
 
   const int lane = xf_lane(), wid = threadIdx.x >> 6;
@@ -503,10 +518,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     AI::tile_nreg(s, sK, kb * 32, qreg.regs());
     AI::tile_nreg(dp, sV, kb * 32, doreg.regs());
+    const uint32_t kbits = sBits[kb] >> (4 * (lane >> 5));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kb * 32 + xf_acc_row(r, lane);
-      const bool vis = (key <= q) && sMask[key];
+      const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
       const float p = vis ? xf_exp2(s[r] * sc - lse2) : 0.f;
       float dpv = dp[r];
       if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)key);
@@ -609,7 +625,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
 
 size_t bf16_smem_fwd(int L) {  // K + V images (aliased by the transposed-store scratch), key mask
   const int Lp = ((L + 31) / 32) * 32;
-  return bf16_panel_bytes(L) + Lp;
+  return bf16_panel_bytes(L) + (Lp / 32 + 2) * sizeof(uint32_t);
 }
 size_t bf16_smem_dkv(int L) {  // Q + dO images (aliased by the scratch), lse + delta
   const int Lp = ((L + 31) / 32) * 32;
