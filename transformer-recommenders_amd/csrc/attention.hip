@@ -602,16 +602,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     AI::tile_nreg(s, sQ, row0, kreg.regs());
     AI::tile_nreg(dp, sDO, row0, vreg.regs());
+    // the lane's 16 query rows are four runs of 4 consecutive rows: lse / delta come as 16-byte LDS reads
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = row0 + xf_acc_row(r, lane);
-      const int q = qi + kblk0;
-      const bool vis = kvis && (key <= q);
-      const float p = vis ? xf_exp2(s[r] * sc - sLse[qi]) : 0.f;
-      float keep = 1.f;
-      if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blockIdx.y * L + q) * L) + (uint32_t)key);
-      s[r] = p * (dp[r] * keep - sDelta[qi]);
-      dp[r] = p * keep;
+    for (int g = 0; g < 4; ++g) {
+      const int qi0 = row0 + 8 * g + 4 * (lane >> 5);
+      const float4 l4 = *reinterpret_cast<const float4*>(&sLse[qi0]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&sDelta[qi0]);
+      const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = 4 * g + u;
+        const int q = qi0 + u + kblk0;
+        const bool vis = kvis && (key <= q);
+        const float p = vis ? xf_exp2(s[r] * sc - ls[u]) : 0.f;
+        float keep = 1.f;
+        if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blockIdx.y * L + q) * L) + (uint32_t)key);
+        s[r] = p * (dp[r] * keep - dl[u]);
+        dp[r] = p * keep;
+      }
     }
     AI::tile_xb_tr(dv, sDO, 0, row0, dp);
     AI::tile_xb_tr(dk, sQ, 0, row0, s);
