@@ -43,8 +43,8 @@ __global__ __launch_bounds__(PREP) void prepare_count_kernel(const uint8_t* key_
 }
 __global__ __launch_bounds__(PREP) void prepare_write_kernel(const uint8_t* key_mask, const int64_t* pos_idx,
                                                              const int64_t* neg_idx, int T, int64_t n_rows,
-                                                             const int2* blockcnt, const float* rnorm, int* counts,
-                                                             int* neg_item, float* neg_rc, int* qrow, int* qpos) {
+                                                             const int2* blockcnt, int* counts, int* hist, int* qrow,
+                                                             int* qpos) {
   __shared__ int sv[PREP / 64], sq[PREP / 64], base[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = blockIdx.x * PREP + tid;
@@ -65,10 +65,11 @@ __global__ __launch_bounds__(PREP) void prepare_write_kernel(const uint8_t* key_
   ov += __popcll(bv & below);
   oq += __popcll(bq & below);
   if (v) {
-    int64_t ni = neg_idx ? neg_idx[i] : 0;
-    if (ni < 0 || ni >= n_rows) ni = 0;
-    neg_item[ov] = (int)ni;
-    neg_rc[ov] = rnorm[ni];
+    if (neg_idx) {  // multiplicity of the position's negative item (integer atomics: deterministic)
+      int64_t ni = neg_idx[i];
+      if (ni < 0 || ni >= n_rows) ni = 0;
+      atomicAdd(&hist[ni], 1);
+    }
     if (q) {
       qrow[oq] = i;
       qpos[oq] = (int)((pi < 0 || pi >= n_rows) ? 0 : pi);
@@ -82,8 +83,7 @@ __global__ __launch_bounds__(PREP) void prepare_write_kernel(const uint8_t* key_
 
 // ---- list form: queries already compacted (EmbedLoss.forward(query_embed, candidates)) ------------
 __global__ void prepare_lists_kernel(const int64_t* pos_items, const int64_t* neg_items, int Np, int N,
-                                     int64_t n_rows, const float* rnorm, int* counts, int* neg_item, float* neg_rc,
-                                     int* qrow, int* qpos) {
+                                     int64_t n_rows, int* counts, int* hist, int* qrow, int* qpos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
     counts[0] = N;
@@ -98,9 +98,51 @@ __global__ void prepare_lists_kernel(const int64_t* pos_items, const int64_t* ne
   if (neg_items && i < N) {
     int64_t n = neg_items[i];
     if (n < 0 || n >= n_rows) n = 0;
-    neg_item[i] = (int)n;
-    neg_rc[i] = rnorm[n];
+    atomicAdd(&hist[n], 1);
   }
+}
+
+// ---- distinct negative items (ascending id) with their multiplicities, from the histogram over the catalogue --
+// Same two-kernel, order-preserving compaction as above, over items instead of positions.
+__global__ __launch_bounds__(PREP) void distinct_count_kernel(const int* hist, int64_t n_rows, int* blockcnt) {
+  __shared__ int sv[PREP / 64];
+  const int64_t i = (int64_t)blockIdx.x * PREP + threadIdx.x;
+  const bool v = i < n_rows && hist[i] > 0;
+  const int nv = __popcll(__ballot(v));
+  if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = nv;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = 0;
+    for (int w = 0; w < PREP / 64; ++w) a += sv[w];
+    blockcnt[blockIdx.x] = a;
+  }
+}
+__global__ __launch_bounds__(PREP) void distinct_write_kernel(const int* hist, int64_t n_rows, const int* blockcnt,
+                                                              const float* rnorm, int* counts, int* neg_item,
+                                                              float* neg_rc, float* neg_mult) {
+  __shared__ int sv[PREP / 64], base;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t i = (int64_t)blockIdx.x * PREP + tid;
+  const int h = i < n_rows ? hist[i] : 0;
+  const bool v = h > 0;
+  const unsigned long long bv = __ballot(v);
+  if (lane == 0) sv[w] = __popcll(bv);
+  if (tid == 0) {
+    int a = 0;
+    for (int k = 0; k < (int)blockIdx.x; ++k) a += blockcnt[k];
+    base = a;
+  }
+  __syncthreads();
+  int ov = base;
+  for (int k = 0; k < w; ++k) ov += sv[k];
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  ov += __popcll(bv & below);
+  if (v) {
+    neg_item[ov] = (int)i;
+    neg_rc[ov] = rnorm[i];
+    neg_mult[ov] = (float)h;
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == PREP - 1) counts[2] = ov + (v ? 1 : 0);
 }
 
 // ---- main kernel -------------------------------------------------------------------------------------
@@ -123,10 +165,11 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   elem* const sQ = reinterpret_cast<elem*>(smem + MAIN_BYTES);
   __shared__ __attribute__((aligned(16))) int sNid[BN];
   __shared__ __attribute__((aligned(16))) float sRc[BN];
+  __shared__ __attribute__((aligned(16))) float sMul[BN];  // multiplicity of each column's item (LossArgs)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
   const int Nq = a.counts[1];
-  const int N = (a.mode == XFMR_NEG_CATALOG) ? (int)a.n_rows : a.counts[0];
+  const int N = (a.mode == XFMR_NEG_CATALOG) ? (int)a.n_rows : a.counts[2];  // columns = distinct negative items
   const int qb0 = blockIdx.x * QB;
   if (qb0 >= Nq) return;
   const int ntiles = (N + BN - 1) / BN;
@@ -189,7 +232,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   // pass p -> row block p&1, column block p>>1. ET writes then land 2-way conflicted at worst.
   float4 pre[NPASS][2];
   int pre_nid = -1;
-  float pre_rc = 0.f;
+  float pre_rc = 0.f, pre_mu = 1.f;
   const int st_rho = lane & 3, st_c = lane >> 2;
   auto item_of = [&](int j) -> int {
     if (j >= N) return -1;
@@ -211,6 +254,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
     if (tid < BN) {
       pre_nid = item_of(j0 + tid);
       pre_rc = pre_nid >= 0 ? a.rnorm[pre_nid] : 0.f;
+      pre_mu = (pre_nid >= 0 && a.neg_mult && !catalog) ? a.neg_mult[j0 + tid] : 1.f;
     }
   };
   auto commit = [&]() {
@@ -226,6 +270,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
     if (tid < BN) {
       sNid[tid] = pre_nid;
       sRc[tid] = pre_rc;
+      sMul[tid] = pre_mu;
     }
   };
 
@@ -259,7 +304,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
         }
         continue;
       }
-      loss_epilogue<ALL, true>(s, st, o, kc, &sNid[sb * 32], &sRc[sb * 32], hh);
+      loss_epilogue<ALL, true>(s, st, o, kc, &sNid[sb * 32], &sRc[sb * 32], &sMul[sb * 32], hh);
       if (do_grad) {
 #pragma unroll
         for (int i = 0; i < H / 32; ++i) P::tile_xb(o[i], sET, LDT, i * 32, sb * 32, s);
@@ -308,14 +353,14 @@ __device__ __forceinline__ float hard_unkey(unsigned k) {
 }
 template <class F>
 __device__ void radix_select(F get, int N, int k, unsigned* hist, int* sh, float& tau, float& rho) {
-  // get(j, &value) -> counted?
+  // get(j, &value) -> weight of column j among the counted negatives (its item's multiplicity, 0 = not counted)
   const int tid = threadIdx.x;
   if (tid == 0) sh[3] = 0;
   __syncthreads();
   int n = 0;
   for (int j = tid; j < N; j += 256) {
     float v;
-    n += get(j, v) ? 1 : 0;
+    n += get(j, v);
   }
   if (n) atomicAdd(&sh[3], n);
   __syncthreads();
@@ -331,9 +376,11 @@ __device__ void radix_select(F get, int N, int k, unsigned* hist, int* sh, float
     const int shift = 8 * p;
     for (int j = tid; j < N; j += 256) {
       float v;
-      if (!get(j, v)) continue;
+      const int wgt = get(j, v);
+      if (!wgt) continue;
       const unsigned key = hard_key(v);
-      if (p == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      if (p == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
+        atomicAdd(&hist[(key >> shift) & 255u], (unsigned)wgt);
     }
     __syncthreads();
     if (tid == 0) {
@@ -355,7 +402,7 @@ __device__ void radix_select(F get, int N, int k, unsigned* hist, int* sh, float
 
 struct SelectArgs {
   const float* dump; int64_t dump_ld; const float2* qinfo; const int* counts; const int* neg_item;
-  const float* neg_rc; const float* rnorm; const int* qpos; float4* tau;
+  const float* neg_rc; const float* neg_mult; const float* rnorm; const int* qpos; float4* tau;
   int mode, mask_fn, k; int64_t n_rows;
 };
 __global__ __launch_bounds__(256) void hard_select_kernel(SelectArgs a) {
@@ -364,9 +411,10 @@ __global__ __launch_bounds__(256) void hard_select_kernel(SelectArgs a) {
   const int qi = blockIdx.x;
   if (qi >= a.counts[1]) return;
   const bool catalog = a.mode == XFMR_NEG_CATALOG;
-  const int N = catalog ? (int)a.n_rows : a.counts[0];
+  const int N = catalog ? (int)a.n_rows : a.counts[2];       // columns (distinct items)
+  const int Ncols = catalog ? (int)a.n_rows : a.counts[0];   // negative columns of the reference's logits
   float4 out = make_float4(-INFINITY, 1.f, -INFINITY, 1.f);
-  if (a.k > 0 && a.k < N + 1) {  // losses.py:312-316: k >= number of columns (1 + N) switches the restriction off
+  if (a.k > 0 && a.k < Ncols + 1) {  // losses.py:312-316: k >= number of columns (1 + N) switches the restriction off
     const int pos_item = a.qpos[qi];
     const float2 qf = a.qinfo[qi];
     const float pos_dot = qf.x, rq = qf.y;
@@ -377,14 +425,16 @@ __global__ __launch_bounds__(256) void hard_select_kernel(SelectArgs a) {
       const int it = catalog ? j : a.neg_item[j];
       const bool same = it == pos_item;
       v = same ? pos_dot : row[j];
-      return !(catalog && same) && (mask_fn ? v < pos_dot : true);
+      const bool counted = !(catalog && same) && (mask_fn ? v < pos_dot : true);
+      return counted ? (catalog ? 1 : (int)a.neg_mult[j]) : 0;
     };
     auto get_c = [&](int j, float& v) {
       const int it = catalog ? j : a.neg_item[j];
       const bool same = it == pos_item;
       const float sv = same ? pos_dot : row[j];
       v = same ? cpos : sv * rq * (catalog ? a.rnorm[j] : a.neg_rc[j]);
-      return !(catalog && same) && (mask_fn ? v < cpos : true);
+      const bool counted = !(catalog && same) && (mask_fn ? v < cpos : true);
+      return counted ? (catalog ? 1 : (int)a.neg_mult[j]) : 0;
     };
     radix_select(get_d, N, a.k, hist, sh, out.x, out.y);
     __syncthreads();
@@ -599,6 +649,7 @@ struct Plan {
   int nsplit;
   size_t off_part2, off_negrc, off_tot;
   size_t off_dump, off_tau, off_qinfo; int64_t dump_ld;  // num_hard_negatives only
+  size_t off_hist, off_dcnt, off_negmul; int ndblocks;    // distinct-item compaction
   size_t off_counts, off_blockcnt, off_neg, off_qrow, off_qpos, off_part, off_partO, off_block, total;
   int nblocks;
 };
@@ -619,6 +670,10 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   p.off_blockcnt = o; o += up256((size_t)((T + PREP - 1) / PREP) * sizeof(int2));
   p.off_neg = o; o += up256((size_t)T * 4);
   p.off_negrc = o; o += up256((size_t)T * 4);
+  p.off_negmul = o; o += up256((size_t)T * 4);
+  p.ndblocks = (int)((n_rows + PREP - 1) / PREP);
+  p.off_hist = o; o += up256((size_t)n_rows * 4);
+  p.off_dcnt = o; o += up256((size_t)p.ndblocks * 4);
   p.off_qrow = o; o += up256((size_t)T * 4);
   p.off_qpos = o; o += up256((size_t)T * 4);
   p.off_part = o; o += up256((size_t)ns * T * REC * 4);
@@ -707,6 +762,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   a.tok = tok; a.table = table; a.rnorm = table_rnorm; a.n_rows = n_rows; a.counts = counts;
   a.neg_item = cfg->mode == XFMR_NEG_SHARED ? neg_item : nullptr;
   a.neg_rc = (const float*)(ws + p.off_negrc);
+  a.neg_mult = cfg->mode == XFMR_NEG_SHARED ? (const float*)(ws + p.off_negmul) : nullptr;
   a.qrow = qrow; a.qpos = qpos; a.part = (float*)(ws + p.off_part); a.partO = (float*)(ws + p.off_partO);
   a.T = T; a.nsplit = p.nsplit; a.train_head = cfg->train_head; a.mask_fn = cfg->mask_false_negatives;
   a.mode = cfg->mode; a.need_grad = d_tok != nullptr; a.scale = cfg->scale; a.margin = cfg->margin;
@@ -728,7 +784,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
     if (rc) return rc;
     SelectArgs s{};
     s.dump = d.dump; s.dump_ld = p.dump_ld; s.qinfo = d.qinfo; s.counts = counts; s.neg_item = neg_item;
-    s.neg_rc = a.neg_rc; s.rnorm = table_rnorm; s.qpos = qpos; s.tau = (float4*)(ws + p.off_tau);
+    s.neg_rc = a.neg_rc; s.neg_mult = a.neg_mult; s.rnorm = table_rnorm; s.qpos = qpos; s.tau = (float4*)(ws + p.off_tau);
     s.mode = cfg->mode; s.mask_fn = cfg->mask_false_negatives; s.k = cfg->num_hard_negatives; s.n_rows = n_rows;
     hipLaunchKernelGGL(hard_select_kernel, dim3((unsigned)T), dim3(256), 0, st, s);
     XF_LAUNCH_CHECK();
@@ -780,6 +836,19 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
                           (double*)(ws + p.off_tot), st);
 }
 
+// histogram over the catalogue -> distinct negative items, inverse norms, multiplicities, counts[2]
+static int launch_distinct(unsigned char* ws, const Plan& p, int64_t n_rows, const float* table_rnorm, hipStream_t st) {
+  const int* hist = (const int*)(ws + p.off_hist);
+  int* dcnt = (int*)(ws + p.off_dcnt);
+  hipLaunchKernelGGL(distinct_count_kernel, dim3(p.ndblocks), dim3(PREP), 0, st, hist, n_rows, dcnt);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(distinct_write_kernel, dim3(p.ndblocks), dim3(PREP), 0, st, hist, n_rows, (const int*)dcnt,
+                     table_rnorm, (int*)(ws + p.off_counts), (int*)(ws + p.off_neg), (float*)(ws + p.off_negrc),
+                     (float*)(ws + p.off_negmul));
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
 static int check_loss_args(const xfmr_loss_cfg* cfg, const float* tok, const float* table, const float* rnorm,
                            float* losses, float* stats, void* workspace, float* d_tok, int64_t rows, int64_t n_rows) {
   if (!cfg || !tok || !table || !rnorm || !losses || !stats || !workspace) return XFMR_EINVAL;
@@ -807,11 +876,16 @@ int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t*
   int2* blockcnt = (int2*)(ws + p.off_blockcnt);
   hipLaunchKernelGGL(prepare_count_kernel, dim3(nprep), dim3(PREP), 0, st, key_mask, pos_idx, T, blockcnt);
   XF_LAUNCH_CHECK();
+  const bool shared = cfg->mode == XFMR_NEG_SHARED;
+  int* hist = (int*)(ws + p.off_hist);
+  if (shared && hipMemsetAsync(hist, 0, (size_t)n_rows * sizeof(int), st) != hipSuccess) return XFMR_EHIP;
   hipLaunchKernelGGL(prepare_write_kernel, dim3(nprep), dim3(PREP), 0, st, key_mask, pos_idx,
-                     cfg->mode == XFMR_NEG_SHARED ? neg_idx : (const int64_t*)nullptr, T, n_rows,
-                     (const int2*)blockcnt, table_rnorm, (int*)(ws + p.off_counts), (int*)(ws + p.off_neg),
-                     (float*)(ws + p.off_negrc), (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
+                     shared ? neg_idx : (const int64_t*)nullptr, T, n_rows, (const int2*)blockcnt,
+                     (int*)(ws + p.off_counts), hist, (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
   XF_LAUNCH_CHECK();
+  if (shared) {
+    if (int rc = launch_distinct(ws, p, n_rows, table_rnorm, st)) return rc;
+  }
   if (d_tok && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
   return run_loss(cfg, tok, table, table_rnorm, table_bf16, n_rows, T, H, losses, stats, d_tok, ws, p, st);
@@ -843,12 +917,16 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
   const int T = (int)rows;
+  const bool shared = cfg->mode == XFMR_NEG_SHARED;
+  int* hist = (int*)(ws + p.off_hist);
+  if (shared && hipMemsetAsync(hist, 0, (size_t)n_rows * sizeof(int), st) != hipSuccess) return XFMR_EHIP;
   hipLaunchKernelGGL(prepare_lists_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, pos_items,
-                     cfg->mode == XFMR_NEG_SHARED ? neg_items : (const int64_t*)nullptr, (int)n_query,
-                     (int)(cfg->mode == XFMR_NEG_SHARED ? n_neg : 0), n_rows, table_rnorm,
-                     (int*)(ws + p.off_counts), (int*)(ws + p.off_neg), (float*)(ws + p.off_negrc),
-                     (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
+                     shared ? neg_items : (const int64_t*)nullptr, (int)n_query, (int)(shared ? n_neg : 0), n_rows,
+                     (int*)(ws + p.off_counts), hist, (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
   XF_LAUNCH_CHECK();
+  if (shared) {
+    if (int rc = launch_distinct(ws, p, n_rows, table_rnorm, st)) return rc;
+  }
   if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
   return run_loss(cfg, query, table, table_rnorm, table_bf16, n_rows, T, H, losses, stats, d_query, ws, p, st);
 }

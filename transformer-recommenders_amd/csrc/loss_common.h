@@ -19,9 +19,15 @@ constexpr int HEAD_INFONCE_MASKED = XFMR_NUM_LOSSES;
 
 struct LossArgs {
   const float* tok; const float* table; const float* rnorm; int64_t n_rows;
-  const int* counts;      // [0] = N valid positions, [1] = Np queries
-  const int* neg_item;    // [N] (shared mode) or null (catalogue mode: item j)
-  const float* neg_rc;    // [N] inverse norm of each negative's row (shared mode)
+  const int* counts;      // [0] = N valid positions (negative columns of the reference), [1] = Np queries,
+                          // [2] = Nd DISTINCT negative items (shared mode): the columns the kernels walk
+  // Shared mode: in-batch negatives repeat items (N positions draw from V items; N = 25 600 vs V = 3 883 on
+  // MovieLens-1M), and every per-column quantity -- logit, mask, each head's term, the gradient weight -- is a function
+  // of the ITEM. The columns are therefore the distinct items (ascending id) with their multiplicity as weight:
+  // sum_j f(s_ij) = sum_u mult_u f(s_iu), dQ_i = sum_u mult_u w_iu e_u. Exact, and Nd <= min(N, V) columns.
+  const int* neg_item;    // [Nd] (shared mode) or null (catalogue mode: item j)
+  const float* neg_rc;    // [Nd] inverse norm of each negative's row (shared mode)
+  const float* neg_mult;  // [Nd] multiplicity of the item among the N negatives (shared mode; null: 1)
   const int* qrow; const int* qpos;
   float* part; float* partO;
   // num_hard_negatives (losses.py:295-330), generic kernel only: `dump` != null turns the launch into a logits dump
@@ -50,7 +56,7 @@ struct RowConst {
 // HARD: weight every counted negative by its top-k weight (1 above the row's threshold, rho at it, 0 below).
 template <bool ALL, int HC, int NO, bool HARD = false>
 __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
-                                                const int* nid_sb, const float* rc_sb, int hh) {
+                                                const int* nid_sb, const float* rc_sb, const float* mu_sb, int hh) {
   float& cnt_d = st.cnt_d; float& m = st.m; float& l = st.l; float& nce = st.nce; float& hinge = st.hinge;
   float& logi = st.logi; float& cnt_c = st.cnt_c; float& contr = st.contr; float& ssum = st.ssum;
   float& ssq = st.ssq; float& smin = st.smin; float& smax = st.smax; float& sw = st.sw;
@@ -96,7 +102,6 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
   }
   // Every head's row reductions and the train head's gradient weight (left in s[r] for the second MFMA).
   // Branch-free per element; the `head` switches are wave-uniform.
-  float pn = 1.f, pl = 1.f;  // products of (1 + exp(-|x|)) of the counted elements: NCE and pairwise-logistic
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl0 = 8 * g + 4 * hh;
@@ -107,6 +112,8 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
       const float4 c4 = *reinterpret_cast<const float4*>(&rc_sb[jl0]);
       rc[0] = c4.x; rc[1] = c4.y; rc[2] = c4.z; rc[3] = c4.w;
     }
+    const float4 m4 = *reinterpret_cast<const float4*>(&mu_sb[jl0]);  // multiplicity of each column's item
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = 4 * g + u;
@@ -114,7 +121,7 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
       const bool same = nn[u] == pos_item;  // exact tie: the negative IS the positive item
       const float sv = same ? pos_dot : s[r];
       const bool excl = catalog & same;
-      float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? 1.f : 0.f;
+      float md = (valid & (mask_fn ? (sv < pos_dot) : true) & !excl) ? mu[u] : 0.f;
       if (HARD) md *= sv > k.tau_d ? 1.f : (sv == k.tau_d ? k.rho_d : 0.f);
       float w = 0.f;
       cnt_d += md;
@@ -126,13 +133,8 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
       }
       if (ALL || head == XFMR_LOSS_NCE) {
         const float t = xf_exp2(-fabsf(sv) * kLog2e);                    // exp(-|x|)
-        // softplus(x) = max(x, 0) + log(1 + exp(-|x|)); the log terms of the sub-block's 16 elements are taken as
-        // ONE log of their product (each factor is in [1, 2]): 2 transcendental issues per 16 elements, not 32
-        if (HARD) nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // md may be fractional
-        else {
-          nce = fmaf(fmaxf(sv, 0.f), md, nce);
-          pn *= fmaf(t, md, 1.f);
-        }
+        // softplus(x) = max(x, 0) + log(1 + exp(-|x|))
+        nce = fmaf(fmaxf(sv, 0.f) + kLn2 * xf_log2(1.f + t), md, nce);  // md = multiplicity (or a top-k fraction)
         if (head == XFMR_LOSS_NCE) w = md * xf_rcp(1.f + t) * (sv >= 0.f ? 1.f : t);  // sigmoid(x)
       }
       if (ALL || head == XFMR_LOSS_PAIRWISE_HINGE || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
@@ -141,17 +143,13 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
         if (head == XFMR_LOSS_PAIRWISE_HINGE) w = d > 0.f ? md : 0.f;
         if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) {
           const float t = xf_exp2(-fabsf(d) * kLog2e);
-          if (HARD) logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
-          else {
-            logi = fmaf(fmaxf(d, 0.f), md, logi);
-            pl *= fmaf(t, md, 1.f);
-          }
+          logi = fmaf(fmaxf(d, 0.f) + kLn2 * xf_log2(1.f + t), md, logi);
           if (head == XFMR_LOSS_PAIRWISE_LOGISTIC) w = md * xf_rcp(1.f + t) * (d >= 0.f ? 1.f : t);
         }
       }
       if (ALL || cos_head) {
         const float c = same ? cpos : sv * rq * rc[u];
-        float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? 1.f : 0.f;
+        float mc = (valid & (mask_fn ? (c < cpos) : true) & !excl) ? mu[u] : 0.f;
         if (HARD) mc *= c > k.tau_c ? 1.f : (c == k.tau_c ? k.rho_c : 0.f);
         cnt_c += mc;
         const float d = c - 1.f + k.margin;
@@ -172,8 +170,6 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
     // live at once and spills at 2 waves/SIMD)
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (ALL || head == XFMR_LOSS_NCE) nce = fmaf(kLn2, xf_log2(pn), nce);
-  if (ALL || head == XFMR_LOSS_PAIRWISE_LOGISTIC) logi = fmaf(kLn2, xf_log2(pl), logi);
 }
 
 // The common case of the gradient pass, stripped to what it needs: InfoNCE head, false-negative masking on, every
@@ -182,19 +178,22 @@ __device__ __forceinline__ void loss_epilogue_t(f32x16& s, RowState& st, f32x16 
 // softmax term (sum of weights == l) and the count is an integer add-with-carry: ~8 issue slots per element
 // instead of ~23 (VALU issue, not the matrix pipe, bounds this kernel).
 template <bool CHECK_VALID>
-__device__ __forceinline__ void loss_epilogue_infonce_masked(f32x16& s, float& l, int& cnt, float pos_dot, float sc2,
-                                                             float m, int pos_item, const int* nid_sb, int hh) {
+__device__ __forceinline__ void loss_epilogue_infonce_masked(f32x16& s, float& l, float& cnt, float pos_dot, float sc2,
+                                                             float m, int pos_item, const int* nid_sb,
+                                                             const float* mu_sb, int hh) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[8 * g + 4 * hh]);
     const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+    const float4 m4 = *reinterpret_cast<const float4*>(&mu_sb[8 * g + 4 * hh]);
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = 4 * g + u;
       bool counted = (s[r] < pos_dot) & (nn[u] != pos_item);
       if (CHECK_VALID) counted &= nn[u] >= 0;  // only the last tile of the range can hold past-the-end columns
-      cnt += counted ? 1 : 0;
-      const float e = xf_exp2(counted ? fmaf(s[r], sc2, -m) : -INFINITY);
+      cnt += counted ? mu[u] : 0.f;
+      const float e = xf_exp2(counted ? fmaf(s[r], sc2, -m) : -INFINITY) * mu[u];
       l += e;
       s[r] = e;
     }
@@ -204,30 +203,30 @@ __device__ __forceinline__ void loss_epilogue_infonce_masked(f32x16& s, float& l
 // runtime head -> compile-time head (one wave-uniform switch per sub-block instead of ~6 per element)
 template <bool ALL, bool GRAD, int NO, bool HARD = false>
 __device__ __forceinline__ void loss_epilogue_h(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
-                                                const int* nid_sb, const float* rc_sb, int hh) {
+                                                const int* nid_sb, const float* rc_sb, const float* mu_sb, int hh) {
   if (!GRAD) {
-    if (ALL) return loss_epilogue_t<true, -1, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+    if (ALL) return loss_epilogue_t<true, -1, NO, HARD>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
     // values of ONE head: its accumulators are selected by the head, no weights needed -> reuse the
     // weighted variants (the weight computation is dead code without the second product)
   }
   switch (k.head) {
-    case XFMR_LOSS_ALIGNMENT: return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+    case XFMR_LOSS_ALIGNMENT: return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT, NO, HARD>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
     case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:
-      return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT_CONTRASTIVE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+      return loss_epilogue_t<ALL, XFMR_LOSS_ALIGNMENT_CONTRASTIVE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
     case XFMR_LOSS_CONTRASTIVE:
-      return loss_epilogue_t<ALL, XFMR_LOSS_CONTRASTIVE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
-    case XFMR_LOSS_INFONCE: return loss_epilogue_t<ALL, XFMR_LOSS_INFONCE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
-    case XFMR_LOSS_NCE: return loss_epilogue_t<ALL, XFMR_LOSS_NCE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+      return loss_epilogue_t<ALL, XFMR_LOSS_CONTRASTIVE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
+    case XFMR_LOSS_INFONCE: return loss_epilogue_t<ALL, XFMR_LOSS_INFONCE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
+    case XFMR_LOSS_NCE: return loss_epilogue_t<ALL, XFMR_LOSS_NCE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
     case XFMR_LOSS_PAIRWISE_HINGE:
-      return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_HINGE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
-    default: return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_LOGISTIC, NO, HARD>(s, st, o, k, nid_sb, rc_sb, hh);
+      return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_HINGE, NO, HARD>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
+    default: return loss_epilogue_t<ALL, XFMR_LOSS_PAIRWISE_LOGISTIC, NO, HARD>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
   }
 }
 template <bool ALL, bool GRAD, int NO>
 __device__ __forceinline__ void loss_epilogue(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
-                                              const int* nid_sb, const float* rc_sb, int hh) {
-  if (k.hard) loss_epilogue_h<ALL, GRAD, NO, true>(s, st, o, k, nid_sb, rc_sb, hh);
-  else loss_epilogue_h<ALL, GRAD, NO, false>(s, st, o, k, nid_sb, rc_sb, hh);
+                                              const int* nid_sb, const float* rc_sb, const float* mu_sb, int hh) {
+  if (k.hard) loss_epilogue_h<ALL, GRAD, NO, true>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
+  else loss_epilogue_h<ALL, GRAD, NO, false>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
 }
 
 // halves of a lane pair (l, l^32) hold disjoint negatives of the same query: combine, then one lane writes
