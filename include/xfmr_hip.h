@@ -244,6 +244,10 @@ enum {
   XFMR_STAT_POS_MEAN = 3, XFMR_STAT_POS_STD = 4, XFMR_STAT_POS_MIN = 5, XFMR_STAT_POS_MAX = 6,
   XFMR_STAT_NEG_MEAN = 7, XFMR_STAT_NEG_STD = 8, XFMR_STAT_NEG_MIN = 9, XFMR_STAT_NEG_MAX = 10,
   XFMR_STAT_NEG_COUNT = 11,  /* number of (row, column) pairs counted as negatives */
+  XFMR_STAT_NEG_DISTINCT = 12, /* columns the kernels walked: distinct negative items (shared mode), catalogue rows
+                                  (catalogue mode), C (dense form). In-batch negatives repeat items; every per-column
+                                  term is a function of the item, so it is evaluated once per distinct item and
+                                  weighted by the item's multiplicity (exactly the reference's sums).             */
   XFMR_NUM_STATS = 16
 };
 typedef struct xfmr_loss_cfg {

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(DenseArgs a) {
 __global__ void dense_counts_kernel(int* counts, int c, int n) {
   counts[0] = c;
   counts[1] = n;
+  counts[2] = c;
 }
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }

@@ -629,6 +629,7 @@ __global__ void loss_final_kernel(const double* tot, const int* counts, int mode
     const double nq = (double)Nq;
     stats[XFMR_STAT_N_VALID] = (float)((mode == XFMR_NEG_CATALOG) ? (int)n_rows : counts[0]);
     stats[XFMR_STAT_N_QUERY] = (float)Nq;
+    stats[XFMR_STAT_NEG_DISTINCT] = (float)((mode == XFMR_NEG_CATALOG) ? (int)n_rows : counts[2]);
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     stats[XFMR_STAT_NEG_DENSITY] = (float)(Nq > 0 ? tot[8] / nq : nan);
     stats[XFMR_STAT_POS_MEAN] = (float)(Nq > 0 ? tot[9] / nq : nan);

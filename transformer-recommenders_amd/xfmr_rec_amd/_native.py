@@ -33,7 +33,7 @@ LOSS_IDS = {
 }
 STAT = dict(
     n_valid=0, n_query=1, neg_density=2, pos_mean=3, pos_std=4, pos_min=5, pos_max=6,
-    neg_mean=7, neg_std=8, neg_min=9, neg_max=10, neg_count=11,
+    neg_mean=7, neg_std=8, neg_min=9, neg_max=10, neg_count=11, neg_distinct=12,
 )
 
 
