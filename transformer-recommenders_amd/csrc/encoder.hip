@@ -59,8 +59,15 @@ struct LayerActs {
   void *qkv, *ctx, *f1, *g;                                           // bf16 when mixed
   float *lse, *pre1, *mean1, *rstd1, *x1, *pre2, *mean2, *rstd2, *x2;  // always fp32
 };
+// Per-layer reduction inputs of the backward pass, reduced by ONE launch at its end (xf_multi_rowsum): split-K slabs
+// of the four weight gradients, partial rows of the two bias gradients that are column sums (b1, bqkv -- produced by
+// the dW GEMMs themselves), LayerNorm partial records (d gamma, d beta, and the bias gradients bo / b2).
+struct RedBufs {
+  float *w2, *w1, *wo, *wqkv, *b1, *bqkv, *ln2, *ln1;
+};
 struct Acts {
   float *emb_pre, *emb_mean, *emb_rstd, *x0;
+  float* emb_ln;  // embedding LayerNorm partial records
   float *dA, *dB;
   void *dLin, *dCtx, *dI, *dQKV;  // bf16 when mixed
   void* scratch;  // ln-bwd partials / dW slabs / colsum partials (used one at a time)
@@ -79,7 +86,7 @@ bool mixed_storage(const xfmr_encoder_cfg* c) {
 }
 
 // Carves `base` (may be null: size query). Layer i's activations are returned in *la when i >= 0.
-Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs* la) {
+Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs* la, RedBufs* rb = nullptr) {
   const size_t T = (size_t)c->batch * c->seq_len, H = c->hidden, I = c->inter, A = c->heads;
   const size_t es = mixed_storage(c) ? 2 : 4;  // bytes per element of the MFMA-only tensors
   size_t o = 0;
@@ -106,6 +113,19 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   a.scratch = base ? base + o : nullptr;
   a.scratch_bytes = sc;
   o += up256(sc);
+  a.emb_ln = take(xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float));
+  for (int i = 0; i < c->layers; ++i) {
+    RedBufs r;
+    r.w2 = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)H, (int32_t)I) / sizeof(float));
+    r.w1 = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)I, (int32_t)H) / sizeof(float));
+    r.wo = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)H, (int32_t)H) / sizeof(float));
+    r.wqkv = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)(3 * H), (int32_t)H) / sizeof(float));
+    r.b1 = take(64 * I);      // <= 64 splits (dw_split_plan)
+    r.bqkv = take(64 * 3 * H);
+    r.ln2 = take(xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float));
+    r.ln1 = take(xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float));
+    if (i == layer && rb) *rb = r;
+  }
   for (int i = 0; i < c->layers; ++i) {
     LayerActs l;
     l.qkv = take_bytes(T * 3 * H * es); l.lse = take((size_t)c->batch * A * c->seq_len);
@@ -251,9 +271,16 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
                  sAB = mix ? (XF_S16_A | XF_S16_B) : 0;
   const XfDropout off = xf_make_dropout(0.f, 0, 0);
   float* dX = d_tok;  // gradient w.r.t. the current layer's output
+  XfReduceSeg segs[12 * 64 + 2];
+  int nseg = 0;
+  auto seg = [&](const float* src, float* dst, int rows, int64_t cols, int64_t ld) {
+    segs[nseg++] = XfReduceSeg{src, dst, rows, (int)cols, (int)ld, 0};
+  };
+  if (cfg->layers > 64) return XFMR_EUNSUPPORTED;
   for (int i = cfg->layers - 1; i >= 0; --i) {
     LayerActs l;
-    carve(cfg, base, i, &l);
+    RedBufs r;
+    carve(cfg, base, i, &l, &r);
     const LayerParams p = layer_params(cfg, i);
     LayerActs prev;
     const float* x_in = a.x0;
@@ -261,35 +288,52 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       carve(cfg, base, i - 1, &prev);
       x_in = prev.x2;
     }
+    int blocks = 0, splits = 0;
     // LayerNorm 2 -> dA = d(pre2); d_lin = gradient of the FFN output Linear (dropout-scaled copy of it)
     const bool lin_copy = hdrop || mix;  // without dropout and with fp32 storage d_lin IS dx
     XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, lin_copy ? a.dLin : nullptr, mix,
-                                 grads + p.ln2g, grads + p.ln2b, grads + p.b2, T, H, off,
-                                 xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_ffn(i)), a.scratch, st));
+                                 nullptr, nullptr, nullptr, T, H, off,
+                                 xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_ffn(i)), r.ln2, st, &blocks));
+    seg(r.ln2, grads + p.ln2g, blocks, H, 3 * H);
+    seg(r.ln2 + H, grads + p.ln2b, blocks, H, 3 * H);
+    seg(r.ln2 + 2 * H, grads + p.b2, blocks, H, 3 * H);
     const void* dlin = lin_copy ? a.dLin : (const void*)a.dA;
-    XF_TRY(xf_linear_bwd_dw_ex(dlin, l.g, grads + p.w2, T, H, I, prec, a.scratch, a.scratch_bytes, sAB, st));
+    XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, st));
+    seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
     XF_TRY(xf_linear_bwd_dx_ex(dlin, params + p.w2, a.dI, T, H, I, nullptr, l.f1, prec, sA | sC | sP, st));
-    XF_TRY(xf_colsum_ex(a.dI, mix, grads + p.b1, T, I, a.scratch, st));
-    XF_TRY(xf_linear_bwd_dw_ex(a.dI, l.x1, grads + p.w1, T, I, H, prec, a.scratch, a.scratch_bytes, sA, st));
+    XF_TRY(xf_linear_bwd_dw_deferred(a.dI, l.x1, T, I, H, prec, sA, r.w1, r.b1, &splits, st));  // + b1 partial rows
+    seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
+    seg(r.b1, grads + p.b1, splits, I, I);
     XF_TRY(xf_linear_bwd_dx_ex(a.dI, params + p.w1, a.dA, T, I, H, a.dA, nullptr, prec, sA, st));  // += d(pre2)
     // LayerNorm 1 -> dX = d(pre1)
     XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, lin_copy ? a.dLin : nullptr, mix,
-                                 grads + p.ln1g, grads + p.ln1b, grads + p.bo, T, H, off,
-                                 xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_out(i)), a.scratch, st));
+                                 nullptr, nullptr, nullptr, T, H, off,
+                                 xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_out(i)), r.ln1, st, &blocks));
+    seg(r.ln1, grads + p.ln1g, blocks, H, 3 * H);
+    seg(r.ln1 + H, grads + p.ln1b, blocks, H, 3 * H);
+    seg(r.ln1 + 2 * H, grads + p.bo, blocks, H, 3 * H);
     dlin = lin_copy ? a.dLin : (const void*)dX;
-    XF_TRY(xf_linear_bwd_dw_ex(dlin, l.ctx, grads + p.wo, T, H, H, prec, a.scratch, a.scratch_bytes, sAB, st));
+    XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.ctx, T, H, H, prec, sAB, r.wo, nullptr, &splits, st));
+    seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
     XF_TRY(xf_linear_bwd_dx_ex(dlin, params + p.wo, a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC, st));  // d(ctx)
     XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, a.dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
                           site_attn(i), prec, mix, st));
-    XF_TRY(xf_colsum_ex(a.dQKV, mix, grads + p.bqkv, T, 3 * H, a.scratch, st));
-    XF_TRY(xf_linear_bwd_dw_ex(a.dQKV, x_in, grads + p.wqkv, T, 3 * H, H, prec, a.scratch, a.scratch_bytes, sA, st));
+    XF_TRY(xf_linear_bwd_dw_deferred(a.dQKV, x_in, T, 3 * H, H, prec, sA, r.wqkv, r.bqkv, &splits, st));
+    seg(r.wqkv, grads + p.wqkv, splits, (int64_t)3 * H * H, (int64_t)3 * H * H);
+    seg(r.bqkv, grads + p.bqkv, splits, 3 * H, 3 * H);
     XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, params + p.wqkv, dX, T, 3 * H, H, dX, nullptr, prec, sA, st));  // += d(pre1)
   }
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
-  XF_TRY(xf_layernorm_bwd_impl(dX, a.emb_pre, a.emb_mean, a.emb_rstd, params + pl.eg, a.dA, nullptr, false, grads + pl.eg,
-                               grads + pl.eb, nullptr, T, H,
-                               xf_make_dropout(cfg->hidden_dropout, cfg->seed, SITE_EMB), off, a.scratch, st));
+  {
+    int blocks = 0;
+    XF_TRY(xf_layernorm_bwd_impl(dX, a.emb_pre, a.emb_mean, a.emb_rstd, params + pl.eg, a.dA, nullptr, false, nullptr,
+                                 nullptr, nullptr, T, H, xf_make_dropout(cfg->hidden_dropout, cfg->seed, SITE_EMB), off,
+                                 a.emb_ln, st, &blocks));
+    seg(a.emb_ln, grads + pl.eg, blocks, H, 3 * H);
+    seg(a.emb_ln + H, grads + pl.eb, blocks, H, 3 * H);
+  }
+  XF_TRY(xf_multi_rowsum(segs, nseg, st));  // every weight / bias / LayerNorm gradient of the encoder, one launch
   XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
   return XFMR_OK;
 }

@@ -26,6 +26,7 @@ struct GemmArgs {
   const void* P;          // pre-activation for gelu' [M,ldc]
   void* C2;               // pre-activation output for EPI_GELU
   uint32_t s16;           // XF_S16_* storage mask (bf16 policy only)
+  float* bias_part;       // EPI_SPLITK with A' = dy^T: row sums of A' over this split's K range -> [splits][M]
   XfDropout drop;
 };
 
@@ -104,6 +105,17 @@ struct OperandTile {
         }
         reg[i] = v;
       }
+    }
+  }
+  // TRANS tiles only: every thread's pieces cover the SAME 4 operand rows (256 % (ROWS/4) == 0) at different k:
+  // acc += the pieces in flight = this thread's share of the row sums over k (the bias gradient when A' = dy^T)
+  template <bool S16>
+  __device__ __forceinline__ void add_rowsum(float4& acc) const {
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+      float4 v = reg[i];
+      if (S16) v = xf_bf16x4_to_f32(make_uint2(__float_as_uint(reg[i].x), __float_as_uint(reg[i].y)));
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
   template <bool S16>
@@ -212,6 +224,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   TileA ta;
   TileB tb;
+  const bool do_bias = (EPI == EPI_SPLITK) && TA && g.bias_part != nullptr && blockIdx.x == 0;
+  float4 bsum = make_float4(0, 0, 0, 0);
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
     ta.template load<a16>(g.A, g.lda, m0, g.M, kbeg, kend);
@@ -219,6 +233,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
+    if (do_bias) ta.template add_rowsum<a16>(bsum);
     ta.template commit<a16>(sA);
     tb.template commit<b16>(sB);
     __syncthreads();
@@ -246,6 +261,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // epilogue (C, residual, pre-activation) is a 16-byte (8-byte for bf16) row-contiguous piece: one wave
   // instruction covers 8 rows x 128 B instead of 2 rows x 32 scattered 4-byte (or 2-byte) elements.
   __syncthreads();  // everyone is done with the operand images the scratch aliases
+  if (do_bias) {  // combine the 256 / (BM/4) threads that share an operand row quad, fixed order
+    constexpr int R4 = BM / 4, G = 256 / R4;
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < R4) {
+      float4 s = red[threadIdx.x];
+#pragma unroll
+      for (int q = 1; q < G; ++q) {
+        const float4 v = red[threadIdx.x + q * R4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int64_t m = m0 + 4 * threadIdx.x;
+      float* dst = g.bias_part + (int64_t)blockIdx.z * g.M + m;
+      if (m < g.M) dst[0] = s.x;
+      if (m + 1 < g.M) dst[1] = s.y;
+      if (m + 2 < g.M) dst[2] = s.z;
+      if (m + 3 < g.M) dst[3] = s.w;
+    }
+    __syncthreads();
+  }
   float* const scr = reinterpret_cast<float*>(smem) + wid * (32 * SCR_LD);
   const int64_t zoff = (EPI == EPI_SPLITK) ? (int64_t)blockIdx.z * g.M * g.ldc : 0;
   const int prow = lane >> 3, c4 = (lane & 7) * 4;
@@ -340,6 +376,33 @@ int launch_rowsum(float* dst, const T* src, int64_t rows, int64_t cols, int64_t 
                      rows, cols, rows_per);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
+}
+
+// Several row reductions in one launch: blockIdx.y = segment, blockIdx.x = block of 64 columns (segments with
+// fewer columns leave their extra blocks idle). Same per-column arithmetic as rowsum_kernel.
+struct MultiSegs { XfReduceSeg s[64]; };
+__global__ __launch_bounds__(256) void multi_rowsum_kernel(MultiSegs m) {
+  __shared__ float red[4][64];
+  const XfReduceSeg sg = m.s[blockIdx.y];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  if (blockIdx.x * 64 >= sg.cols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < sg.cols) {
+    const float* src = sg.src + col;
+    const int64_t ld = sg.ld;
+    int r = rg;
+    for (; r + 12 < sg.rows; r += 16) {
+      s0 += src[r * ld];
+      s1 += src[(r + 4) * ld];
+      s2 += src[(r + 8) * ld];
+      s3 += src[(r + 12) * ld];
+    }
+    for (; r < sg.rows; r += 4) s0 += src[r * ld];
+  }
+  red[rg][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && col < sg.cols) sg.dst[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // Tuning override for experiments: XFMR_GEMM_TILE="bm,bn,bk" (64|128, 64|128, 32|128) forces the tile.
@@ -497,6 +560,41 @@ int xf_linear_bwd_dw_ex(const void* dy, const void* x, float* dw, int64_t M, int
   if (rc) return rc;
   const int64_t n = (int64_t)N * K;
   return launch_rowsum(dw, (const float*)workspace, splits, n, splits, st);
+}
+
+size_t xf_linear_bwd_dw_slab_bytes(int64_t M, int32_t N, int32_t K) { return xfmr_linear_bwd_dw_workspace(M, N, K); }
+
+int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t N, int32_t K, int32_t precision,
+                              uint32_t s16, float* slabs, float* bias_part, int* splits_out, hipStream_t st) {
+  if (!dy || !x || !slabs || !splits_out || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
+  if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
+  if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(slabs)) return XFMR_EALIGN;
+  if (s16 && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  int k_chunk;
+  const int splits = dw_split_plan(M, N, K, &k_chunk);
+  GemmArgs g{};
+  g.A = dy; g.B = x; g.C = slabs; g.lda = N; g.ldb = K; g.ldc = K;
+  g.M = N; g.N = K; g.K = (int)M; g.k_chunk = k_chunk;
+  g.s16 = s16 & (XF_S16_A | XF_S16_B); g.bias_part = bias_part;
+  g.drop = xf_make_dropout(0.f, 0, 0);
+  *splits_out = splits;
+  return dispatch_gemm<true, true, EPI_SPLITK, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, splits, precision, st);
+}
+
+int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st) {
+  for (int base = 0; base < nseg; base += 64) {
+    MultiSegs m{};
+    const int n = nseg - base < 64 ? nseg - base : 64;
+    int maxcols = 0;
+    for (int i = 0; i < n; ++i) {
+      m.s[i] = segs[base + i];
+      if (m.s[i].cols > maxcols) maxcols = m.s[i].cols;
+    }
+    if (maxcols <= 0) continue;
+    hipLaunchKernelGGL(multi_rowsum_kernel, dim3((unsigned)((maxcols + 63) / 64), (unsigned)n), dim3(256), 0, st, m);
+    XF_LAUNCH_CHECK();
+  }
+  return XFMR_OK;
 }
 
 int xfmr_linear_bwd_dw(const float* dy, const float* x, float* dw, int64_t M, int32_t N, int32_t K,

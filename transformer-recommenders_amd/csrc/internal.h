@@ -22,6 +22,16 @@ int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int
 int xf_linear_bwd_dw_ex(const void* dy, const void* x, float* dw, int64_t M, int32_t N, int32_t K, int32_t precision,
                         void* workspace, size_t workspace_bytes, uint32_t s16, hipStream_t st);
 int xf_colsum_ex(const void* a, bool a16, float* out, int64_t M, int32_t N, void* workspace, hipStream_t st);
+// Deferred form of the weight gradient for the whole-encoder backward: the split-K slabs [splits][N*K] are left in
+// `slabs` and, when bias_part is given, the column sums of dy (the Linear's bias gradient) are left as partial rows
+// [splits][N] -- both are reduced later by ONE xf_multi_rowsum launch for the whole backward instead of one
+// (dW) + two (bias) small launches per Linear. Returns the number of splits in *splits.
+size_t xf_linear_bwd_dw_slab_bytes(int64_t M, int32_t N, int32_t K);
+int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t N, int32_t K, int32_t precision,
+                              uint32_t s16, float* slabs, float* bias_part, int* splits, hipStream_t st);
+// dst[c] = sum_r src[r * ld + c], r < rows, c < cols, for every segment, in one launch (deterministic order)
+struct XfReduceSeg { const float* src; float* dst; int rows; int cols; int ld; int pad; };
+int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st);
 int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st);
 int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t A,
                    int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision, bool s16,
@@ -34,8 +44,10 @@ int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, co
 int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, const int* counts, int mode,
                      int64_t n_rows, float* losses, float* stats, double* tot, hipStream_t st);
 // d_lin (optional): the gradient of the Linear output feeding this LayerNorm (dropout-scaled dx), bf16 if lin16
+// d_gamma == d_beta == d_bias == nullptr defers the reduction of `partials` ([blocks][3][H], blocks returned in
+// *blocks_out) to the caller (xf_multi_rowsum)
 int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           float* dx, void* d_lin, bool lin16, float* d_gamma, float* d_beta, float* d_bias,
                           int64_t rows, int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials,
-                          hipStream_t st);
+                          hipStream_t st, int* blocks_out = nullptr);
 }

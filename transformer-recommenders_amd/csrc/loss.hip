@@ -662,6 +662,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   const int64_t tiles = (cols + BN - 1) / BN;
   int64_t ns = (1024 + qblocks / 2) / qblocks;  // ~1024 workgroups: two full rounds at 2 workgroups/CU
   if (ns > 16) ns = 16;
+  if (const char* e = getenv("XFMR_LOSS_NSPLIT")) ns = atoi(e);  // tuning experiments
   if (ns > tiles) ns = tiles;
   if (ns < 1) ns = 1;
   p.nsplit = (int)ns;

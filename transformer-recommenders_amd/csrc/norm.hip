@@ -532,7 +532,7 @@ size_t xfmr_layernorm_bwd_workspace(int64_t rows, int32_t H) {
 int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           float* dx, void* d_lin, bool lin16, float* d_gamma, float* d_beta, float* d_bias,
                           int64_t rows, int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials,
-                          hipStream_t st) {
+                          hipStream_t st, int* blocks_out) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !partials || rows <= 0 || H <= 0) return XFMR_EINVAL;
   if (drop_lin.on && !d_lin) return XFMR_EINVAL;
   LnBwdArgs a{};
@@ -553,6 +553,8 @@ int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, co
   else if (npl <= kMaxPerLane) hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, shmem, st, a);
   else return XFMR_EUNSUPPORTED;
   XF_LAUNCH_CHECK();
+  if (blocks_out) *blocks_out = blocks;
+  if (!d_gamma && !d_beta && !d_bias) return XFMR_OK;  // reduction deferred to the caller
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * H + 63) / 64), dim3(1024), 0, st, (const float*)partials,
                      blocks, H, d_gamma, d_beta, d_bias);
   XF_LAUNCH_CHECK();
