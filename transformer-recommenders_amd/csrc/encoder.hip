@@ -333,6 +333,8 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     seg(a.emb_ln, grads + pl.eg, blocks, H, 3 * H);
     seg(a.emb_ln + H, grads + pl.eb, blocks, H, 3 * H);
   }
+  // (Measured and not kept: the weight-gradient GEMMs on a side stream beside the dX -> LayerNorm -> attention chain.
+  // The kernels do overlap, and each slows down by what the overlap would have gained: 1.910 vs 1.904 ms/step.)
   XF_TRY(xf_multi_rowsum(segs, nseg, st));  // every weight / bias / LayerNorm gradient of the encoder, one launch
   XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
   return XFMR_OK;
