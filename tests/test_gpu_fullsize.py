@@ -1,0 +1,164 @@
+"""Size-independent properties at BASELINE.json's FULL sizes (configs 2, 4, 5), where the CPU oracle's materialised
+(Np, 1+N, H) candidate tensor no longer fits (21 GB at B=32 already): each test checks the product path through the
+C ABI against an identity the reference's arithmetic satisfies, with torch on the GPU only as the checker of small
+closed forms (a dense matmul / indexing), never as the thing under test.
+
+* config 2 (V=3883, L=200, H=128, B=128, in-batch shared negatives): the loss is a function of the MULTISET of
+  negatives -- shuffling the negative positions must not change any head, statistic or gradient (bit for bit: the
+  kernels walk distinct items in id order); two identical calls are bitwise equal; the InfoNCE gradient matches a
+  central finite difference along a random direction; sum over rows of softmax-type weights identity.
+* config 4 (V=27278, H=256, full-catalogue softmax): InfoNCE over CatalogCandidates == cross_entropy(Q E^T, pos)
+  computed densely by torch for a slice of rows that fits.
+* config 5 (V=1e6, L=512, H=256): embedding gather + key mask + LayerNorm input bit-exact against torch indexing
+  on 32 768 tokens; the CCL head runs at that vocabulary size.
+"""
+
+import pytest
+import torch
+
+from helpers import TOL, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _unit_table(V, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(V + 1, H, generator=g)
+    t = t / t.norm(dim=-1, keepdim=True)
+    t[0] = 0
+    return t
+
+
+@pytest.fixture(scope="module")
+def XL():
+    import xfmr_rec_amd.losses as m
+
+    return m
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from xfmr_rec_amd import ops as o
+
+    return o
+
+
+def _config2_inputs():
+    B, L, H, V = 128, 200, 128, 3883
+    g = torch.Generator().manual_seed(21)
+    table = _unit_table(V, H, 1234).to(DEV)
+    tok = torch.randn(B * L, H, generator=g).to(DEV)
+    lens = torch.randint(20, L + 1, (B,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).reshape(-1).to(torch.uint8).to(DEV)
+    pos = torch.randint(1, V + 1, (B * L,), generator=g).to(DEV)
+    neg = torch.randint(1, V + 1, (B * L,), generator=g).to(DEV)
+    return B, L, H, V, table, tok, mask, pos, neg
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_config2_full_size_loss_is_a_function_of_the_negative_multiset(ops, prec):
+    from xfmr_rec_amd import _native as N
+
+    B, L, H, V, table, tok, mask, pos, neg = _config2_inputs()
+    rn, tb = ops.table_prepare(table)
+    kw = dict(train_head="InfoNCELoss", all_heads=True, precision=prec, table_bf16=tb if prec == "bf16" else None)
+    l0, s0, d0 = ops.sampled_loss(tok, mask, pos, neg, table, rn, **kw)
+    # a permutation of the negatives AMONG THE VALID POSITIONS keeps the multiset of negative items
+    valid = mask.bool().nonzero().flatten()
+    perm = valid[torch.randperm(valid.numel(), generator=torch.Generator().manual_seed(5)).to(DEV)]
+    neg2 = neg.clone()
+    neg2[valid] = neg[perm]
+    l1, s1, d1 = ops.sampled_loss(tok, mask, pos, neg2, table, rn, **kw)
+    assert torch.equal(l0, l1) and torch.equal(s0, s1) and torch.equal(d0, d1)
+    # determinism
+    l2, s2, d2 = ops.sampled_loss(tok, mask, pos, neg, table, rn, **kw)
+    assert torch.equal(l0, l2) and torch.equal(d0, d2)
+    # the statistics are self-consistent with the batch
+    n_valid, n_query = int(s0[N.STAT["n_valid"]]), int(s0[N.STAT["n_query"]])
+    assert n_valid == int(mask.sum()) and n_query == int((mask.bool() & (pos != 0)).sum())
+    assert int(s0[N.STAT["neg_distinct"]]) == int(torch.unique(neg[mask.bool()]).numel())
+    assert 0.0 < float(s0[N.STAT["neg_density"]]) < 1.0
+    # train-head-only evaluation gives the same InfoNCE value and gradient as the all-heads evaluation
+    l3, _s3, d3 = ops.sampled_loss(tok, mask, pos, neg, table, rn, **(kw | {"all_heads": False}))
+    i = N.LOSS_IDS["InfoNCELoss"]
+    assert float(l3[i]) == pytest.approx(float(l0[i]), rel=1e-6)
+    assert rel_l2(d3, d0) <= 1e-6
+
+
+def test_config2_full_size_infonce_gradient_matches_finite_differences(ops):
+    """dL/dtok from the fused kernel (fp32 policy) against a central difference of its own loss value along a random
+    direction (false-negative masking off: the masked loss is only piecewise smooth)."""
+    from xfmr_rec_amd import _native as N
+
+    B, L, H, V, table, tok, mask, pos, neg = _config2_inputs()
+    rn = ops.table_rnorm(table)
+    kw = dict(train_head="InfoNCELoss", all_heads=False, precision="fp32", mask_false_negatives=False, scale=2.0)
+    i = N.LOSS_IDS["InfoNCELoss"]
+    _l, _s, d = ops.sampled_loss(tok, mask, pos, neg, table, rn, **kw)
+    g = torch.Generator().manual_seed(9)
+    u = torch.randn(tok.shape, generator=g).to(DEV)
+    eps = 1e-2
+    lp = ops.sampled_loss(tok + eps * u, mask, pos, neg, table, rn, need_grad=False, **kw)[0][i].double()
+    lm = ops.sampled_loss(tok - eps * u, mask, pos, neg, table, rn, need_grad=False, **kw)[0][i].double()
+    fd = float((lp - lm) / (2 * eps))
+    an = float((d.double() * u.double()).sum())
+    assert an == pytest.approx(fd, rel=2e-3), (an, fd)
+
+
+def test_config4_full_catalogue_softmax_equals_dense_cross_entropy(XL, ops):
+    """BASELINE config 4: V = 27 278, H = 256, full-catalogue softmax. The (Np x V) logits are never materialised by
+    the kernel; for 1 024 rows torch can materialise them and F.cross_entropy is the closed form."""
+    V, H, Np = 27278, 256, 1024
+    g = torch.Generator().manual_seed(31)
+    table = _unit_table(V, H, 77).to(DEV)
+    rn, tb = ops.table_prepare(table)
+    q = (3.0 * torch.randn(Np, H, generator=g)).to(DEV)
+    pos = torch.randint(1, V + 1, (Np,), generator=g).to(DEV)
+    cfg = XL.LossConfig(target_position=None, mask_false_negatives=False)
+    for prec in ("fp32", "bf16"):
+        qd = q.clone().requires_grad_(True)
+        got = XL.InfoNCELoss(cfg, precision=prec)(qd, XL.CatalogCandidates(table, rn, Np, table_bf16=tb), pos)
+        got.backward()
+        qr = q.clone().requires_grad_(True)
+        want = torch.nn.functional.cross_entropy(qr @ table.T, pos, reduction="sum")
+        want.backward()
+        assert abs(got.item() - want.item()) <= TOL[prec]["loss_rel"] * abs(want.item()), (prec, got.item(), want.item())
+        assert rel_l2(qd.grad, qr.grad) <= TOL[prec]["grad_l2"], prec
+
+
+def test_config5_million_item_gather_is_bit_exact_and_ccl_runs(XL, ops):
+    """BASELINE config 5: V = 1 000 000, L = 512, H = 256. Gather + key mask (models.py:336-343) bit-exact against
+    torch indexing; the CCL head (AlignmentContrastiveLoss) runs against in-batch negatives drawn from the 1M vocab."""
+    V, L, H, B = 1_000_000, 512, 256, 64
+    g = torch.Generator().manual_seed(41)
+    table = torch.randn(V + 1, H, generator=g)
+    table[0] = 0
+    table = table.to(DEV)
+    idx = torch.randint(0, V + 1, (B, L), generator=g)
+    idx[:, -37:] = 0  # right padding
+    idx = idx.to(DEV)
+    Hh = H
+    pos_emb = torch.zeros(L, Hh, device=DEV)
+    type_emb = torch.zeros(2, Hh, device=DEV)
+    gamma, beta = torch.ones(Hh, device=DEV), torch.zeros(Hh, device=DEV)
+    x, pre, mean, rstd, key_mask = ops.embed_ln_fwd(idx, table, pos_emb, type_emb, gamma, beta)
+    want = table[idx.reshape(-1)]
+    assert torch.equal(pre.reshape(-1, H), want)  # pre-LayerNorm input = gathered rows (+0 +0)
+    assert torch.equal(key_mask.reshape(-1).bool(), (want != 0).any(-1))
+    # loss at this vocabulary size: few duplicates among the negatives (Nd ~ N)
+    rn, tb = ops.table_prepare(table)
+    T = 8192
+    tok = torch.randn(T, H, generator=g).to(DEV)
+    mask = torch.ones(T, dtype=torch.uint8, device=DEV)
+    pos = torch.randint(1, V + 1, (T,), generator=g).to(DEV)
+    neg = torch.randint(1, V + 1, (T,), generator=g).to(DEV)
+    from xfmr_rec_amd import _native as N
+
+    losses, stats, d = ops.sampled_loss(tok, mask, pos, neg, table, rn, train_head="AlignmentContrastiveLoss",
+                                        all_heads=True, precision="bf16", table_bf16=tb)
+    assert torch.isfinite(losses).all() and torch.isfinite(d).all()
+    assert int(stats[N.STAT["neg_distinct"]]) == int(torch.unique(neg).numel())
+    # CCL = alignment + contrastive, evaluated in the same pass
+    a, c, ac = (float(losses[N.LOSS_IDS[k]]) for k in ("AlignmentLoss", "ContrastiveLoss", "AlignmentContrastiveLoss"))
+    assert ac == pytest.approx(a + c, rel=1e-5)
