@@ -308,6 +308,26 @@ int xfmr_table_prepare(const float* table, float* table_rnorm, void* table_bf16,
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Device-side sequence sampler: SeqDataset.__getitem__ + collate of the reference
+ * (xfmr_rec/data.py:669-805) for a whole batch in one launch.
+ *   items / labels (nnz): all users' histories back to back (item index 1..n_items, positive-label flag), as
+ *   process_events leaves them (data.py:590-656); offsets (R+1): row r = [offsets[r], offsets[r+1]);
+ *   rows (batch): the dataset rows of this batch. Per row: positions 0..n-2, at most max_seq_length of them uniformly
+ *   without replacement, sorted (data.py:669-688); for each a positive drawn uniformly from the later
+ *   positive-labelled items, within pos_lookahead if > 0, else 0 (data.py:690-722); as many negatives, uniform over
+ *   the catalogue minus the row's history, without replacement while possible (data.py:724-747); everything
+ *   right-padded with 0 to `width` (pad_sequence, data.py:789-805; width = the batch's longest row, <= max_seq_length).
+ * Outputs hist_out / pos_out / neg_out: (batch, width) int64 -- exactly the three index tensors of SeqBatch.
+ * max_history >= the longest history among `rows` (<= 8192). Random stream: counter-based hash of
+ * (seed, row, purpose, counter) -- reproducible, but not numpy's generator: parity is distributional.
+ * ---------------------------------------------------------------------------------------------- */
+size_t xfmr_seq_sample_workspace(int32_t batch, int64_t n_items);
+int xfmr_seq_sample(const int64_t* items, const uint8_t* labels, const int64_t* offsets, const int64_t* rows,
+                    int32_t batch, int32_t width, int32_t max_seq_length, int32_t pos_lookahead, int64_t n_items,
+                    int32_t max_history, uint64_t seed, int64_t* hist_out, int64_t* pos_out, int64_t* neg_out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K18: AdamW over the flat buffer (torch.optim.AdamW as configured at xfmr_rec/trainer.py:327-332:
  * decoupled weight decay, bias-corrected moments, eps outside the sqrt). `step` is 1-based.
  * grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce).
