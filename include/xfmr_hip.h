@@ -328,6 +328,30 @@ int xfmr_seq_sample(const int64_t* items, const uint8_t* labels, const int64_t* 
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Exact top-k retrieval and ranking metrics for validation: replaces the LanceDB
+ * IVF_HNSW_PQ search with the history prefiltered out (xfmr_rec/index.py:214-255, called from trainer.py:186-211,
+ * 305-314) by an exact scan -- the ANN's limit of full probing -- and torchmetrics' seven retrieval metrics on the
+ * synthesised score vector of xfmr_rec/metrics.py:17-79.
+ *   xfmr_topk: query (n_query,H) sentence embeddings; table (n_rows,H) item embeddings, row 0 = padding (never
+ *   returned); exclude / exclude_offsets: CSR of item indices to leave out per query (NULL, NULL: none);
+ *   metric XFMR_METRIC_* (index.py:47, default cosine); out_idx (n_query,k) item indices best first, -1 where fewer
+ *   than k items remain; out_score = 1 - distance (index.py:248-251): cosine similarity, dot, or 1 - |q - e|^2.
+ *   Ties are broken by the lower item index. k <= 1024, H <= 256.
+ *   xfmr_retrieval_metrics: rec_idx (n_query,k) as above; targets / target_offsets: CSR of each query's positive
+ *   item indices; out (n_query,7) = nDCG, MAP, AUROC, precision, recall, hit rate, MRR at top_k (XFMR_RM_*);
+ *   valid[q] = 0 when the query has no target (the reference reports nothing for it, metrics.py:58-59).
+ * ---------------------------------------------------------------------------------------------- */
+enum { XFMR_METRIC_COSINE = 0, XFMR_METRIC_DOT = 1, XFMR_METRIC_L2 = 2 };
+enum { XFMR_RM_NDCG = 0, XFMR_RM_MAP = 1, XFMR_RM_AUROC = 2, XFMR_RM_PRECISION = 3, XFMR_RM_RECALL = 4,
+       XFMR_RM_HIT_RATE = 5, XFMR_RM_MRR = 6, XFMR_NUM_RM = 7 };
+size_t xfmr_topk_workspace(int64_t n_query, int64_t n_rows);
+int xfmr_topk(const float* query, const float* table, const float* table_rnorm, int64_t n_rows, int64_t n_query,
+              int32_t H, const int64_t* exclude, const int64_t* exclude_offsets, int32_t k, int32_t metric,
+              int64_t* out_idx, float* out_score, void* workspace, size_t workspace_bytes, void* stream);
+int xfmr_retrieval_metrics(const int64_t* rec_idx, const int64_t* targets, const int64_t* target_offsets, int32_t n_query,
+                           int32_t k, int32_t top_k, float* out, uint8_t* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K18: AdamW over the flat buffer (torch.optim.AdamW as configured at xfmr_rec/trainer.py:327-332:
  * decoupled weight decay, bias-corrected moments, eps outside the sqrt). `step` is 1-based.
  * grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce).

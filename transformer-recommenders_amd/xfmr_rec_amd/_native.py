@@ -106,6 +106,10 @@ _SIGNATURES = {
     "xfmr_seq_sample_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
     "xfmr_seq_sample": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                   C.c_uint64, _P, _P, _P, _P, C.c_size_t, _P]),
+    "xfmr_topk_workspace": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "xfmr_topk": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P,
+                            C.c_size_t, _P]),
+    "xfmr_retrieval_metrics": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "xfmr_adamw": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                              C.c_int64, C.c_float, _P]),
     "xfmr_scale_by_device_scalar": (C.c_int, [_P, C.c_int64, _P, _P]),

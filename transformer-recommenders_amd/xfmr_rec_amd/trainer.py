@@ -229,6 +229,64 @@ class RecommenderLightningModule(_Base):
             res |= stats_to_dict(s)
         return res
 
+    # ------------------------------------------------------------------ validation path (trainer.py:186-325)
+    @property
+    def items_index(self):
+        """Exact item index over the model's frozen table (the reference builds a LanceDB ANN index at
+        ``on_validation_start``, ``trainer.py:316-325``; the table here never changes, so the index is a view)."""
+        from .retrieval import ExactItemIndex
+
+        assert self.model is not None and self.model.embeddings is not None
+        idx = getattr(self, "_items_index", None)
+        if idx is None or idx.table.data_ptr() != self.model.embeddings.data_ptr():
+            idx = ExactItemIndex(self.model.embeddings, self.model.table_rnorm)
+            self._items_index = idx
+        return idx
+
+    def _to_idx(self, item_ids) -> list[int]:
+        """Item ids -> table rows; unknown ids are dropped (``models.py:347-364``). Integer inputs are rows already."""
+        m = self.model
+        if len(item_ids) and not isinstance(item_ids[0], (str, bytes)):
+            return [int(i) for i in item_ids]
+        assert m.id2idx is not None, "configure_embeddings(items_dataset) provides the id -> row mapping"
+        if hasattr(m.id2idx, "index"):
+            return [int(m.id2idx[i]) for i in item_ids if i in m.id2idx.index]
+        return [int(m.id2idx[i]) for i in item_ids if i in m.id2idx]
+
+    @torch.no_grad()
+    def recommend(self, item_ids, *, top_k: int = 0, exclude_item_ids=None):
+        """``trainer.py:186-211``: nearest items to the pooled embedding of ``item_ids``, ``exclude_item_ids`` left
+        out. Returns ``{"item_idx": (k,) int64 rows of the table (-1 = fewer than k left), "score": (k,)}``."""
+        hist = self._to_idx(item_ids)
+        emb = self.model(torch.as_tensor(hist, dtype=torch.int64, device=self.model.device)[None, :])["sentence_embedding"]
+        excl = None if exclude_item_ids is None else [self._to_idx(exclude_item_ids)]
+        idx, score = self.items_index.search(emb, excl, top_k=top_k or self.config.top_k)
+        return {"item_idx": idx[0], "score": score[0]}
+
+    def predict_step(self, row):
+        """``trainer.py:305-314``: recommendations for the row's history, the history itself excluded."""
+        hist = list(row["history"]["item_id"])
+        return self.recommend(hist, top_k=self.config.top_k, exclude_item_ids=hist)
+
+    def compute_metrics(self, row, stage: str = "val") -> dict[str, torch.Tensor]:
+        """``trainer.py:266-286``: the seven retrieval metrics of one validation row under ``{stage}/<name>``."""
+        from .retrieval import compute_retrieval_metrics
+
+        recs = self.predict_step(row)
+        tgt_ids = [i for i, l in zip(row["target"]["item_id"], row["target"]["label"]) if l]
+        metrics = compute_retrieval_metrics(recs["item_idx"], self._to_idx(tgt_ids), top_k=self.config.top_k)
+        return {f"{stage}/{k}": v for k, v in metrics.items()}
+
+    def validation_step(self, row, batch_idx: int = 0):
+        metrics = self.compute_metrics(row, stage="val")
+        self.log_dict(metrics, batch_size=1)
+        return metrics
+
+    def test_step(self, row, batch_idx: int = 0):
+        metrics = self.compute_metrics(row, stage="test")
+        self.log_dict(metrics, batch_size=1)
+        return metrics
+
     def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         loss_dict = self.compute_losses(batch)
         self.log_dict(loss_dict)
