@@ -169,3 +169,39 @@ def test_data_parallel_gloo_world2(tmp_path):
     for i in range(world):
         torch.testing.assert_close(r[i]["reduced"], total, rtol=1e-6, atol=1e-7)
     assert not torch.allclose(r[0]["local"], r[1]["local"])  # shards really differ (negatives stay rank-local)
+
+
+def test_saved_directory_is_a_loadable_hf_bert_with_the_sentence_transformer_layout(tmp_path):
+    """RecommenderModel.save writes what SentenceTransformer.save writes for the reference's model (models.py:104-149,
+    261-269): transformers' own BertModel.from_pretrained must load the directory strictly and compute the same
+    function as the oracle encoder from the same tensors; the Pooling / Normalize modules round-trip."""
+    import json
+
+    import torch
+    from transformers import BertModel
+
+    from oracle import encoder as enc
+    from xfmr_rec_amd.models import ModelConfig, read_sentence_transformer_dir, write_sentence_transformer_dir
+
+    H, A, I, nL, L = 64, 2, 96, 2, 12
+    params = enc.init_params(H, nL, I, L, seed=3)
+    cfg = ModelConfig(vocab_size=1, hidden_size=H, num_hidden_layers=nL, num_attention_heads=A, intermediate_size=I,
+                      max_seq_length=L, pooling_mode="max", is_normalized=True)
+    write_sentence_transformer_dir(tmp_path, cfg, params)
+    mods = json.loads((tmp_path / "modules.json").read_text())
+    assert [m["type"].rsplit(".", 1)[1] for m in mods] == ["Transformer", "Pooling", "Normalize"]
+    assert json.loads((tmp_path / "1_Pooling" / "config.json").read_text())["pooling_mode_max_tokens"] is True
+    hf = BertModel.from_pretrained(str(tmp_path), local_files_only=True).eval()
+    assert hf.config.is_decoder and hf.config.max_position_embeddings == L
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, L, H, generator=g)
+    mask = torch.ones(2, L, dtype=torch.long)
+    mask[1, 7:] = 0
+    with torch.no_grad():
+        want = hf(inputs_embeds=x, attention_mask=mask).last_hidden_state
+        got = enc.encoder_forward(params, x, mask, A)
+    torch.testing.assert_close(got[mask.bool()], want[mask.bool()], rtol=1e-5, atol=1e-5)
+    cfg2, state = read_sentence_transformer_dir(tmp_path)
+    assert cfg2.pooling_mode == "max" and cfg2.is_normalized and cfg2.max_seq_length == L
+    for k, v in params.items():
+        assert torch.equal(state[k], v.detach()), k

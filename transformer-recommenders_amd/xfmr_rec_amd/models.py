@@ -291,32 +291,101 @@ class RecommenderModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ persistence
     def save(self, path: str) -> None:
-        """Writes ``config.json`` + ``model.safetensors`` with HF BERT keys (``models.py:261-269``)."""
-        from safetensors.torch import save_file
-
-        p = pathlib.Path(path)
-        p.mkdir(parents=True, exist_ok=True)
-        save_file({k: v.contiguous().cpu() for k, v in self.encoder_state_dict().items()}, str(p / "model.safetensors"))
-        c = self.config
-        (p / "config.json").write_text(json.dumps({
-            "model_type": "bert", "is_decoder": c.is_decoder, "vocab_size": c.vocab_size,
-            "hidden_size": c.hidden_size, "num_hidden_layers": c.num_hidden_layers,
-            "num_attention_heads": c.num_attention_heads, "intermediate_size": c.intermediate_size,
-            "max_position_embeddings": c.max_seq_length, "pooling_mode": c.pooling_mode,
-            "is_normalized": c.is_normalized, "pretrained_model_name": c.pretrained_model_name,
-        }, indent=2))
+        """``models.py:261-269``: the SentenceTransformer directory layout (see write_sentence_transformer_dir)."""
+        write_sentence_transformer_dir(
+            path, self.config, {k: v.contiguous().cpu() for k, v in self.encoder_state_dict().items()}
+        )
 
     @classmethod
     def load(cls, path: str, device=None, precision: str = "bf16") -> "RecommenderModel":
-        from safetensors.torch import load_file
+        """``models.py:271-304``: rebuild the config from the saved directory (HF ``config.json``, ``1_Pooling``,
+        ``modules.json``) and load the encoder tensors."""
+        config, state = read_sentence_transformer_dir(path)
+        return cls(config, device=device, model=state, precision=precision)
 
-        p = pathlib.Path(path)
-        d = json.loads((p / "config.json").read_text())
-        config = ModelConfig(
-            vocab_size=d["vocab_size"], hidden_size=d["hidden_size"], num_hidden_layers=d["num_hidden_layers"],
-            num_attention_heads=d["num_attention_heads"], intermediate_size=d["intermediate_size"],
-            max_seq_length=d["max_position_embeddings"], is_decoder=d["is_decoder"],
-            pretrained_model_name=d.get("pretrained_model_name", PRETRAINED_MODEL_NAME),
-            pooling_mode=d.get("pooling_mode", "mean"), is_normalized=d.get("is_normalized", False),
-        )
-        return cls(config, device=device, model=load_file(str(p / "model.safetensors")), precision=precision)
+
+POOLING_FLAGS = {  # sentence-transformers Pooling config keys for the modes ModelConfig allows
+    "cls": "pooling_mode_cls_token", "mean": "pooling_mode_mean_tokens", "max": "pooling_mode_max_tokens",
+    "lasttoken": "pooling_mode_lasttoken",
+}
+
+
+def write_sentence_transformer_dir(path, config: ModelConfig, encoder_state: dict) -> None:
+    """The directory ``SentenceTransformer.save`` produces for the reference's model (``models.py:104-149, 261-269``;
+    sentence-transformers 5.7 layout): ``modules.json`` (Transformer, Pooling[, Normalize]), the HF BertModel at the
+    root (``config.json`` + ``model.safetensors`` with ``BertModel`` keys), ``sentence_bert_config.json``,
+    ``1_Pooling/config.json``. ``word_embeddings`` and ``pooler.*`` never train on this path: they are
+    written with their (deterministic) HF init so that ``BertModel.from_pretrained`` loads the directory strictly.
+    Tokenizer files belong to ``config.pretrained_model_name`` and cannot be produced offline: copy them next to
+    these files before loading with sentence-transformers (the training path feeds ``inputs_embeds`` only)."""
+    from safetensors.torch import save_file
+
+    p = pathlib.Path(path)
+    p.mkdir(parents=True, exist_ok=True)
+    c = config
+    H = c.hidden_size
+    state = {k: torch.as_tensor(v).detach().to(torch.float32).contiguous().cpu() for k, v in encoder_state.items()}
+    g = torch.Generator().manual_seed(0)
+    state.setdefault("embeddings.word_embeddings.weight", torch.randn(c.vocab_size or 1, H, generator=g) * 0.02)
+    state.setdefault("pooler.dense.weight", torch.randn(H, H, generator=g) * 0.02)
+    state.setdefault("pooler.dense.bias", torch.zeros(H))
+    save_file(state, str(p / "model.safetensors"), metadata={"format": "pt"})
+    (p / "config.json").write_text(json.dumps({
+        "architectures": ["BertModel"], "model_type": "bert", "is_decoder": c.is_decoder,
+        "vocab_size": c.vocab_size or 1, "hidden_size": H, "num_hidden_layers": c.num_hidden_layers,
+        "num_attention_heads": c.num_attention_heads, "intermediate_size": c.intermediate_size,
+        "max_position_embeddings": c.max_seq_length, "type_vocab_size": 2, "hidden_act": "gelu",
+        "hidden_dropout_prob": 0.1, "attention_probs_dropout_prob": 0.1, "layer_norm_eps": 1e-12,
+        "initializer_range": 0.02, "pad_token_id": 0, "position_embedding_type": "absolute", "use_cache": True,
+        "torch_dtype": "float32",
+        # build-specific extras (ignored by HF): lets RecommenderModel.load round-trip without sentence-transformers
+        "xfmr_pooling_mode": c.pooling_mode, "xfmr_is_normalized": c.is_normalized,
+        "xfmr_pretrained_model_name": c.pretrained_model_name,
+    }, indent=2))
+    modules = [
+        {"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+        {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"},
+    ]
+    if c.is_normalized:
+        modules.append({"idx": 2, "name": "2", "path": "2_Normalize", "type": "sentence_transformers.models.Normalize"})
+        (p / "2_Normalize").mkdir(exist_ok=True)
+    (p / "modules.json").write_text(json.dumps(modules, indent=2))
+    (p / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": c.max_seq_length, "do_lower_case": False}, indent=2))
+    (p / "config_sentence_transformers.json").write_text(json.dumps(
+        {"__version__": {"sentence_transformers": "5.7.0"}, "prompts": {}, "default_prompt_name": None,
+         "similarity_fn_name": "cosine"}, indent=2))
+    (p / "1_Pooling").mkdir(exist_ok=True)
+    pool = {"word_embedding_dimension": H, "include_prompt": True}
+    pool |= {flag: mode == c.pooling_mode for mode, flag in POOLING_FLAGS.items()}
+    pool |= {"pooling_mode_mean_sqrt_len_tokens": False, "pooling_mode_weightedmean_tokens": False}
+    (p / "1_Pooling" / "config.json").write_text(json.dumps(pool, indent=2))
+
+
+def read_sentence_transformer_dir(path):
+    """(ModelConfig, HF-keyed encoder state) from a directory written by :func:`write_sentence_transformer_dir` or by
+    ``SentenceTransformer.save`` of the reference's model."""
+    from safetensors.torch import load_file
+
+    p = pathlib.Path(path)
+    d = json.loads((p / "config.json").read_text())
+    pooling_mode = d.get("xfmr_pooling_mode", d.get("pooling_mode", "mean"))
+    pc = p / "1_Pooling" / "config.json"
+    if pc.exists():
+        flags = json.loads(pc.read_text())
+        for mode, flag in POOLING_FLAGS.items():
+            if flags.get(flag):
+                pooling_mode = mode
+    is_normalized = d.get("xfmr_is_normalized", d.get("is_normalized", False))
+    mj = p / "modules.json"
+    if mj.exists():
+        is_normalized = any(m.get("type", "").endswith("Normalize") for m in json.loads(mj.read_text()))
+    config = ModelConfig(
+        vocab_size=d.get("vocab_size", 1), hidden_size=d["hidden_size"], num_hidden_layers=d["num_hidden_layers"],
+        num_attention_heads=d["num_attention_heads"], intermediate_size=d["intermediate_size"],
+        max_seq_length=d["max_position_embeddings"], is_decoder=d.get("is_decoder", True),
+        pretrained_model_name=d.get("xfmr_pretrained_model_name", d.get("pretrained_model_name", PRETRAINED_MODEL_NAME)),
+        pooling_mode=pooling_mode, is_normalized=is_normalized,
+    )
+    state = load_file(str(p / "model.safetensors"))
+    state = {(k[len("bert."):] if k.startswith("bert.") else k): v for k, v in state.items()}
+    return config, state
