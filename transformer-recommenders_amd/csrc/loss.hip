@@ -453,7 +453,7 @@ struct CombineArgs {
   float* d_tok; double* blockpart;
   int T, H, nsplit, train_head, need_grad, mode; int64_t n_rows;
   float scale, margin;
-  int k_hard, skip_train_head;
+  int k_hard, skip_train_head, lse_from_grad;
 };
 
 __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
@@ -494,14 +494,15 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
     const Merged G = merge(a.part);
     const Merged V = (a.part_loss == a.part) ? G : merge(a.part_loss);
     {
-      const float ltot_v = V.l + exp2f(z2pos - V.M);
+      const float Mv = a.lse_from_grad ? G.M : V.M, lv = a.lse_from_grad ? G.l : V.l;
+      const float ltot_v = lv + exp2f(z2pos - Mv);
       const float inv_dv = 1.f / (V.cnt_d + 1e-9f), inv_cv = 1.f / (V.cnt_c + 1e-9f);
       const float loss_align = 1.f - cpos;
       const float loss_contr = V.contr * inv_cv;
       acc[XFMR_LOSS_ALIGNMENT] = loss_align;
       acc[XFMR_LOSS_ALIGNMENT_CONTRASTIVE] = loss_align + loss_contr;
       acc[XFMR_LOSS_CONTRASTIVE] = loss_contr;
-      acc[XFMR_LOSS_INFONCE] = (V.M + log2f(ltot_v)) * kLn2 - a.scale * pos_dot;
+      acc[XFMR_LOSS_INFONCE] = (Mv + log2f(ltot_v)) * kLn2 - a.scale * pos_dot;
       acc[XFMR_LOSS_NCE] = xf_softplus(-pos_dot) + V.nce * inv_dv;
       acc[XFMR_LOSS_PAIRWISE_HINGE] = V.hinge * inv_dv;
       acc[XFMR_LOSS_PAIRWISE_LOGISTIC] = V.logi * inv_dv;
@@ -773,6 +774,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
   g_prof_start = g_prof_stop = nullptr;  // one-shot
   const float* part_loss = nullptr;  // records the loss VALUES are read from (null: the same as the gradient's)
+  bool lse_from_grad = false;        // InfoNCE value from the gradient pass's records (logging pass ran without it)
   const bool hard = cfg->num_hard_negatives > 0;
   if (hard) {
     // top-k hard negatives (losses.py:295-330), generic kernel for both precisions: (1) the same kernel dumps its
@@ -810,7 +812,11 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       if (!grad_pass && ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
       // all_heads == 2: the train head's value is not wanted from this call (the caller has it from the gradient
       // pass of the same step): for InfoNCE that drops the log-sum-exp from the per-logit work
-      const int code = (cfg->all_heads == 2 && cfg->train_head == XFMR_LOSS_INFONCE && !grad_pass) ? -2 : -1;
+      // ... and likewise when the gradient pass of THIS call is the InfoNCE one: the combine kernel then takes the
+      // head's value from the gradient pass's records
+      const bool lse_elsewhere = cfg->train_head == XFMR_LOSS_INFONCE && (grad_pass || cfg->all_heads == 2);
+      lse_from_grad = lse_elsewhere && grad_pass;
+      const int code = lse_elsewhere ? -2 : -1;
       rc = launch_dma_h(b, table_bf16, H, code, grid, st);
       if (rc) return rc;
       if (!grad_pass && ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
@@ -832,6 +838,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
   c.k_hard = cfg->num_hard_negatives;
   c.skip_train_head = (cfg->all_heads == 2 && d_tok == nullptr) ? 1 : 0;
+  c.lse_from_grad = lse_from_grad ? 1 : 0;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
   return xf_loss_finalize(c.blockpart, p.nblocks, 4, counts, cfg->mode, n_rows, losses, stats,
