@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using FB = Frag<P, TB>;
   constexpr bool a16 = S & XF_S16_A, b16 = S & XF_S16_B, c16 = S & XF_S16_C, p16 = S & XF_S16_P;
   static_assert(S == 0 || sizeof(elem) == 2, "bf16 storage needs the bf16 policy");
-  constexpr int SCR_LD = 36;  // per-wave 32 x 32 fp32 transposition scratch (rows 16-byte aligned)
+  constexpr int SCR_LD = (BN / 2) + 4;  // per-wave 32 x (BN/2) fp32 transposition scratch (rows 16-byte aligned)
   constexpr size_t OPER_BYTES = (size_t)(TileA::IMG_ELEMS + TileB::IMG_ELEMS) * sizeof(elem);
   constexpr size_t SCR_BYTES = (size_t)4 * 32 * SCR_LD * sizeof(float);
   __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES > SCR_BYTES ? OPER_BYTES : SCR_BYTES];
@@ -257,9 +257,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------
-  // Each 32 x 32 accumulator tile goes through a per-wave LDS transposition so that every global access of the
-  // epilogue (C, residual, pre-activation) is a 16-byte (8-byte for bf16) row-contiguous piece: one wave
-  // instruction covers 8 rows x 128 B instead of 2 rows x 32 scattered 4-byte (or 2-byte) elements.
+  // The wave's 32 x (NI*32) accumulator strip goes through a per-wave LDS transposition so that every global access
+  // of the epilogue (C, residual, pre-activation) is a 16-byte (8-byte for bf16) piece of a row-contiguous run that
+  // covers the wave's whole column range: full 128-byte lines even for bf16 outputs when the wave owns 64 columns
+  // (one wave instruction = 4-8 rows x 128-256 B instead of 2 rows x 32 scattered 4- or 2-byte elements).
   __syncthreads();  // everyone is done with the operand images the scratch aliases
   if (do_bias) {  // combine the 256 / (BM/4) threads that share an operand row quad, fixed order
     constexpr int R4 = BM / 4, G = 256 / R4;
@@ -282,62 +283,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     __syncthreads();
   }
+  constexpr int CW = NI * 32;        // columns this wave owns
+  constexpr int LPR = CW / 4;        // lanes per row (4 columns each)
+  constexpr int RPP = 64 / LPR;      // rows per pass
+  constexpr int NPASS = 32 / RPP;
   float* const scr = reinterpret_cast<float*>(smem) + wid * (32 * SCR_LD);
   const int64_t zoff = (EPI == EPI_SPLITK) ? (int64_t)blockIdx.z * g.M * g.ldc : 0;
-  const int prow = lane >> 3, c4 = (lane & 7) * 4;
+  const int prow = lane / LPR, c4 = (lane % LPR) * 4;
   const float* aux_src = reinterpret_cast<const float*>((EPI == EPI_GELU_GRAD) ? g.P : (const void*)g.R);
   constexpr bool aux16 = (EPI == EPI_GELU_GRAD) && p16;
   constexpr bool has_aux = (EPI == EPI_STORE || EPI == EPI_DROP_RES || EPI == EPI_GELU_GRAD);
+  const int n = n0 + wc * WN + c4;
+  const bool ncol = n < g.N;
+  float4 bias = make_float4(0, 0, 0, 0);
+  if (EPI != EPI_SPLITK && EPI != EPI_GELU_GRAD && g.bias && ncol) bias = *reinterpret_cast<const float4*>(g.bias + n);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    const int64_t mb = m0 + wr * WM + i * 32;
+    // issue the epilogue operand loads first: their latency hides under the LDS round trip
+    float4 aux[NPASS];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wc * WN + j * 32 + c4;
-      const int64_t mb = m0 + wr * WM + i * 32;
-      const bool ncol = n < g.N;
-      // issue the epilogue operand loads first: their latency hides under the LDS round trip
-      float4 aux[4];
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        aux[ps] = make_float4(0, 0, 0, 0);
-        const int64_t m = mb + prow + 8 * ps;
-        if (has_aux && aux_src && ncol && m < g.M) aux[ps] = xf_ld4<aux16>(aux_src, m * g.ldc + n);
-      }
-      float4 bias = make_float4(0, 0, 0, 0);
-      if (EPI != EPI_SPLITK && EPI != EPI_GELU_GRAD && g.bias && ncol) bias = *reinterpret_cast<const float4*>(g.bias + n);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) scr[xf_acc_row(r, lane) * SCR_LD + (lane & 31)] = acc[i][j][r];
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave re-reads its own writes
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int row = prow + 8 * ps;
-        const int64_t m = mb + row;
-        if (!ncol || m >= g.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4);
-        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-        const int64_t o = m * g.ldc + n;
-        if (EPI == EPI_STORE) {
-          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
-        } else if (EPI == EPI_GELU) {
-          xf_st4<c16>(g.C2, o, v);
-          v.x = xf_gelu(v.x); v.y = xf_gelu(v.y); v.z = xf_gelu(v.z); v.w = xf_gelu(v.w);
-        } else if (EPI == EPI_DROP_RES) {
-          if (g.drop.on) {
-            const uint32_t e = (uint32_t)(m * g.N + n);
-            v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
-            v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
-          }
-          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
-        } else if (EPI == EPI_GELU_GRAD) {
-          v.x *= xf_gelu_grad(aux[ps].x); v.y *= xf_gelu_grad(aux[ps].y);
-          v.z *= xf_gelu_grad(aux[ps].z); v.w *= xf_gelu_grad(aux[ps].w);
-        }
-        xf_st4<(c16 && EPI != EPI_SPLITK)>(g.C, zoff + o, v);
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();  // the next tile overwrites the scratch
+    for (int ps = 0; ps < NPASS; ++ps) {
+      aux[ps] = make_float4(0, 0, 0, 0);
+      const int64_t m = mb + prow + RPP * ps;
+      if (has_aux && aux_src && ncol && m < g.M) aux[ps] = xf_ld4<aux16>(aux_src, m * g.ldc + n);
     }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[xf_acc_row(r, lane) * SCR_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave re-reads its own writes
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = prow + RPP * ps;
+      const int64_t m = mb + row;
+      if (!ncol || m >= g.M) continue;
+      float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4);
+      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+      const int64_t o = m * g.ldc + n;
+      if (EPI == EPI_STORE) {
+        v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
+      } else if (EPI == EPI_GELU) {
+        xf_st4<c16>(g.C2, o, v);
+        v.x = xf_gelu(v.x); v.y = xf_gelu(v.y); v.z = xf_gelu(v.z); v.w = xf_gelu(v.w);
+      } else if (EPI == EPI_DROP_RES) {
+        if (g.drop.on) {
+          const uint32_t e = (uint32_t)(m * g.N + n);
+          v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
+          v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
+        }
+        v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
+      } else if (EPI == EPI_GELU_GRAD) {
+        v.x *= xf_gelu_grad(aux[ps].x); v.y *= xf_gelu_grad(aux[ps].y);
+        v.z *= xf_gelu_grad(aux[ps].z); v.w *= xf_gelu_grad(aux[ps].w);
+      }
+      xf_st4<(c16 && EPI != EPI_SPLITK)>(g.C, zoff + o, v);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();  // the next strip overwrites the scratch
   }
 }
 
@@ -442,6 +446,11 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   const TileOverride ov = tile_override();
   if constexpr (P::kId == XFMR_PREC_BF16 && EPI == EPI_SPLITK) {
     if (kspan % 128 == 0 && ov.bk != 32) return launch_gemm_bk<P, 128, TA, TB, EPI, S>(g, splits, st);
+  }
+  if constexpr (P::kId == XFMR_PREC_BF16 && EPI != EPI_SPLITK) {
+    // 64-deep slices for the forward / dX GEMMs: measured 1.874 vs 1.888 ms/step against 32-deep (whole-K 128-deep
+    // slices: 2.026). XFMR_GEMM_TILE="bm,bn,32" forces 32.
+    if (ov.bk != 32 && kspan % 64 == 0) return launch_gemm_bk<P, 64, TA, TB, EPI, S>(g, splits, st);
   }
   return launch_gemm_bk<P, 32, TA, TB, EPI, S>(g, splits, st);
 }
