@@ -2,6 +2,8 @@
 // embedding-parameter gradients, masked mean pooling, AdamW, per-item inverse norms.
 // One wavefront owns one row (H <= 1024): lanes stride the row in 4-byte steps, so every wave
 // instruction touches 256 contiguous bytes; row statistics are wave reductions, never LDS.
+#include <stdlib.h>
+
 #include "internal.h"
 
 // single-level deterministic column sum dst[c] = sum_r src[r*cols + c] (gemm.hip)
@@ -485,8 +487,10 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
 }
 
 int ln_bwd_blocks(int64_t rows, int* rows_per_block) {
-  int64_t blocks = (rows + 63) / 64;
-  if (blocks > 512) blocks = 512;
+  // 32 rows per workgroup, <= 1024 workgroups (measured at T = 25 600: 1.859 ms/step; 64 rows / 512: 1.877;
+  // 16 rows / 2048: 1.891 -- the partial records the final reduction reads grow with the workgroup count)
+  int64_t blocks = (rows + 31) / 32;
+  if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   int64_t rpb = (rows + blocks - 1) / blocks;
   rpb = ((rpb + 15) / 16) * 16;  // whole wave-iterations of the vectorised kernel (4 waves x up to 4 rows)
