@@ -355,14 +355,19 @@ class EncoderFunction(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.save_for_backward(flat_params, key_mask, acts)
         ctx.mark_non_differentiable(key_mask)
+        ctx.set_materialize_grads(False)  # no zero-filled gradient for the mask output
         return tok, key_mask
 
     @staticmethod
     def backward(ctx, d_tok, _d_mask):
         flat_params, key_mask, acts = ctx.saved_tensors
+        if d_tok is None:
+            return None, None, None, None
         d = d_tok.contiguous()
-        if d.data_ptr() == d_tok.data_ptr():
-            d = d.clone()  # the kernel sequence reuses this buffer as scratch
+        # the kernel sequence reuses this buffer as scratch: it may only do so in place when the producer hands the
+        # buffer over (the fused loss does: its saved gradient is dead after its own backward)
+        if d.data_ptr() == d_tok.data_ptr() and not getattr(d_tok, "_xfmr_consumable", False):
+            d = d.clone()
         grads = encoder_bwd(ctx.cfg, flat_params, d, key_mask, acts)
         return grads, None, None, None
 
@@ -380,14 +385,19 @@ class SampledLossFunction(torch.autograd.Function):
         if need:
             ctx.save_for_backward(d_tok)
         ctx.mark_non_differentiable(losses, stats)
+        ctx.set_materialize_grads(False)  # no zero-filled gradients for the logging outputs
         return losses[head].clone(), losses, stats
 
     @staticmethod
     def backward(ctx, g, _gl, _gs):
+        if g is None:
+            return (None,) * 7
         (d_tok,) = ctx.saved_tensors
         g = g.contiguous().to(f32)
         N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(d_tok), d_tok.numel(), N.ptr(g), N.stream()),
                 "xfmr_scale_by_device_scalar")
+        if not torch.is_grad_enabled():  # not under create_graph: the buffer is dead after this backward
+            d_tok._xfmr_consumable = True
         return d_tok, None, None, None, None, None, None
 
 
