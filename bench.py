@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step")
+    ap.add_argument("--batch", type=int, default=512,
+                    help="sequences per GPU per step (SURVEY section 8d, config 2: per-GPU B in {32, 128, 512}; the "
+                         "largest is the default -- a 288 GB part is sized for it; DESIGN.md lists all three)")
     ap.add_argument("--seq-len", type=int, default=200)
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--layers", type=int, default=4)
