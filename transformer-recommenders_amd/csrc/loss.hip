@@ -663,6 +663,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   const int64_t tiles = (cols + BN - 1) / BN;
   int64_t ns = (1024 + qblocks / 2) / qblocks;  // ~1024 workgroups: two full rounds at 2 workgroups/CU
   if (ns > 16) ns = 16;
+  if (ns < 2) ns = 2;  // measured at 800 query blocks (B = 512): 2 splits 95.5k seq/s, 1 split 94.1k
   if (const char* e = getenv("XFMR_LOSS_NSPLIT")) ns = atoi(e);  // tuning experiments
   if (ns > tiles) ns = tiles;
   if (ns < 1) ns = 1;
