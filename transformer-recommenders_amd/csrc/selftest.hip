@@ -13,7 +13,6 @@ __device__ __forceinline__ float tval(int which, int r, int c) {
 
 template <class P>
 __device__ int run_checks(typename P::elem* sA, typename P::elem* sB, float* sRow) {
-  using elem = typename P::elem;
   constexpr int K = 32, LD = xf_ld<P>(K), LDTT = 32 + 4;
   const int lane = xf_lane();
   int bad = 0;
