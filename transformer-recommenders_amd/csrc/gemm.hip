@@ -20,7 +20,8 @@ struct GemmArgs {
   const void* A; const void* B; void* C;  // fp32, or bf16 where the storage mask says so
   int64_t lda, ldb, ldc;
   int64_t M; int N; int K;
-  int k_chunk;            // split-K: blockIdx.z handles [z*k_chunk, min(K,(z+1)*k_chunk)); 0 = whole K
+  int k_chunk;            // split-K: split z handles [z*k_chunk, min(K,(z+1)*k_chunk)); 0 = whole K
+  int nt_n, nt_m, nt_z;   // tiles along N, M and the number of K splits (the launch is one-dimensional: see tile_of)
   const float* bias;      // [N] or null
   const float* R;         // residual / residual-grad [M,ldc] or null
   const void* P;          // pre-activation for gelu' [M,ldc]
@@ -185,6 +186,32 @@ __device__ __forceinline__ f32x16 xf_mma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// XCD-aware tile order. Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroups d and
+// d + 8 share an L2 and d, d + 1 do not. With the plain (n fastest) order the N-tiles of one M-tile -- which all read
+// the SAME A rows -- land on different XCDs and every one of them fetches A from the fabric again: measured at
+// T = 102 400 (FETCH_SIZE), the FFN1 GEMM fetched 206 MB for 52 MB of activations, the gelu' GEMM 308 MB for 131 MB.
+// Here the workgroups of one XCD (d % 8) walk the N-tiles of one M-tile (one K split for the dW GEMMs) back to back,
+// so the re-reads hit that XCD's L2.
+struct TileIdx { int n, m, z; bool valid; };
+__device__ __forceinline__ TileIdx tile_of(const int nt_n, const int nt_m, const int nt_z) {
+  const int d = blockIdx.x, xcd = d & 7, slot = d >> 3;
+  TileIdx t;
+  if (nt_z > 1) {  // split-K: the (m, n) tiles of one split share its A and B slices
+    const int per = nt_n * nt_m;
+    t.z = (slot / per) * 8 + xcd;
+    const int r = slot % per;
+    t.n = r % nt_n;
+    t.m = r / nt_n;
+    t.valid = t.z < nt_z;
+  } else {
+    t.z = 0;
+    t.n = slot % nt_n;
+    t.m = (slot / nt_n) * 8 + xcd;
+    t.valid = t.m < nt_m;
+  }
+  return t;
+}
+
 // S = XF_S16_* storage mask (compile time: a runtime switch between the fp32 and bf16 load paths cost the
 // forward / dX GEMMs 15-80 %).
 template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S>
@@ -206,11 +233,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
-  const int64_t m0 = (int64_t)blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  const TileIdx tix = tile_of(g.nt_n, g.nt_m, g.nt_z);
+  if (!tix.valid) return;  // (whole workgroup: the grid is padded to a multiple of 8 M-tiles / K splits)
+  const int64_t m0 = (int64_t)tix.m * BM;
+  const int n0 = tix.n * BN;
   int kbeg = 0, kend = g.K;
   if (g.k_chunk > 0) {
-    kbeg = blockIdx.z * g.k_chunk;
+    kbeg = tix.z * g.k_chunk;
     kend = min(g.K, kbeg + g.k_chunk);
   }
 
@@ -224,7 +253,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   TileA ta;
   TileB tb;
-  const bool do_bias = (EPI == EPI_SPLITK) && TA && g.bias_part != nullptr && blockIdx.x == 0;
+  const bool do_bias = (EPI == EPI_SPLITK) && TA && g.bias_part != nullptr && tix.n == 0;
   float4 bsum = make_float4(0, 0, 0, 0);
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
       const int64_t m = m0 + 4 * threadIdx.x;
-      float* dst = g.bias_part + (int64_t)blockIdx.z * g.M + m;
+      float* dst = g.bias_part + (int64_t)tix.z * g.M + m;
       if (m < g.M) dst[0] = s.x;
       if (m + 1 < g.M) dst[1] = s.y;
       if (m + 2 < g.M) dst[2] = s.z;
@@ -288,7 +317,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int RPP = 64 / LPR;      // rows per pass
   constexpr int NPASS = 32 / RPP;
   float* const scr = reinterpret_cast<float*>(smem) + wid * (32 * SCR_LD);
-  const int64_t zoff = (EPI == EPI_SPLITK) ? (int64_t)blockIdx.z * g.M * g.ldc : 0;
+  const int64_t zoff = (EPI == EPI_SPLITK) ? (int64_t)tix.z * g.M * g.ldc : 0;
   const int prow = lane / LPR, c4 = (lane % LPR) * 4;
   const float* aux_src = reinterpret_cast<const float*>((EPI == EPI_GELU_GRAD) ? g.P : (const void*)g.R);
   constexpr bool aux16 = (EPI == EPI_GELU_GRAD) && p16;
@@ -430,11 +459,19 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   const TileOverride ov = tile_override();
   if (ov.bm) { bm = ov.bm; bn = ov.bn; }
   dim3 block(256);
-  dim3 grid((unsigned)((g.N + bn - 1) / bn), (unsigned)((g.M + bm - 1) / bm), splits);
-  if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI, S>), grid, block, 0, st, g);
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI, S>), grid, block, 0, st, g);
-  else if (bm == 64) hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI, S>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI, S>), grid, block, 0, st, g);
+  GemmArgs ga = g;
+  ga.nt_n = (int)((g.N + bn - 1) / bn);
+  ga.nt_m = (int)((g.M + bm - 1) / bm);
+  ga.nt_z = splits;
+  // one-dimensional launch, padded so that every XCD gets whole groups (see tile_of)
+  const int64_t groups = splits > 1 ? (splits + 7) / 8 : (ga.nt_m + 7) / 8;
+  const int64_t per = splits > 1 ? (int64_t)ga.nt_n * ga.nt_m : ga.nt_n;
+  if (groups * per * 8 > 0x7fffffffll) return XFMR_EUNSUPPORTED;
+  dim3 grid((unsigned)(groups * per * 8));
+  if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI, S>), grid, block, 0, st, ga);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI, S>), grid, block, 0, st, ga);
+  else if (bm == 64) hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI, S>), grid, block, 0, st, ga);
+  else hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI, S>), grid, block, 0, st, ga);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
