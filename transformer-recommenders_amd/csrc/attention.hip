@@ -306,6 +306,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 // Q^T, dO^T) and no scattered transposing stores while staging.
 // ================================================================================================================
 using AI = SwzImg<DH>;
+// XCD-aware workgroup order (cf. gemm.hip tile_of): the 128-row blocks and the heads of ONE sequence read the same
+// qkv / ctx / d_ctx rows (a 128-byte line holds two heads' slices), so all of a sequence's workgroups run on one XCD
+// (d % 8) and share its L2. bx = 128-row block, by = b * A + h, as the (nblk, B*A) grid had them.
+struct AttnBlock { int bx, by; bool valid; };
+__device__ __forceinline__ AttnBlock attn_block(const AttnArgs& a) {
+  const int nblk = (a.L + 127) / 128;
+  const int d = blockIdx.x, xcd = d & 7, slot = d >> 3;
+  const int per_b = nblk * a.A;
+  const int b = (slot / per_b) * 8 + xcd, r = slot % per_b;
+  return AttnBlock{r % nblk, b * a.A + r / nblk, b < a.B};
+}
 // bytes of the two staged row panels of a (batch, head), or of the 4 x 32 x 33 fp32 output-transposition scratch
 // that later aliases them, whichever is larger (16-byte multiple)
 __host__ __device__ inline size_t bf16_panel_bytes(int L) {
@@ -402,8 +413,10 @@ template <bool S16>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
-  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
-  const int qblk0 = blockIdx.x * 128;
+  const AttnBlock blk = attn_block(a);
+  if (!blk.valid) return;  // (whole workgroup: the grid is padded to a multiple of 8 sequences)
+  const int b = blk.by / a.A, h = blk.by % a.A;
+  const int qblk0 = blk.bx * 128;
   const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sV = sK + nkeys * DH;
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
+  const uint32_t ebase = (uint32_t)(((int64_t)blk.by * L + q) * L);
   const int kb_end = active ? min((q0 + 31) / 32, nkeys / 32 - 1) : -1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s;
@@ -470,15 +483,17 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   if (!active) return;
   xf_store_tile_T_at<S16>(scratch + wid * 32 * 33, o, inv, a.ctx, tok0 * H + h * DH, H, q0, L);
   if (lane < 32 && q < L)
-    a.lse[((int64_t)blockIdx.y) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
+    a.lse[((int64_t)blk.by) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
 }
 
 template <bool S16>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
-  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
-  const int qblk0 = blockIdx.x * 128;
+  const AttnBlock blk = attn_block(a);
+  if (!blk.valid) return;  // (whole workgroup: the grid is padded to a multiple of 8 sequences)
+  const int b = blk.by / a.A, h = blk.by % a.A;
+  const int qblk0 = blk.bx * 128;
   const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sV = sK + nkeys * DH;
@@ -505,9 +520,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   float delta = 0.f;
   if (qv) delta = dot16<S16>(a.ctx, a.d_ctx, (tok0 + q) * H + h * DH + 16 * (lane >> 5));
   delta += xf_half_swap(delta);
-  const float lse2 = qv ? a.lse[(int64_t)blockIdx.y * L + q] * kLog2e : INFINITY;
+  const float lse2 = qv ? a.lse[(int64_t)blk.by * L + q] * kLog2e : INFINITY;
   const float sc = 0.17677669529663687f * kLog2e;
-  const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
+  const uint32_t ebase = (uint32_t)(((int64_t)blk.by * L + q) * L);
   f32x16 dq;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -540,8 +555,10 @@ template <bool S16>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
-  const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
-  const int kblk0 = blockIdx.x * 128;
+  const AttnBlock blk = attn_block(a);
+  if (!blk.valid) return;  // (whole workgroup: the grid is padded to a multiple of 8 sequences)
+  const int b = blk.by / a.A, h = blk.by % a.A;
+  const int kblk0 = blk.bx * 128;
   const int Lp = ((L + 31) / 32) * 32;
   const int nq = Lp - kblk0;
   __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
@@ -565,7 +582,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
       if (c < nq * 8 && kblk0 + r < L) {
         x[u] = xf_ld4<S16>(a.ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
         y[u] = xf_ld4<S16>(a.d_ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
-        if ((c & 7) == 0) ls[u] = a.lse[(int64_t)blockIdx.y * L + kblk0 + r] * kLog2e;
+        if ((c & 7) == 0) ls[u] = a.lse[(int64_t)blk.by * L + kblk0 + r] * kLog2e;
       }
     }
 #pragma unroll
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
         const bool vis = kvis && (key <= q);
         const float p = vis ? xf_exp2(s[r] * sc - ls[u]) : 0.f;
         float keep = 1.f;
-        if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blockIdx.y * L + q) * L) + (uint32_t)key);
+        if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blk.by * L + q) * L) + (uint32_t)key);
         s[r] = p * (dp[r] * keep - dl[u]);
         dp[r] = p * keep;
       }
@@ -663,7 +680,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 
 template <bool S16>
 int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
-  dim3 grid((a.L + 127) / 128, a.B * a.A);
+  dim3 grid((unsigned)(((a.L + 127) / 128) * a.A * ((a.B + 7) / 8) * 8));  // see attn_block
   const size_t sm = bf16_smem_fwd(a.L);
   if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
   if (hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -675,7 +692,7 @@ int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
 }
 template <bool S16>
 int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
-  dim3 grid((a.L + 127) / 128, a.B * a.A);
+  dim3 grid((unsigned)(((a.L + 127) / 128) * a.A * ((a.B + 7) / 8) * 8));  // see attn_block
   const size_t s1 = bf16_smem_fwd(a.L), s2 = bf16_smem_dkv(a.L);
   if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
   if (hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
