@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using FB = Frag<P, TB>;
   constexpr bool a16 = S & XF_S16_A, b16 = S & XF_S16_B, c16 = S & XF_S16_C, p16 = S & XF_S16_P;
   static_assert(S == 0 || sizeof(elem) == 2, "bf16 storage needs the bf16 policy");
-  constexpr int SCR_LD = (BN / 2) + 4;  // per-wave 32 x (BN/2) fp32 transposition scratch (rows 16-byte aligned)
+  constexpr int SCR_LD = (BN / 2) + 4;  // per-wave 16 x (BN/2) fp32 transposition scratch (rows 16-byte aligned)
   constexpr size_t OPER_BYTES = (size_t)(TileA::IMG_ELEMS + TileB::IMG_ELEMS) * sizeof(elem);
-  constexpr size_t SCR_BYTES = (size_t)4 * 32 * SCR_LD * sizeof(float);
+  constexpr size_t SCR_BYTES = (size_t)4 * 16 * SCR_LD * sizeof(float);  // <= the operand images for every tile used
   __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES > SCR_BYTES ? OPER_BYTES : SCR_BYTES];
   elem* const sA = reinterpret_cast<elem*>(smem);
   elem* const sB = sA + TileA::IMG_ELEMS;
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int CW = NI * 32;        // columns this wave owns
   constexpr int LPR = CW / 4;        // lanes per row (4 columns each)
   constexpr int RPP = 64 / LPR;      // rows per pass
-  constexpr int NPASS = 32 / RPP;
-  float* const scr = reinterpret_cast<float*>(smem) + wid * (32 * SCR_LD);
+  constexpr int NPASS = 16 / RPP;    // passes per half strip (16 rows: the scratch stays below the operand images)
+  float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
   const int64_t zoff = (EPI == EPI_SPLITK) ? (int64_t)tix.z * g.M * g.ldc : 0;
   const int prow = lane / LPR, c4 = (lane % LPR) * 4;
   const float* aux_src = reinterpret_cast<const float*>((EPI == EPI_GELU_GRAD) ? g.P : (const void*)g.R);
@@ -328,49 +328,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   if (EPI != EPI_SPLITK && EPI != EPI_GELU_GRAD && g.bias && ncol) bias = *reinterpret_cast<const float4*>(g.bias + n);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int64_t mb = m0 + wr * WM + i * 32;
-    // issue the epilogue operand loads first: their latency hides under the LDS round trip
-    float4 aux[NPASS];
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      aux[ps] = make_float4(0, 0, 0, 0);
-      const int64_t m = mb + prow + RPP * ps;
-      if (has_aux && aux_src && ncol && m < g.M) aux[ps] = xf_ld4<aux16>(aux_src, m * g.ldc + n);
-    }
+    for (int hf = 0; hf < 2; ++hf) {  // accumulator registers 8*hf .. 8*hf+7 hold the strip's rows 16*hf .. 16*hf+15
+      const int64_t mb = m0 + wr * WM + i * 32 + 16 * hf;
+      // issue the epilogue operand loads first: their latency hides under the LDS round trip
+      float4 aux[NPASS];
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) scr[xf_acc_row(r, lane) * SCR_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave re-reads its own writes
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int row = prow + RPP * ps;
-      const int64_t m = mb + row;
-      if (!ncol || m >= g.M) continue;
-      float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4);
-      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-      const int64_t o = m * g.ldc + n;
-      if (EPI == EPI_STORE) {
-        v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
-      } else if (EPI == EPI_GELU) {
-        xf_st4<c16>(g.C2, o, v);
-        v.x = xf_gelu(v.x); v.y = xf_gelu(v.y); v.z = xf_gelu(v.z); v.w = xf_gelu(v.w);
-      } else if (EPI == EPI_DROP_RES) {
-        if (g.drop.on) {
-          const uint32_t e = (uint32_t)(m * g.N + n);
-          v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
-          v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
-        }
-        v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
-      } else if (EPI == EPI_GELU_GRAD) {
-        v.x *= xf_gelu_grad(aux[ps].x); v.y *= xf_gelu_grad(aux[ps].y);
-        v.z *= xf_gelu_grad(aux[ps].z); v.w *= xf_gelu_grad(aux[ps].w);
+      for (int ps = 0; ps < NPASS; ++ps) {
+        aux[ps] = make_float4(0, 0, 0, 0);
+        const int64_t m = mb + prow + RPP * ps;
+        if (has_aux && aux_src && ncol && m < g.M) aux[ps] = xf_ld4<aux16>(aux_src, m * g.ldc + n);
       }
-      xf_st4<(c16 && EPI != EPI_SPLITK)>(g.C, zoff + o, v);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[i][j][8 * hf + r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave re-reads its own writes
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = prow + RPP * ps;
+        const int64_t m = mb + row;
+        if (!ncol || m >= g.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        const int64_t o = m * g.ldc + n;
+        if (EPI == EPI_STORE) {
+          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
+        } else if (EPI == EPI_GELU) {
+          xf_st4<c16>(g.C2, o, v);
+          v.x = xf_gelu(v.x); v.y = xf_gelu(v.y); v.z = xf_gelu(v.z); v.w = xf_gelu(v.w);
+        } else if (EPI == EPI_DROP_RES) {
+          if (g.drop.on) {
+            const uint32_t e = (uint32_t)(m * g.N + n);
+            v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
+            v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
+          }
+          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
+        } else if (EPI == EPI_GELU_GRAD) {
+          v.x *= xf_gelu_grad(aux[ps].x); v.y *= xf_gelu_grad(aux[ps].y);
+          v.z *= xf_gelu_grad(aux[ps].z); v.w *= xf_gelu_grad(aux[ps].w);
+        }
+        xf_st4<(c16 && EPI != EPI_SPLITK)>(g.C, zoff + o, v);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();  // the next half strip overwrites the scratch
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();  // the next strip overwrites the scratch
   }
 }
 
