@@ -451,13 +451,23 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     AI::tile_nreg(s, sK, kb * 32, qreg.regs());
     float bmax = -INFINITY;
-    const uint32_t kbits = sBits[kb] >> (4 * (lane >> 5));  // this half-wave's keys: bit (r&3) + 8*(r>>2)
+    const uint32_t kword = sBits[kb];
+    // interior tile: every key is at or before the wave's first query and none is padding -- no per-score masking
+    const bool interior = kb * 32 + 31 <= q0 && __builtin_amdgcn_readfirstlane(kword) == 0xFFFFFFFFu;
+    if (interior) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + xf_acc_row(r, lane);
-      const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
-      s[r] = vis ? s[r] * sc : -INFINITY;
-      bmax = fmaxf(bmax, s[r]);
+      for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, s[r]);
+      bmax *= sc;
+    } else {
+      const uint32_t kbits = kword >> (4 * (lane >> 5));  // this half-wave's keys: bit (r&3) + 8*(r>>2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + xf_acc_row(r, lane);
+        const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
+        s[r] = vis ? s[r] : -INFINITY;
+        bmax = fmaxf(bmax, s[r]);
+      }
+      bmax *= sc;  // (sc > 0; -inf stays -inf)
     }
     bmax = fmaxf(bmax, xf_half_swap(bmax));
     const float mnew = fmaxf(m, bmax);
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = xf_exp2(s[r] - msafe);
+      const float p = xf_exp2(fmaf(s[r], sc, -msafe));
       psum += p;
       s[r] = a.drop.on ? p * xf_keep_scale(a.drop, ebase + (uint32_t)(kb * 32 + xf_acc_row(r, lane))) : p;
     }
@@ -533,15 +543,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     AI::tile_nreg(s, sK, kb * 32, qreg.regs());
     AI::tile_nreg(dp, sV, kb * 32, doreg.regs());
-    const uint32_t kbits = sBits[kb] >> (4 * (lane >> 5));
+    const uint32_t kword = sBits[kb];
+    const bool interior = kb * 32 + 31 <= q0 && __builtin_amdgcn_readfirstlane(kword) == 0xFFFFFFFFu;
+    if (interior) {  // (see attn_fwd_bf16_kernel)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + xf_acc_row(r, lane);
-      const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
-      const float p = vis ? xf_exp2(s[r] * sc - lse2) : 0.f;
-      float dpv = dp[r];
-      if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)key);
-      s[r] = p * (dpv - delta);
+      for (int r = 0; r < 16; ++r) {
+        const float p = xf_exp2(fmaf(s[r], sc, -lse2));
+        float dpv = dp[r];
+        if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)(kb * 32 + xf_acc_row(r, lane)));
+        s[r] = p * (dpv - delta);
+      }
+    } else {
+      const uint32_t kbits = kword >> (4 * (lane >> 5));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + xf_acc_row(r, lane);
+        const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
+        const float p = vis ? xf_exp2(fmaf(s[r], sc, -lse2)) : 0.f;
+        float dpv = dp[r];
+        if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)key);
+        s[r] = p * (dpv - delta);
+      }
     }
     AI::tile_xb_tr(dq, sK, 0, kb * 32, s);
   }
@@ -612,6 +634,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   f32x16 dk, dv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+  const bool all_kvis = __all(kvis);
   for (int qb = active ? k0 / 32 : Lp / 32; qb < Lp / 32; ++qb) {
     const int row0 = qb * 32 - kblk0;
     f32x16 s, dp;
@@ -619,6 +642,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     AI::tile_nreg(s, sQ, row0, kreg.regs());
     AI::tile_nreg(dp, sDO, row0, vreg.regs());
+    const bool interior = all_kvis && qb * 32 > k0;  // every query row is after the wave's keys, every key valid
     // the lane's 16 query rows are four runs of 4 consecutive rows: lse / delta come as 16-byte LDS reads
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -626,12 +650,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
       const float4 l4 = *reinterpret_cast<const float4*>(&sLse[qi0]);
       const float4 d4 = *reinterpret_cast<const float4*>(&sDelta[qi0]);
       const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+      float pr[4];
+      if (interior) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pr[u] = xf_exp2(fmaf(s[4 * g + u], sc, -ls[u]));
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          pr[u] = (kvis && key <= qi0 + u + kblk0) ? xf_exp2(fmaf(s[4 * g + u], sc, -ls[u])) : 0.f;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int r = 4 * g + u;
         const int q = qi0 + u + kblk0;
-        const bool vis = kvis && (key <= q);
-        const float p = vis ? xf_exp2(s[r] * sc - ls[u]) : 0.f;
+        const float p = pr[u];
         float keep = 1.f;
         if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blk.by * L + q) * L) + (uint32_t)key);
         s[r] = p * (dp[r] * keep - dl[u]);
