@@ -218,6 +218,51 @@ def test_attention_dropout_forward_backward_agree(ops):
     assert not torch.allclose(ctx, ctx0)  # dropout really changed the output
 
 
+@pytest.mark.parametrize("B,L,A", [(2, 200, 2), (1, 96, 1)])
+def test_attention_dropout_mask_is_shared_by_all_kernels(ops, B, L, A):
+    """The dropout decision is a function of (seed, site, query row, key column) only: the bf16 kernels (forward,
+    dQ, dK/dV -- interior and diagonal tiles, row keys staged in LDS) must apply the mask the fp32 kernels apply,
+    whose forward / backward agreement the finite-difference test above checks."""
+    H = 32 * A
+    qkv = _rand(B, L, 3 * H, seed=5).to(DEV)
+    mask = torch.ones(B, L, dtype=torch.uint8, device=DEV)
+    mask[0, L - 9:] = 0
+    w = (_rand(B, L, H, seed=6).to(DEV)) * mask[..., None]
+    kw = dict(dropout_p=0.25, seed=3, site=2)
+    ctx32, lse32 = ops.attn_fwd(qkv, mask, A, precision="fp32", **kw)
+    d32 = ops.attn_bwd(qkv, mask, ctx32, lse32, w, A, precision="fp32", **kw)
+    ctx16, lse16 = ops.attn_fwd(qkv, mask, A, precision="bf16", **kw)
+    d16 = ops.attn_bwd(qkv, mask, ctx16, lse16, w, A, precision="bf16", **kw)
+    valid = mask.bool()
+    assert_close("attn.ctx (dropout)", ctx16[valid].cpu(), ctx32[valid].cpu(), "bf16")
+    assert_close("attn.d_qkv (dropout)", d16.cpu(), d32.cpu(), "bf16", "grad")
+    # another site (= layer) draws another mask
+    ctx_other, _ = ops.attn_fwd(qkv, mask, A, precision="bf16", **(kw | {"site": 3}))
+    assert not torch.allclose(ctx_other, ctx16)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_attention_dropout_keep_rate(ops, prec):
+    """q = k = 0 makes the causal softmax uniform and v = 1 turns ctx[q] into (kept keys of row q) / ((q+1)(1-p)):
+    the kept fraction over all (row, key) pairs must be 1 - p within sampling error, per head and overall."""
+    B, L, A, p = 16, 200, 4, 0.1
+    H = 32 * A
+    qkv = torch.zeros(B, L, 3 * H, device=DEV)
+    qkv[..., 2 * H:] = 1.0
+    mask = torch.ones(B, L, dtype=torch.uint8, device=DEV)
+    ctx, _ = ops.attn_fwd(qkv, mask, A, dropout_p=p, seed=1234, site=1, precision=prec)
+    rows = torch.arange(1, L + 1, device=DEV, dtype=torch.float32)
+    kept = ctx.view(B, L, A, 32)[..., 0] * rows[None, :, None] * (1 - p)  # (B, L, A) kept keys per row
+    total = B * A * L * (L + 1) / 2
+    rate = float(kept.sum()) / total
+    sigma = (p * (1 - p) / total) ** 0.5
+    assert abs(rate - (1 - p)) <= 5 * sigma + 2e-3 * (prec == "bf16"), (rate, sigma)
+    per_head = kept.sum(dim=(0, 1)) / (total / A)
+    assert float((per_head - (1 - p)).abs().max()) <= 5 * sigma * A**0.5 + 2e-3 * (prec == "bf16")
+    # per-key-column and per-row keep rates show no structure (columns 0..L-1 are seen by L-col rows each)
+    assert float(kept[:, -1, :].mean()) / L == pytest.approx(1 - p, abs=0.02)
+
+
 def test_adamw_matches_torch(ops):
     n = 10007
     p, g = _rand(n, seed=1), _rand(n, seed=2)

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
+  const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blockIdx.y * L + q));
 
   const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
   for (int kb = 0; kb <= kb_end; ++kb) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) {
       const float p = exp2f(s[r] - msafe);  // masked: exp2(-inf) = 0
       psum += p;
-      s[r] = a.drop.on ? p * xf_keep_scale(a.drop, ebase + (uint32_t)(kb * 32 + xf_acc_row(r, lane))) : p;
+      s[r] = a.drop.on ? p * xf_keep_scale_rc(a.drop, rowkey, (uint32_t)(kb * 32 + xf_acc_row(r, lane)) * kDropColMul) : p;
     }
     lsum = lsum * alpha + psum;
 #pragma unroll
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   delta += xf_half_swap(delta);
   const float lse2 = qv ? a.lse[(int64_t)blockIdx.y * L + q] * kLog2e : INFINITY;
   const float sc = 0.17677669529663687f * kLog2e;
-  const uint32_t ebase = (uint32_t)(((int64_t)blockIdx.y * L + q) * L);
+  const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blockIdx.y * L + q));
 
   f32x16 dq;
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
       const bool vis = (key <= q) && sMask[key];
       const float p = vis ? exp2f(s[r] * sc - lse2) : 0.f;
       float dpv = dp[r];
-      if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)key);
+      if (a.drop.on) dpv *= xf_keep_scale_rc(a.drop, rowkey, (uint32_t)key * kDropColMul);
       s[r] = p * (dpv - delta);
     }
     P::tile_xb(dq, sKT, ldt, 0, kb * 32, s);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       const bool vis = kvis && (key <= q);
       const float p = vis ? exp2f(s[r] * sc - sLse[qi]) : 0.f;  // q >= L: lse = +inf -> 0
       float keep = 1.f;
-      if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blockIdx.y * L + q) * L) + (uint32_t)key);
+      if (a.drop.on) keep = xf_keep_scale_rc(a.drop, xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blockIdx.y * L + q)), (uint32_t)key * kDropColMul);
       s[r] = p * (dp[r] * keep - sDelta[qi]);  // dS
       dp[r] = p * keep;                        // P.D
     }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  const uint32_t ebase = (uint32_t)(((int64_t)blk.by * L + q) * L);
+  const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + q));
   const int kb_end = active ? min((q0 + 31) / 32, nkeys / 32 - 1) : -1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) {
       const float p = xf_exp2(fmaf(s[r], sc, -msafe));
       psum += p;
-      s[r] = a.drop.on ? p * xf_keep_scale(a.drop, ebase + (uint32_t)(kb * 32 + xf_acc_row(r, lane))) : p;
+      s[r] = a.drop.on ? p * xf_keep_scale_rc(a.drop, rowkey, (uint32_t)(kb * 32 + xf_acc_row(r, lane)) * kDropColMul) : p;
     }
     lsum = lsum * alpha + psum;
 #pragma unroll
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   delta += xf_half_swap(delta);
   const float lse2 = qv ? a.lse[(int64_t)blk.by * L + q] * kLog2e : INFINITY;
   const float sc = 0.17677669529663687f * kLog2e;
-  const uint32_t ebase = (uint32_t)(((int64_t)blk.by * L + q) * L);
+  const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + q));
   f32x16 dq;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) {
         const float p = xf_exp2(fmaf(s[r], sc, -lse2));
         float dpv = dp[r];
-        if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)(kb * 32 + xf_acc_row(r, lane)));
+        if (a.drop.on) dpv *= xf_keep_scale_rc(a.drop, rowkey, (uint32_t)(kb * 32 + xf_acc_row(r, lane)) * kDropColMul);
         s[r] = p * (dpv - delta);
       }
     } else {
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
         const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
         const float p = vis ? xf_exp2(fmaf(s[r], sc, -lse2)) : 0.f;
         float dpv = dp[r];
-        if (a.drop.on) dpv *= xf_keep_scale(a.drop, ebase + (uint32_t)key);
+        if (a.drop.on) dpv *= xf_keep_scale_rc(a.drop, rowkey, (uint32_t)key * kDropColMul);
         s[r] = p * (dpv - delta);
       }
     }
@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   float* scratch = reinterpret_cast<float*>(smem_raw);  // aliases the Q / dO images: see attn_fwd_bf16_kernel
   float* sLse = reinterpret_cast<float*>(smem_raw + bf16_panel_bytes(L));
   float* sDelta = sLse + nq;
+  uint32_t* sRowKey = reinterpret_cast<uint32_t*>(sDelta + nq);  // dropout row keys of the staged query rows
 
   const int64_t tok0 = (int64_t)b * L;
   const int64_t hoff = tok0 * H + h * DH;
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
       if (c < nq * 8 && (c & 7) == 0) {
         sDelta[r] = part;
         sLse[r] = ls[u];
+        sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + kblk0 + r));
       }
     }
   }
@@ -635,6 +637,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
   const bool all_kvis = __all(kvis);
+  const uint32_t colmix = (uint32_t)key * kDropColMul;
   for (int qb = active ? k0 / 32 : Lp / 32; qb < Lp / 32; ++qb) {
     const int row0 = qb * 32 - kblk0;
     f32x16 s, dp;
@@ -650,6 +653,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
       const float4 l4 = *reinterpret_cast<const float4*>(&sLse[qi0]);
       const float4 d4 = *reinterpret_cast<const float4*>(&sDelta[qi0]);
       const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+      uint32_t rk[4] = {0u, 0u, 0u, 0u};
+      if (a.drop.on) {
+        const uint4 k4 = *reinterpret_cast<const uint4*>(&sRowKey[qi0]);
+        rk[0] = k4.x; rk[1] = k4.y; rk[2] = k4.z; rk[3] = k4.w;
+      }
       float pr[4];
       if (interior) {
 #pragma unroll
@@ -662,10 +670,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int r = 4 * g + u;
-        const int q = qi0 + u + kblk0;
         const float p = pr[u];
         float keep = 1.f;
-        if (a.drop.on) keep = xf_keep_scale(a.drop, (uint32_t)(((int64_t)blk.by * L + q) * L) + (uint32_t)key);
+        if (a.drop.on) keep = xf_keep_scale_rc(a.drop, rk[u], colmix);
         s[r] = p * (dp[r] * keep - dl[u]);
         dp[r] = p * keep;
       }
@@ -686,7 +693,7 @@ size_t bf16_smem_fwd(int L) {  // K + V images (aliased by the transposed-store 
 }
 size_t bf16_smem_dkv(int L) {  // Q + dO images (aliased by the scratch), lse + delta
   const int Lp = ((L + 31) / 32) * 32;
-  return bf16_panel_bytes(L) + 2 * (size_t)Lp * sizeof(float);
+  return bf16_panel_bytes(L) + 3 * (size_t)Lp * sizeof(float);
 }
 
 template <class P>
