@@ -361,6 +361,13 @@ __device__ __forceinline__ float xf_gelu(float x) {
   float e;
   return 0.5f * x * (1.f + xf_erf_sqrt2(x, e));
 }
+// gelu(x) and gelu'(x) = Phi(x) + x phi(x) from ONE erf / exp evaluation
+__device__ __forceinline__ float xf_gelu_both(float x, float& grad) {
+  float e;
+  const float cdf = 0.5f * (1.f + xf_erf_sqrt2(x, e));
+  grad = fmaf(x * 0.3989422804014327f, e, cdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float xf_gelu_grad(float x) {
   float e;
   const float er = xf_erf_sqrt2(x, e);

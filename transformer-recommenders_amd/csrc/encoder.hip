@@ -51,8 +51,8 @@ LayerParams layer_params(const xfmr_encoder_cfg* c, int i) {
 
 // Activation storage: with the bf16 MFMA policy the tensors that are only ever MFMA operands are kept in HBM as
 // bf16 ("mixed" storage; bit-identical products, half the bytes): qkv, ctx, the GELU output g, and in backward the
-// gradients d_lin / d_ctx / dQKV / dI that feed the dX and dW GEMMs. The GELU pre-activation f1 is bf16 too (gelu'
-// is evaluated on the rounded value; covered by the bf16 tolerance of the parity tests). Everything that is added,
+// gradients d_lin / d_ctx / dQKV / dI that feed the dX and dW GEMMs. f1 holds gelu'(pre) -- not the pre-activation: the forward
+// epilogue has erf and exp(-x^2/2) in registers, the backward epilogue multiplies -- and is bf16 too. Everything that is added,
 // normalised or reduced elementwise (residual streams, LayerNorm inputs, statistics) stays fp32.
 // XFMR_ACT_FP32=1 keeps every activation fp32 (A/B measurements).
 struct LayerActs {
@@ -243,7 +243,7 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     XF_TRY(xfmr_layernorm_fwd(l.pre1, params + p.ln1g, params + p.ln1b, l.x1, l.mean1, l.rstd1, T, H, cfg->ln_eps,
                               stream));
     XF_TRY(xf_linear_fwd_ex(l.x1, params + p.w1, params + p.b1, l.g, T, I, H, XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f,
-                            0, 0, prec, mix ? XF_S16_C : 0, st));
+                            0, 0, prec, (mix ? XF_S16_C : 0) | XF_AUX_GELU_GRAD, st));  // f1 <- gelu'(pre)
     XF_TRY(xf_linear_fwd_ex(l.g, params + p.w2, params + p.b2, l.pre2, T, H, I, XFMR_EPI_BIAS_DROP_RES, l.x1, nullptr,
                             cfg->hidden_dropout, cfg->seed, site_ffn(i), prec, mix ? XF_S16_A : 0, st));
     XF_TRY(xfmr_layernorm_fwd(l.pre2, params + p.ln2g, params + p.ln2b, out, l.mean2, l.rstd2, T, H, cfg->ln_eps,
@@ -300,7 +300,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     const void* dlin = lin_copy ? a.dLin : (const void*)a.dA;
     XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, st));
     seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
-    XF_TRY(xf_linear_bwd_dx_ex(dlin, params + p.w2, a.dI, T, H, I, nullptr, l.f1, prec, sA | sC | sP, st));
+    XF_TRY(xf_linear_bwd_dx_ex(dlin, params + p.w2, a.dI, T, H, I, nullptr, l.f1, prec, sA | sC | sP | XF_AUX_GELU_GRAD, st));
     XF_TRY(xf_linear_bwd_dw_deferred(a.dI, l.x1, T, I, H, prec, sA, r.w1, r.b1, &splits, st));  // + b1 partial rows
     seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
     seg(r.b1, grads + p.b1, splits, I, I);

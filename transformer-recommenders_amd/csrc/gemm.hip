@@ -26,6 +26,7 @@ struct GemmArgs {
   const float* R;         // residual / residual-grad [M,ldc] or null
   const void* P;          // pre-activation for gelu' [M,ldc]
   void* C2;               // pre-activation output for EPI_GELU
+  int aux_grad;           // C2 / P hold gelu'(pre) instead of pre (XF_AUX_GELU_GRAD)
   uint32_t s16;           // XF_S16_* storage mask (bf16 policy only)
   float* bias_part;       // EPI_SPLITK with A' = dy^T: row sums of A' over this split's K range -> [splits][M]
   XfDropout drop;
@@ -357,8 +358,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         if (EPI == EPI_STORE) {
           v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
         } else if (EPI == EPI_GELU) {
-          xf_st4<c16>(g.C2, o, v);
-          v.x = xf_gelu(v.x); v.y = xf_gelu(v.y); v.z = xf_gelu(v.z); v.w = xf_gelu(v.w);
+          if (g.aux_grad) {  // C2 <- gelu'(pre): both values from one erf / exp
+            float4 d;
+            v.x = xf_gelu_both(v.x, d.x); v.y = xf_gelu_both(v.y, d.y);
+            v.z = xf_gelu_both(v.z, d.z); v.w = xf_gelu_both(v.w, d.w);
+            xf_st4<c16>(g.C2, o, d);
+          } else {
+            xf_st4<c16>(g.C2, o, v);
+            v.x = xf_gelu(v.x); v.y = xf_gelu(v.y); v.z = xf_gelu(v.z); v.w = xf_gelu(v.w);
+          }
         } else if (EPI == EPI_DROP_RES) {
           if (g.drop.on) {
             const uint32_t e = (uint32_t)(m * g.N + n);
@@ -367,8 +375,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
           }
           v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
         } else if (EPI == EPI_GELU_GRAD) {
-          v.x *= xf_gelu_grad(aux[ps].x); v.y *= xf_gelu_grad(aux[ps].y);
-          v.z *= xf_gelu_grad(aux[ps].z); v.w *= xf_gelu_grad(aux[ps].w);
+          if (g.aux_grad) {
+            v.x *= aux[ps].x; v.y *= aux[ps].y; v.z *= aux[ps].z; v.w *= aux[ps].w;
+          } else {
+            v.x *= xf_gelu_grad(aux[ps].x); v.y *= xf_gelu_grad(aux[ps].y);
+            v.z *= xf_gelu_grad(aux[ps].z); v.w *= xf_gelu_grad(aux[ps].w);
+          }
         }
         xf_st4<(c16 && EPI != EPI_SPLITK)>(g.C, zoff + o, v);
       }
@@ -535,10 +547,11 @@ int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, 
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(x) || !xf_aligned16(w) || !xf_aligned16(y)) return XFMR_EALIGN;
-  if (s16 && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   GemmArgs g{};
   g.A = x; g.B = w; g.C = y; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K; g.k_chunk = 0;
   g.bias = bias; g.R = residual; g.C2 = aux_out; g.P = nullptr; g.s16 = s16 & (XF_S16_A | XF_S16_C);
+  g.aux_grad = (s16 & XF_AUX_GELU_GRAD) != 0;
   g.drop = xf_make_dropout(dropout_p, seed, site);
   switch (epilogue) {
     case XFMR_EPI_BIAS:
@@ -568,12 +581,13 @@ int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int
   if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(w) || !xf_aligned16(dx)) return XFMR_EALIGN;
-  if (s16 && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   // dx[M,K] = dy[M,N] * w[N,K]: contraction over N; B' [K rows][N] = w^T -> w is stored [N][K] = K-major
   GemmArgs g{};
   g.A = dy; g.B = w; g.C = dx; g.lda = N; g.ldb = K; g.ldc = K; g.M = M; g.N = K; g.K = N; g.k_chunk = 0;
   g.bias = nullptr; g.R = residual_grad; g.P = gelu_pre; g.C2 = nullptr;
   g.s16 = s16 & (XF_S16_A | XF_S16_C | XF_S16_P);
+  g.aux_grad = (s16 & XF_AUX_GELU_GRAD) != 0;
   g.drop = xf_make_dropout(0.f, 0, 0);
   if (gelu_pre)
     return dispatch_gemm<false, true, EPI_GELU_GRAD, (XF_S16_A | XF_S16_C | XF_S16_P)>(g, 1, precision, st);
@@ -597,7 +611,7 @@ int xf_linear_bwd_dw_ex(const void* dy, const void* x, float* dw, int64_t M, int
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(workspace)) return XFMR_EALIGN;
   if (workspace_bytes < xfmr_linear_bwd_dw_workspace(M, N, K)) return XFMR_EWORKSPACE;
-  if (s16 && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   // dw[N,K] = dy^T[N,M] * x[M,K]: contraction over M. A' = dy^T (dy stored [M][N]), B'[K rows][M] = x^T.
   int k_chunk;
   int splits = dw_split_plan(M, N, K, &k_chunk);
@@ -619,7 +633,7 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
   if (!dy || !x || !slabs || !splits_out || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(slabs)) return XFMR_EALIGN;
-  if (s16 && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   int k_chunk;
   const int splits = dw_split_plan(M, N, K, &k_chunk);
   GemmArgs g{};

@@ -10,6 +10,9 @@ enum : uint32_t {
   XF_S16_B = 2u,    // GEMM operand B when it is an activation (dW)
   XF_S16_C = 4u,    // GEMM output (and the pre-activation side output of the GELU epilogue)
   XF_S16_P = 8u,    // pre-activation input of the gelu' epilogue
+  // (not a storage bit) the GELU Linear's auxiliary tensor holds gelu'(pre) instead of pre: the forward epilogue has
+  // erf and exp(-x^2/2) in registers anyway, and the backward dX epilogue becomes one multiply
+  XF_AUX_GELU_GRAD = 0x100u,
 };
 
 extern "C" {
