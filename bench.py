@@ -259,7 +259,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.precision,
-            "data": "synthetic",
+            "data": "synthetic" if not D.rehearsal_on_one_gpu() else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {
                 "workload": (f"MovieLens-1M-shaped: {V} items, seq_len={L}, d_model={H}, {args.layers}-layer causal BERT "
                              f"(heads={H // 32}, ffn={args.inter}), {args.loss} over in-batch shared negatives, AdamW"),

@@ -26,10 +26,19 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        if rehearsal_on_one_gpu():
+            backend, local = "gloo", 0  # RCCL refuses two ranks on one device
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def rehearsal_on_one_gpu() -> bool:
+    """XFMR_REHEARSE_ONE_GPU=1: run a multi-rank job's ranks on device 0 with the gloo backend -- exercises the
+    N > 1 control flow (rendezvous, barriers, the all-reduce call, max-over-ranks timing) where only one GPU is at
+    hand. Never a measurement configuration."""
+    return os.environ.get("XFMR_REHEARSE_ONE_GPU", "0") == "1"
 
 
 def shard_rows(n_rows: int, rank: int, world: int) -> range:
