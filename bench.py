@@ -67,9 +67,24 @@ def parse():
                     help="logging heads on a side stream under the encoder backward: pays off once the logging pass is "
                          "long enough (B*L >= 51200: +2 %% at B=512; -2 %% at B=128); auto decides by that")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)  # former default switch; no effect
+    ap.add_argument("--heads", type=int, default=0, help="attention heads (default hidden/32: head size 32)")
+    ap.add_argument("--negatives", default="in_batch", choices=["in_batch", "catalogue"],
+                    help="catalogue = full-catalogue softmax (BASELINE config 4; SURVEY F9)")
+    ap.add_argument("--preset", default=None, choices=["config2", "config3", "config4", "config5"],
+                    help="the other BASELINE.json configs as sanity workloads (the bench line is config2, the default)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=12)
-    return ap.parse_args()
+    args = ap.parse_args()
+    presets = {
+        "config2": {},
+        "config3": dict(loss="PairwiseLogisticLoss"),
+        "config4": dict(items=27278, hidden=256, layers=6, inter=1024, batch=64, negatives="catalogue"),
+        "config5": dict(items=1_000_000, seq_len=512, hidden=256, layers=4, inter=1024, batch=64,
+                        loss="AlignmentContrastiveLoss"),
+    }
+    for k, v in presets.get(args.preset or "config2", {}).items():
+        setattr(args, k, v)
+    return args
 
 
 def synth_batch(B, L, V, seed, lengths_mode):
@@ -168,9 +183,11 @@ def main():
     dev = torch.device("cuda", local)
 
     B, L, H, V = args.batch, args.seq_len, args.hidden, args.items
-    conf = X.LightningConfig(hidden_size=H, num_attention_heads=H // 32, intermediate_size=args.inter,
+    catalogue = args.negatives == "catalogue"
+    conf = X.LightningConfig(hidden_size=H, num_attention_heads=args.heads or H // 32, intermediate_size=args.inter,
                              num_hidden_layers=args.layers, max_seq_length=L, train_loss=args.loss,
-                             precision=args.precision, log_all_losses=not args.lean)
+                             precision=args.precision, log_all_losses=not args.lean, negatives=args.negatives,
+                             **(dict(target_position=None, mask_false_negatives=False) if catalogue else {}))
     mod = X.RecommenderLightningModule(conf)
     mod.configure_model()
     mod.model.set_table(unit_table(V, H).to(dev))
@@ -261,8 +278,10 @@ def main():
             "dtype": args.precision,
             "data": "synthetic" if not D.rehearsal_on_one_gpu() else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {
-                "workload": (f"MovieLens-1M-shaped: {V} items, seq_len={L}, d_model={H}, {args.layers}-layer causal BERT "
-                             f"(heads={H // 32}, ffn={args.inter}), {args.loss} over in-batch shared negatives, AdamW"),
+                "workload": (f"{'MovieLens-1M-shaped' if V == 3883 else 'synthetic'}: {V} items, seq_len={L}, "
+                             f"d_model={H}, {args.layers}-layer causal BERT (heads={args.heads or H // 32}, "
+                             f"ffn={args.inter}), {args.loss} over "
+                             f"{'the full item catalogue' if catalogue else 'in-batch shared negatives'}, AdamW"),
                 "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "lengths": args.lengths,
                 "mean_tokens_per_sequence": round(tokens_per_seq, 1),
                 "loss_heads_evaluated": "train head only" if args.lean else "all 7 + LogitsStatistics (reference training_step)",

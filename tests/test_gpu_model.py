@@ -428,6 +428,45 @@ def test_three_adamw_steps_match_reference_golden(X, golden_dir, train_loss):
     assert "model.embeddings.weight" not in sd and any(k.startswith("model.model.0.auto_model.") for k in sd)
 
 
+def test_full_catalogue_training_step_equals_dense_cross_entropy(X, golden_dir):
+    """LightningConfig.negatives='catalogue' (BASELINE config 4): the training step's InfoNCE is
+    cross_entropy(Q E^T, pos, 'sum') over every row of the item table -- the reference API's
+    EmbedLoss.forward(q, table[None].expand(N,-1,-1), target=pos_idx), target_position=None, mask_false_negatives
+    False -- and its parameter gradients are those of that dense form pushed through the encoder backward."""
+    g3 = np.load(golden_dir / "g3_step.npz")
+    cfg = json.loads(str(g3["cfg"]))
+    conf = X.LightningConfig(hidden_size=cfg["H"], num_attention_heads=cfg["A"], intermediate_size=cfg["I"],
+                             num_hidden_layers=cfg["nL"], max_seq_length=cfg["L"], train_loss="InfoNCELoss",
+                             precision="fp32", negatives="catalogue", target_position=None,
+                             mask_false_negatives=False)
+    mod = X.RecommenderLightningModule(conf)
+    mod.configure_model()
+    mod.model.load_encoder_state_dict({k[len("param0/"):]: _t(g3[k]) for k in g3.files if k.startswith("param0/")})
+    mod.model.set_table(_t(g3["table"]).to(DEV))
+    mod = mod.to(DEV).eval()
+    batch = {"history_item_idx": _t(g3["hist"]), "pos_item_idx": _t(g3["pos"])}  # no negatives are sampled
+    mod.model.flat.requires_grad_(True)
+    out = mod.compute_losses(batch)
+    out["loss/InfoNCELoss"].backward()
+    got_grad = mod.model.flat.grad.clone()
+    # the closed form on the same token embeddings (torch on the device as the checker)
+    mod.model.flat.grad = None
+    tok, key_mask = mod.model._encode_tokens(batch["history_item_idx"])
+    pos = batch["pos_item_idx"].to(DEV)[:, -tok.shape[1]:]
+    rows = key_mask.bool() & (pos != 0)
+    want = torch.nn.functional.cross_entropy(tok[rows] @ mod.model.embeddings.T, pos[rows], reduction="sum")
+    want.backward()
+    assert float(out["loss/InfoNCELoss"]) == pytest.approx(float(want), rel=1e-4)
+    assert rel_l2(got_grad, mod.model.flat.grad) <= 5e-4
+    assert out["batch/positive_non_zero"] == int(rows.sum())
+    with pytest.raises(ValueError):  # the catalogue form names the positive by `target`
+        bad = X.LightningConfig(**(conf.model_dump() | {"target_position": "first"}))
+        m2 = X.RecommenderLightningModule(bad)
+        m2.configure_model()
+        m2.model.set_table(_t(g3["table"]).to(DEV))
+        m2.to(DEV).compute_losses(batch)
+
+
 def test_training_mode_dropout_and_trainer_loop(X, golden_dir):
     """Training mode (dropout 0.1 as TF:configuration_bert.py): loss differs from eval, is finite, decreases."""
     # (InfoNCE with false-negative masking is not monotone even in the reference's own run -- g3 loss_step0..2

@@ -44,6 +44,11 @@ class LightningConfig(LossConfig, ModelConfig):
     # build-specific knobs (not in the reference)
     precision: str = "bf16"  # MFMA arithmetic: "bf16" (reference default bf16-mixed) or "fp32"
     log_all_losses: bool = True  # evaluate all 7 heads + statistics every step like trainer.py:250-264
+    # "in_batch": [positive | the batch's sampled negatives] (models.py:366-419, the reference's only mode);
+    # "catalogue": every row of the item table is a column and pos_item_idx is the target -- the reference API's
+    # EmbedLoss.forward(q, table[None].expand(N,-1,-1), target=pos_idx) with target_position=None (SURVEY F9;
+    # BASELINE config 4 "full-catalogue softmax"). The (Np x V) logits are never materialised.
+    negatives: str = "in_batch"
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -135,8 +140,14 @@ class RecommenderLightningModule(_Base):
         """
         assert self.model is not None
         m, c = self.model, self.config
-        if c.target_position != "first":
+        if c.negatives not in ("in_batch", "catalogue"):
+            raise ValueError(f"invalid {c.negatives = }")
+        catalogue = c.negatives == "catalogue"
+        if not catalogue and c.target_position != "first":
             raise ValueError("the training path scores [positive | shared negatives]: target_position='first'")
+        if catalogue and c.target_position is not None:
+            raise ValueError("negatives='catalogue' names the positive by `target` (= pos_item_idx): "
+                             "target_position=None (losses.py:233-238)")
         dev = m.device
         hist = batch["history_item_idx"]
         tok, key_mask = m._encode_tokens(hist)
@@ -144,9 +155,9 @@ class RecommenderLightningModule(_Base):
             tok = ops.l2_normalize(tok)
         L = tok.shape[1]
         pos = batch["pos_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
-        neg = batch["neg_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
+        neg = None if catalogue else batch["neg_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
         opts = dict(train_head=c.train_loss, all_heads=c.log_all_losses, mask_false_negatives=c.mask_false_negatives,
-                    mode=N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision,
+                    mode=N.NEG_CATALOG if catalogue else N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision,
                     table_bf16=m.table_bf16, num_hard_negatives=c.num_hard_negatives)
         overlap = (defer_logging and c.log_all_losses and tok.requires_grad and torch.is_grad_enabled()
                    and m.table_bf16 is not None and c.precision == "bf16" and c.num_hard_negatives == 0)
@@ -167,7 +178,8 @@ class RecommenderLightningModule(_Base):
                     **(opts | {"all_heads": 2})
                 )
             for tns in (tok, key_mask, pos, neg):
-                tns.record_stream(side)
+                if tns is not None:
+                    tns.record_stream(side)
             self._logging_pending = True
         else:
             train_loss, losses, stats = ops.SampledLossFunction.apply(
