@@ -687,6 +687,235 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   xf_store_tile_T_at<S16>(sc_w, dv, 1.f, a.d_qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, k0, L);
 }
 
+// ---- fused backward: ONE workgroup per (batch, head) computes dQ, dK and dV -------------------------------------
+// The two-kernel form stages Q / dO / ctx / d_ctx (dK/dV kernel) and K / V / q / dO / ctx / d_ctx (dQ kernel) per
+// 128-row block and evaluates every probability twice; measured at B = 512, L = 200: 40 + 61 us of the 65 + 132 us
+// were staging and stores alone, not overlapped with the score loops. Here Q and dO are staged once, a wave owns
+// key tiles (dK, dV in registers, as before) and every score tile's dS additionally goes through a per-wave
+// 32 x 32 bf16 image -- written from the accumulator layout with 8-byte stores, read back TRANSPOSED as the MFMA
+// A operand -- for dQ[q][d] += sum_key dS[q][key] K[key][d], which is added into an fp32 [L][32] accumulator in LDS
+// (ds_add_f32; the four waves reach a query tile at different times). Key tiles are dealt to the waves in snake
+// order (w, 7-w, 8+w, 15-w, ...): tile t has (tiles - t) query tiles to walk, so the pairs balance.
+// Lock-step schedule of the fused backward: kBwdSched[tiles - 1][wave][step] = key tile << 4 | query tile (255 =
+// idle). A wave walks one key tile's query tiles contiguously (dK / dV stay in registers), the loads are balanced
+// (snake deal of the key tiles) and within a step the four waves hold four DIFFERENT query tiles, so the dQ
+// accumulator tile in LDS is read-modify-written without atomics (ds_add_f32 measured 2.5 cycles PER LANE: 244 us of
+// a 354 us kernel) and in a fixed order: results are bit-reproducible. Found by exhaustive search over tile orders,
+// rotations and directions (up to 8 tiles = L <= 256; longer sequences use the two-kernel form).
+__constant__ uint8_t kBwdSched[8][4][9] = {
+  {{0,255,255,255,255,255,255,255,255}, {255,255,255,255,255,255,255,255,255}, {255,255,255,255,255,255,255,255,255}, {255,255,255,255,255,255,255,255,255}},
+  {{0,1,255,255,255,255,255,255,255}, {17,255,255,255,255,255,255,255,255}, {255,255,255,255,255,255,255,255,255}, {255,255,255,255,255,255,255,255,255}},
+  {{0,1,2,255,255,255,255,255,255}, {17,18,255,255,255,255,255,255,255}, {34,255,255,255,255,255,255,255,255}, {255,255,255,255,255,255,255,255,255}},
+  {{0,1,2,3,255,255,255,255,255}, {17,18,19,255,255,255,255,255,255}, {34,35,255,255,255,255,255,255,255}, {51,255,255,255,255,255,255,255,255}},
+  {{0,1,2,3,4,255,255,255,255}, {19,18,17,20,255,255,255,255,255}, {34,35,36,255,255,255,255,255,255}, {68,52,51,255,255,255,255,255,255}},
+  {{0,1,2,3,4,5,255,255,255}, {21,20,19,18,17,255,255,255,255}, {34,35,36,37,85,255,255,255,255}, {68,69,53,52,51,255,255,255,255}},
+  {{0,1,2,3,4,5,6,255,255}, {102,22,21,20,19,18,17,255,255}, {34,35,36,37,38,86,85,255,255}, {68,69,70,54,53,52,51,255,255}},
+  {{0,1,2,3,4,5,6,7,119}, {102,103,23,22,21,20,19,18,17}, {34,35,36,37,38,39,87,86,85}, {68,69,70,71,55,54,53,52,51}},
+};
+__constant__ uint8_t kBwdSteps[8] = {1, 2, 3, 4, 5, 6, 7, 9};
+constexpr int kFusedMaxL = 256;
+
+__device__ __forceinline__ AttnBlock attn_seq_block(const AttnArgs& a) {  // as attn_block with one block per (b, h)
+  const int d = blockIdx.x, xcd = d & 7, slot = d >> 3;
+  const int b = (slot / a.A) * 8 + xcd;
+  return AttnBlock{0, b * a.A + slot % a.A, b < a.B};
+}
+
+template <bool S16>
+__global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const AttnBlock blk = attn_seq_block(a);
+  if (!blk.valid) return;  // (whole workgroup)
+  const int b = blk.by / a.A, h = blk.by % a.A;
+  const int Lp = ((L + 31) / 32) * 32, nt = Lp / 32;
+  __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* sDO = sQ + Lp * DH;
+  float* sDq = reinterpret_cast<float*>(sDO + Lp * DH);           // [Lp][32] fp32 dQ accumulator
+  float* sLse = sDq + Lp * DH;
+  float* sDelta = sLse + Lp;
+  uint32_t* sRowKey = reinterpret_cast<uint32_t*>(sDelta + Lp);
+  __bf16* sDS = reinterpret_cast<__bf16*>(sRowKey + Lp);          // [4 waves][32 keys][32 queries] swizzled
+
+  const int64_t tok0 = (int64_t)b * L;
+  const int64_t hoff = tok0 * H + h * DH;
+  stage2_rows_swz<S16>(sQ, a.qkv, tok0 * 3 * H + h * DH, 3 * H, sDO, a.d_ctx, hoff, H, 0, Lp, L);
+  for (int c = threadIdx.x; c < Lp * 8; c += (int)blockDim.x) reinterpret_cast<float4*>(sDq)[c] = make_float4(0, 0, 0, 0);
+  // delta[r] = rowsum(dO * O), lse[r], dropout row key: loads of a batch of 4 pieces issued together
+  for (int c0 = threadIdx.x; c0 < Lp * 8; c0 += (int)blockDim.x * 4) {
+    float4 x[4], y[4];
+    float ls[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * (int)blockDim.x, r = c >> 3, dd = (c & 7) * 4;
+      x[u] = y[u] = make_float4(0, 0, 0, 0);
+      ls[u] = INFINITY;
+      if (c < Lp * 8 && r < L) {
+        x[u] = xf_ld4<S16>(a.ctx, hoff + (int64_t)r * H + dd);
+        y[u] = xf_ld4<S16>(a.d_ctx, hoff + (int64_t)r * H + dd);
+        if ((c & 7) == 0) ls[u] = a.lse[(int64_t)blk.by * L + r] * kLog2e;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * (int)blockDim.x, r = c >> 3;
+      float part = x[u].x * y[u].x + x[u].y * y[u].y + x[u].z * y[u].z + x[u].w * y[u].w;
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      if (c < Lp * 8 && (c & 7) == 0) {
+        sDelta[r] = part;
+        sLse[r] = ls[u];
+        sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + r));
+      }
+    }
+  }
+  __syncthreads();
+
+  const int lane = xf_lane(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5;
+  __bf16* sDSw = sDS + wid * 32 * DH;
+  const float sc = 0.17677669529663687f * kLog2e;
+  // per-key-tile state of the wave
+  int cur_kt = -1, key = 0;
+  bool kin = false, kvis = false, all_kvis = false;
+  uint32_t colmix = 0;
+  RegRows<PrecBF16, DH> kreg, vreg;
+  bf16x8 kb[2];
+  f32x16 dk, dv;
+  auto flush = [&]() {  // dK / dV straight from the accumulator layout: lane = key row, 4 consecutive d per group
+    if (cur_kt >= 0 && kin) {
+      const int64_t o = (tok0 + key) * 3 * H + h * DH;
+      const float ks = 0.17677669529663687f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xf_st4<S16>(a.d_qkv, o + H + 8 * g + 4 * hh,
+                    make_float4(dk[4 * g] * ks, dk[4 * g + 1] * ks, dk[4 * g + 2] * ks, dk[4 * g + 3] * ks));
+        xf_st4<S16>(a.d_qkv, o + 2 * H + 8 * g + 4 * hh,
+                    make_float4(dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]));
+      }
+    }
+  };
+  const int steps = kBwdSteps[nt - 1];
+  for (int step = 0; step < steps; ++step) {
+    const int code = kBwdSched[nt - 1][wid][step];  // (wave-uniform)
+    if (code != 255) {
+      const int kt = code >> 4, qb = code & 15;
+      if (kt != cur_kt) {
+        flush();
+        cur_kt = kt;
+        const int k0 = kt * 32;
+        key = k0 + (lane & 31);
+        kin = key < L;
+        kvis = kin && a.key_mask[tok0 + (kin ? key : 0)];
+        all_kvis = __all(kvis);
+        colmix = (uint32_t)key * kDropColMul;
+        kreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + H + h * DH, kin);
+        vreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + 2 * H + h * DH, kin);
+        // B operand of the dQ product: K[k0 + row(j)][d = lane & 31] in the accumulator's row order
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int kr = k0 + xf_acc_row(8 * s + j, lane);
+            float v = 0.f;
+            if (kr < L) {
+              const int64_t o = (tok0 + kr) * 3 * H + H + h * DH + (lane & 31);
+              v = S16 ? (float)reinterpret_cast<const __bf16*>(a.qkv)[o] : reinterpret_cast<const float*>(a.qkv)[o];
+            }
+            kb[s][j] = (__bf16)v;
+          }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+      }
+      const int row0 = qb * 32;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      AI::tile_nreg(s, sQ, row0, kreg.regs());
+      AI::tile_nreg(dp, sDO, row0, vreg.regs());
+      const bool interior = all_kvis && qb > kt;  // every query row is after the wave's keys, every key valid
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qi0 = row0 + 8 * g + 4 * hh;
+        const float4 l4 = *reinterpret_cast<const float4*>(&sLse[qi0]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&sDelta[qi0]);
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+        uint32_t rk[4] = {0u, 0u, 0u, 0u};
+        if (a.drop.on) {
+          const uint4 k4 = *reinterpret_cast<const uint4*>(&sRowKey[qi0]);
+          rk[0] = k4.x; rk[1] = k4.y; rk[2] = k4.z; rk[3] = k4.w;
+        }
+        float pr[4];
+        if (interior) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pr[u] = xf_exp2(fmaf(s[4 * g + u], sc, -ls[u]));
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            pr[u] = (kvis && key <= qi0 + u) ? xf_exp2(fmaf(s[4 * g + u], sc, -ls[u])) : 0.f;
+        }
+        float4 ds4;
+        float* dsv = &ds4.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = 4 * g + u;
+          const float p = pr[u];
+          float keep = 1.f;
+          if (a.drop.on) keep = xf_keep_scale_rc(a.drop, rk[u], colmix);
+          s[r] = p * (dp[r] * keep - dl[u]);  // dS
+          dp[r] = p * keep;                   // P.D
+          dsv[u] = s[r];
+        }
+        // dS^T image: row = key (this lane), columns = the tile's queries 8g + 4hh .. + 3
+        *reinterpret_cast<uint2*>(sDSw + AI::off(lane & 31, g) + 4 * hh) = xf_f32x4_to_bf16(ds4);
+      }
+      AI::tile_xb_tr(dv, sDO, 0, row0, dp);
+      AI::tile_xb_tr(dk, sQ, 0, row0, s);
+      // dQ tile [q][d] += sum_key dS^T[key][q] K[key][d]: the tile of the LDS accumulator goes through the MFMA
+      // accumulator (no other wave touches query tile qb during this step: kBwdSched)
+      float* dq_ptr = sDq + (row0 + 4 * hh) * DH + (lane & 31);
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = dq_ptr[((r & 3) + 8 * (r >> 2)) * DH];
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave reads back its own image
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int g16 = lane >> 4, th = g16 >> 1, li = lane & 15, qq = li >> 2, pp = li & 3;
+        const int col = 16 * (g16 & 1) + 4 * pp;
+        const int c = col >> 3, within = col & 7;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          union { xf_s16x4 v[2]; bf16x8 f; } av;
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            const int row = 16 * st + 8 * t2 + 4 * th + qq;
+            av.v[t2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) xf_s16x4*)(sDSw + AI::off(row, c) + within));
+          }
+          dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.f, kb[st], dq, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq_ptr[((r & 3) + 8 * (r >> 2)) * DH] = dq[r];
+    }
+    __syncthreads();  // step boundary: the next step's query tiles are dealt differently
+  }
+  flush();
+  __syncthreads();
+  for (int c = threadIdx.x; c < L * 8; c += (int)blockDim.x) {
+    const int r = c >> 3, dd = (c & 7) * 4;
+    float4 v = *reinterpret_cast<const float4*>(&sDq[r * DH + dd]);
+    const float ks = 0.17677669529663687f;
+    v.x *= ks; v.y *= ks; v.z *= ks; v.w *= ks;
+    xf_st4<S16>(a.d_qkv, (tok0 + r) * 3 * H + h * DH + dd, v);
+  }
+}
+
+size_t bf16_smem_fused(int L) {  // Q + dO images, fp32 dQ accumulator, lse + delta + row keys, 4 dS images
+  const size_t Lp = ((size_t)L + 31) / 32 * 32;
+  return 2 * Lp * DH * 2 + Lp * DH * 4 + 3 * Lp * 4 + 4 * 32 * DH * 2;
+}
+
 size_t bf16_smem_fwd(int L) {  // K + V images (aliased by the transposed-store scratch), key mask
   const int Lp = ((L + 31) / 32) * 32;
   return bf16_panel_bytes(L) + (Lp / 32 + 2) * sizeof(uint32_t);
@@ -731,6 +960,17 @@ int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
 }
 template <bool S16>
 int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
+  static const int two_kernels = [] { const char* e = getenv("XFMR_ATTN_BWD_SPLIT"); return e ? atoi(e) : 0; }();
+  const size_t sf = bf16_smem_fused(a.L);
+  if (!two_kernels && a.L <= kFusedMaxL && sf <= kLdsLimit) {
+    if (hipFuncSetAttribute((const void*)attn_bwd_fused_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sf) != hipSuccess)
+      return XFMR_EHIP;
+    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<S16>), dim3((unsigned)(a.A * ((a.B + 7) / 8) * 8)), dim3(256), sf,
+                       st, a);
+    XF_LAUNCH_CHECK();
+    return XFMR_OK;
+  }
   dim3 grid((unsigned)(((a.L + 127) / 128) * a.A * ((a.B + 7) / 8) * 8));  // see attn_block
   const size_t s1 = bf16_smem_fwd(a.L), s2 = bf16_smem_dkv(a.L);
   if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
