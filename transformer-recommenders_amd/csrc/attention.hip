@@ -739,38 +739,62 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
 
   const int64_t tok0 = (int64_t)b * L;
   const int64_t hoff = tok0 * H + h * DH;
-  stage2_rows_swz<S16>(sQ, a.qkv, tok0 * 3 * H + h * DH, 3 * H, sDO, a.d_ctx, hoff, H, 0, Lp, L);
+  // Staging in ONE round trip: the Q, dO and ctx pieces of a row chunk are loaded together; Q and dO go to the
+  // swizzled images, delta[r] = rowsum(dO * O) is reduced over the lanes that hold the row's chunks.
   for (int c = threadIdx.x; c < Lp * 8; c += (int)blockDim.x) reinterpret_cast<float4*>(sDq)[c] = make_float4(0, 0, 0, 0);
-  // delta[r] = rowsum(dO * O), lse[r], dropout row key: loads of a batch of 4 pieces issued together
-  for (int c0 = threadIdx.x; c0 < Lp * 8; c0 += (int)blockDim.x * 4) {
-    float4 x[4], y[4];
-    float ls[4];
+  {
+    constexpr int U = 4, PPR = S16 ? 4 : 8;  // pieces per 32-wide row: 16-byte pieces of bf16 / fp32
+    const int total = Lp * PPR;
+    for (int c0 = threadIdx.x; c0 < total; c0 += (int)blockDim.x * U) {
+      uint4 vq[U], vd[U], vo[U];
+      float ls[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + u * (int)blockDim.x, r = c >> 3, dd = (c & 7) * 4;
-      x[u] = y[u] = make_float4(0, 0, 0, 0);
-      ls[u] = INFINITY;
-      if (c < Lp * 8 && r < L) {
-        x[u] = xf_ld4<S16>(a.ctx, hoff + (int64_t)r * H + dd);
-        y[u] = xf_ld4<S16>(a.d_ctx, hoff + (int64_t)r * H + dd);
-        if ((c & 7) == 0) ls[u] = a.lse[(int64_t)blk.by * L + r] * kLog2e;
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * (int)blockDim.x, r = c / PPR, pc = c % PPR;
+        vq[u] = vd[u] = vo[u] = make_uint4(0u, 0u, 0u, 0u);
+        ls[u] = INFINITY;
+        if (c < total && r < L) {
+          const int e = pc * (32 / PPR);  // first element of the piece
+          vq[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.qkv, (tok0 + r) * 3 * H + h * DH + e));
+          vd[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.d_ctx, hoff + (int64_t)r * H + e));
+          vo[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.ctx, hoff + (int64_t)r * H + e));
+          if (pc == 0) ls[u] = a.lse[(int64_t)blk.by * L + r] * kLog2e;
+        }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + u * (int)blockDim.x, r = c >> 3;
-      float part = x[u].x * y[u].x + x[u].y * y[u].y + x[u].z * y[u].z + x[u].w * y[u].w;
-      part += __shfl_xor(part, 1, 64);
-      part += __shfl_xor(part, 2, 64);
-      part += __shfl_xor(part, 4, 64);
-      if (c < Lp * 8 && (c & 7) == 0) {
-        sDelta[r] = part;
-        sLse[r] = ls[u];
-        sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + r));
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * (int)blockDim.x, r = c / PPR, pc = c % PPR;
+        float part;
+        if (S16) {
+          if (c < total) {
+            *reinterpret_cast<uint4*>(sQ + AI::off(r, pc)) = vq[u];
+            *reinterpret_cast<uint4*>(sDO + AI::off(r, pc)) = vd[u];
+          }
+          const float4 d0 = xf_bf16x4_to_f32(make_uint2(vd[u].x, vd[u].y)), d1 = xf_bf16x4_to_f32(make_uint2(vd[u].z, vd[u].w));
+          const float4 o0 = xf_bf16x4_to_f32(make_uint2(vo[u].x, vo[u].y)), o1 = xf_bf16x4_to_f32(make_uint2(vo[u].z, vo[u].w));
+          part = d0.x * o0.x + d0.y * o0.y + d0.z * o0.z + d0.w * o0.w + d1.x * o1.x + d1.y * o1.y + d1.z * o1.z +
+                 d1.w * o1.w;
+        } else {
+          const float4 q4 = *reinterpret_cast<const float4*>(&vq[u]), d4 = *reinterpret_cast<const float4*>(&vd[u]),
+                       o4 = *reinterpret_cast<const float4*>(&vo[u]);
+          if (c < total) {
+            const int dd = pc * 4;
+            xf_store4<PrecBF16>(sQ + AI::off(r, dd >> 3) + (dd & 7), q4);
+            xf_store4<PrecBF16>(sDO + AI::off(r, dd >> 3) + (dd & 7), d4);
+          }
+          part = d4.x * o4.x + d4.y * o4.y + d4.z * o4.z + d4.w * o4.w;
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if (!S16) part += __shfl_xor(part, 4, 64);
+        if (c < total && pc == 0) {
+          sDelta[r] = part;
+          sLse[r] = ls[u];
+          sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + r));
+        }
       }
     }
   }
-  __syncthreads();
 
   const int lane = xf_lane(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5;
   __bf16* sDSw = sDS + wid * 32 * DH;
@@ -795,37 +819,44 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
       }
     }
   };
+  auto load_tile = [&](int kt) {  // the wave's next key tile: K / V row operands, K in the dQ product's B layout
+    cur_kt = kt;
+    const int k0 = kt * 32;
+    key = k0 + (lane & 31);
+    kin = key < L;
+    kvis = kin && a.key_mask[tok0 + (kin ? key : 0)];
+    all_kvis = __all(kvis);
+    colmix = (uint32_t)key * kDropColMul;
+    kreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + H + h * DH, kin);
+    vreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + 2 * H + h * DH, kin);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kr = k0 + xf_acc_row(8 * s + j, lane);
+        float v = 0.f;
+        if (kr < L) {
+          const int64_t o = (tok0 + kr) * 3 * H + H + h * DH + (lane & 31);
+          v = S16 ? (float)reinterpret_cast<const __bf16*>(a.qkv)[o] : reinterpret_cast<const float*>(a.qkv)[o];
+        }
+        kb[s][j] = (__bf16)v;
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+  };
   const int steps = kBwdSteps[nt - 1];
+  {  // first tile's operands are in flight while the workgroup waits for the staged panels
+    const int code0 = kBwdSched[nt - 1][wid][0];
+    if (code0 != 255) load_tile(code0 >> 4);
+  }
+  __syncthreads();
   for (int step = 0; step < steps; ++step) {
     const int code = kBwdSched[nt - 1][wid][step];  // (wave-uniform)
     if (code != 255) {
       const int kt = code >> 4, qb = code & 15;
       if (kt != cur_kt) {
         flush();
-        cur_kt = kt;
-        const int k0 = kt * 32;
-        key = k0 + (lane & 31);
-        kin = key < L;
-        kvis = kin && a.key_mask[tok0 + (kin ? key : 0)];
-        all_kvis = __all(kvis);
-        colmix = (uint32_t)key * kDropColMul;
-        kreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + H + h * DH, kin);
-        vreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + 2 * H + h * DH, kin);
-        // B operand of the dQ product: K[k0 + row(j)][d = lane & 31] in the accumulator's row order
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int kr = k0 + xf_acc_row(8 * s + j, lane);
-            float v = 0.f;
-            if (kr < L) {
-              const int64_t o = (tok0 + kr) * 3 * H + H + h * DH + (lane & 31);
-              v = S16 ? (float)reinterpret_cast<const __bf16*>(a.qkv)[o] : reinterpret_cast<const float*>(a.qkv)[o];
-            }
-            kb[s][j] = (__bf16)v;
-          }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+        load_tile(kt);
       }
       const int row0 = qb * 32;
       f32x16 s, dp;
