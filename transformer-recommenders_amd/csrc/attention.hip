@@ -803,8 +803,6 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
   int cur_kt = -1, key = 0;
   bool kin = false, kvis = false, all_kvis = false;
   uint32_t colmix = 0;
-  RegRows<PrecBF16, DH> kreg, vreg;
-  bf16x8 kb[2];
   f32x16 dk, dv;
   auto flush = [&]() {  // dK / dV straight from the accumulator layout: lane = key row, 4 consecutive d per group
     if (cur_kt >= 0 && kin) {
@@ -819,16 +817,13 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
       }
     }
   };
-  auto load_tile = [&](int kt) {  // the wave's next key tile: K / V row operands, K in the dQ product's B layout
-    cur_kt = kt;
-    const int k0 = kt * 32;
-    key = k0 + (lane & 31);
-    kin = key < L;
-    kvis = kin && a.key_mask[tok0 + (kin ? key : 0)];
-    all_kvis = __all(kvis);
-    colmix = (uint32_t)key * kDropColMul;
-    kreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + H + h * DH, kin);
-    vreg.load_at<S16>(a.qkv, (tok0 + key) * 3 * H + 2 * H + h * DH, kin);
+  // a wave walks at most two key tiles (up to 8 tiles): the operands of BOTH are fetched up front -- a fetch at the
+  // switch would stall the wave, and with it the whole lock-step, for a global round trip
+  struct TileOps { RegRows<PrecBF16, DH> k, v; bf16x8 kb[2]; };
+  auto fetch_tile = [&](int kt, TileOps& o) {  // K / V row operands, K in the dQ product's B layout
+    const int k0 = kt * 32, ky = k0 + (lane & 31);
+    o.k.template load_at<S16>(a.qkv, (tok0 + ky) * 3 * H + H + h * DH, ky < L);
+    o.v.template load_at<S16>(a.qkv, (tok0 + ky) * 3 * H + 2 * H + h * DH, ky < L);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -836,18 +831,34 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
         const int kr = k0 + xf_acc_row(8 * s + j, lane);
         float v = 0.f;
         if (kr < L) {
-          const int64_t o = (tok0 + kr) * 3 * H + H + h * DH + (lane & 31);
-          v = S16 ? (float)reinterpret_cast<const __bf16*>(a.qkv)[o] : reinterpret_cast<const float*>(a.qkv)[o];
+          const int64_t off = (tok0 + kr) * 3 * H + H + h * DH + (lane & 31);
+          v = S16 ? (float)reinterpret_cast<const __bf16*>(a.qkv)[off] : reinterpret_cast<const float*>(a.qkv)[off];
         }
-        kb[s][j] = (__bf16)v;
+        o.kb[s][j] = (__bf16)v;
       }
+  };
+  auto enter_tile = [&](int kt) {
+    cur_kt = kt;
+    key = kt * 32 + (lane & 31);
+    kin = key < L;
+    kvis = kin && a.key_mask[tok0 + (kin ? key : 0)];
+    all_kvis = __all(kvis);
+    colmix = (uint32_t)key * kDropColMul;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
   };
   const int steps = kBwdSteps[nt - 1];
-  {  // first tile's operands are in flight while the workgroup waits for the staged panels
+  TileOps cur, nxt;
+  {
     const int code0 = kBwdSched[nt - 1][wid][0];
-    if (code0 != 255) load_tile(code0 >> 4);
+    int kt_a = code0 == 255 ? -1 : (code0 >> 4), kt_b = -1;
+    for (int sidx = 1; sidx < steps; ++sidx) {
+      const int cd = kBwdSched[nt - 1][wid][sidx];
+      if (cd != 255 && (cd >> 4) != kt_a && kt_b < 0) kt_b = cd >> 4;
+    }
+    if (kt_a >= 0) fetch_tile(kt_a, cur);
+    if (kt_b >= 0) fetch_tile(kt_b, nxt);
+    if (kt_a >= 0) enter_tile(kt_a);
   }
   __syncthreads();
   for (int step = 0; step < steps; ++step) {
@@ -856,14 +867,15 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
       const int kt = code >> 4, qb = code & 15;
       if (kt != cur_kt) {
         flush();
-        load_tile(kt);
+        cur = nxt;
+        enter_tile(kt);
       }
       const int row0 = qb * 32;
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-      AI::tile_nreg(s, sQ, row0, kreg.regs());
-      AI::tile_nreg(dp, sDO, row0, vreg.regs());
+      AI::tile_nreg(s, sQ, row0, cur.k.regs());
+      AI::tile_nreg(dp, sDO, row0, cur.v.regs());
       const bool interior = all_kvis && qb > kt;  // every query row is after the wave's keys, every key valid
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -923,7 +935,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
             av.v[t2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) xf_s16x4*)(sDSw + AI::off(row, c) + within));
           }
-          dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.f, kb[st], dq, 0, 0, 0);
+          dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.f, cur.kb[st], dq, 0, 0, 0);
         }
       }
 #pragma unroll
