@@ -70,12 +70,20 @@ struct Acts {
   float* emb_ln;  // embedding LayerNorm partial records
   float *dA, *dB;
   void *dLin, *dCtx, *dI, *dQKV;  // bf16 when mixed
+  void* wbf;      // bf16 copy of the flat parameter buffer (mixed storage): the B operand of the forward / dX GEMMs
   void* scratch;  // ln-bwd partials / dW slabs / colsum partials (used one at a time)
   size_t scratch_bytes;
   size_t total;
 };
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// fp32 parameters -> the bf16 copy the MFMA B operands are staged from (the bf16 policy rounds them at staging time
+// anyway: identical products, half the L2 -> LDS bytes of the most re-read operand)
+__global__ __launch_bounds__(256) void params_to_bf16_kernel(const float* src, __bf16* dst, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) xf_st4<true>(dst, 4 * i, *reinterpret_cast<const float4*>(src + 4 * i));
+}
 
 bool mixed_storage(const xfmr_encoder_cfg* c) {
   static const bool force_fp32 = [] {
@@ -101,6 +109,7 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   a.dA = take(T * H); a.dB = take(T * H);
   a.dLin = take_bytes(T * H * es); a.dCtx = take_bytes(T * H * es);
   a.dI = take_bytes(T * I * es); a.dQKV = take_bytes(T * 3 * H * es);
+  a.wbf = take_bytes(mixed_storage(c) ? (size_t)xfmr_param_count(c) * 2 : 0);
   size_t sc = xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H);
   size_t s2 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)(3 * H), (int32_t)H);
   size_t s3 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)I, (int32_t)H);
@@ -229,23 +238,33 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
                            params + pl.eb, a.x0, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask, B, L, H, cfg->ln_eps,
                            cfg->hidden_dropout, cfg->seed, SITE_EMB, stream));
   const float* x = a.x0;
+  if (mix) {
+    const int64_t n4 = pl.total / 4;  // (every tensor size is a multiple of 4: H, I multiples of 32)
+    hipLaunchKernelGGL(params_to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, params,
+                       (__bf16*)a.wbf, n4);
+    XF_LAUNCH_CHECK();
+  }
+  const uint32_t sB = mix ? XF_S16_B : 0;
+  auto W = [&](int64_t off) -> const float* {  // weight operand: the bf16 copy under mixed storage
+    return mix ? reinterpret_cast<const float*>((const __bf16*)a.wbf + off) : params + off;
+  };
   for (int i = 0; i < cfg->layers; ++i) {
     LayerActs l;
     carve(cfg, base, i, &l);
     const LayerParams p = layer_params(cfg, i);
     float* out = (i == cfg->layers - 1) ? tok : l.x2;
-    XF_TRY(xf_linear_fwd_ex(x, params + p.wqkv, params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
-                            0.f, 0, 0, prec, mix ? XF_S16_C : 0, st));
+    XF_TRY(xf_linear_fwd_ex(x, W(p.wqkv), params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
+                            0.f, 0, 0, prec, (mix ? XF_S16_C : 0) | sB, st));
     XF_TRY(xf_attn_fwd_ex(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, cfg->seed, site_attn(i), prec,
                           mix, st));
-    XF_TRY(xf_linear_fwd_ex(l.ctx, params + p.wo, params + p.bo, l.pre1, T, H, H, XFMR_EPI_BIAS_DROP_RES, x, nullptr,
-                            cfg->hidden_dropout, cfg->seed, site_out(i), prec, mix ? XF_S16_A : 0, st));
+    XF_TRY(xf_linear_fwd_ex(l.ctx, W(p.wo), params + p.bo, l.pre1, T, H, H, XFMR_EPI_BIAS_DROP_RES, x, nullptr,
+                            cfg->hidden_dropout, cfg->seed, site_out(i), prec, (mix ? XF_S16_A : 0) | sB, st));
     XF_TRY(xfmr_layernorm_fwd(l.pre1, params + p.ln1g, params + p.ln1b, l.x1, l.mean1, l.rstd1, T, H, cfg->ln_eps,
                               stream));
-    XF_TRY(xf_linear_fwd_ex(l.x1, params + p.w1, params + p.b1, l.g, T, I, H, XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f,
-                            0, 0, prec, (mix ? XF_S16_C : 0) | XF_AUX_GELU_GRAD, st));  // f1 <- gelu'(pre)
-    XF_TRY(xf_linear_fwd_ex(l.g, params + p.w2, params + p.b2, l.pre2, T, H, I, XFMR_EPI_BIAS_DROP_RES, l.x1, nullptr,
-                            cfg->hidden_dropout, cfg->seed, site_ffn(i), prec, mix ? XF_S16_A : 0, st));
+    XF_TRY(xf_linear_fwd_ex(l.x1, W(p.w1), params + p.b1, l.g, T, I, H, XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f,
+                            0, 0, prec, (mix ? XF_S16_C : 0) | sB | XF_AUX_GELU_GRAD, st));  // f1 <- gelu'(pre)
+    XF_TRY(xf_linear_fwd_ex(l.g, W(p.w2), params + p.b2, l.pre2, T, H, I, XFMR_EPI_BIAS_DROP_RES, l.x1, nullptr,
+                            cfg->hidden_dropout, cfg->seed, site_ffn(i), prec, (mix ? XF_S16_A : 0) | sB, st));
     XF_TRY(xfmr_layernorm_fwd(l.pre2, params + p.ln2g, params + p.ln2b, out, l.mean2, l.rstd2, T, H, cfg->ln_eps,
                               stream));
     x = out;
@@ -268,7 +287,10 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   const bool hdrop = cfg->hidden_dropout > 0.f;
   const bool mix = mixed_storage(cfg);
   const uint32_t sA = mix ? XF_S16_A : 0, sC = mix ? XF_S16_C : 0, sP = mix ? XF_S16_P : 0,
-                 sAB = mix ? (XF_S16_A | XF_S16_B) : 0;
+                 sAB = mix ? (XF_S16_A | XF_S16_B) : 0, sB = mix ? XF_S16_B : 0;
+  auto W = [&](int64_t off) -> const float* {  // weight operand: the bf16 copy the forward pass made
+    return mix ? reinterpret_cast<const float*>((const __bf16*)a.wbf + off) : params + off;
+  };
   const XfDropout off = xf_make_dropout(0.f, 0, 0);
   float* dX = d_tok;  // gradient w.r.t. the current layer's output
   XfReduceSeg segs[12 * 64 + 2];
@@ -300,11 +322,11 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     const void* dlin = lin_copy ? a.dLin : (const void*)a.dA;
     XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, st));
     seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
-    XF_TRY(xf_linear_bwd_dx_ex(dlin, params + p.w2, a.dI, T, H, I, nullptr, l.f1, prec, sA | sC | sP | XF_AUX_GELU_GRAD, st));
+    XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), a.dI, T, H, I, nullptr, l.f1, prec, sA | sC | sP | sB | XF_AUX_GELU_GRAD, st));
     XF_TRY(xf_linear_bwd_dw_deferred(a.dI, l.x1, T, I, H, prec, sA, r.w1, r.b1, &splits, st));  // + b1 partial rows
     seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
     seg(r.b1, grads + p.b1, splits, I, I);
-    XF_TRY(xf_linear_bwd_dx_ex(a.dI, params + p.w1, a.dA, T, I, H, a.dA, nullptr, prec, sA, st));  // += d(pre2)
+    XF_TRY(xf_linear_bwd_dx_ex(a.dI, W(p.w1), a.dA, T, I, H, a.dA, nullptr, prec, sA | sB, st));  // += d(pre2)
     // LayerNorm 1 -> dX = d(pre1)
     XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, lin_copy ? a.dLin : nullptr, mix,
                                  nullptr, nullptr, nullptr, T, H, off,
@@ -315,13 +337,13 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     dlin = lin_copy ? a.dLin : (const void*)dX;
     XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.ctx, T, H, H, prec, sAB, r.wo, nullptr, &splits, st));
     seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
-    XF_TRY(xf_linear_bwd_dx_ex(dlin, params + p.wo, a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC, st));  // d(ctx)
+    XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
     XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, a.dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
                           site_attn(i), prec, mix, st));
     XF_TRY(xf_linear_bwd_dw_deferred(a.dQKV, x_in, T, 3 * H, H, prec, sA, r.wqkv, r.bqkv, &splits, st));
     seg(r.wqkv, grads + p.wqkv, splits, (int64_t)3 * H * H, (int64_t)3 * H * H);
     seg(r.bqkv, grads + p.bqkv, splits, 3 * H, 3 * H);
-    XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, params + p.wqkv, dX, T, 3 * H, H, dX, nullptr, prec, sA, st));  // += d(pre1)
+    XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, W(p.wqkv), dX, T, 3 * H, H, dX, nullptr, prec, sA | sB, st));  // += d(pre1)
   }
   ParamLayout pl;
   layer_base(cfg, 0, &pl);

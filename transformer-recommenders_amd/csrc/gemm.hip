@@ -550,19 +550,19 @@ int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, 
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   GemmArgs g{};
   g.A = x; g.B = w; g.C = y; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K; g.k_chunk = 0;
-  g.bias = bias; g.R = residual; g.C2 = aux_out; g.P = nullptr; g.s16 = s16 & (XF_S16_A | XF_S16_C);
+  g.bias = bias; g.R = residual; g.C2 = aux_out; g.P = nullptr; g.s16 = s16 & (XF_S16_A | XF_S16_B | XF_S16_C);
   g.aux_grad = (s16 & XF_AUX_GELU_GRAD) != 0;
   g.drop = xf_make_dropout(dropout_p, seed, site);
   switch (epilogue) {
     case XFMR_EPI_BIAS:
       g.R = nullptr;
-      return dispatch_gemm<false, false, EPI_STORE, XF_S16_C>(g, 1, precision, st);
+      return dispatch_gemm<false, false, EPI_STORE, XF_S16_C, (XF_S16_C | XF_S16_B)>(g, 1, precision, st);
     case XFMR_EPI_BIAS_GELU:
       if (!aux_out) return XFMR_EINVAL;
-      return dispatch_gemm<false, false, EPI_GELU, XF_S16_C>(g, 1, precision, st);
+      return dispatch_gemm<false, false, EPI_GELU, XF_S16_C, (XF_S16_C | XF_S16_B)>(g, 1, precision, st);
     case XFMR_EPI_BIAS_DROP_RES:
       if (!residual) return XFMR_EINVAL;
-      return dispatch_gemm<false, false, EPI_DROP_RES, XF_S16_A>(g, 1, precision, st);
+      return dispatch_gemm<false, false, EPI_DROP_RES, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, 1, precision, st);
     default:
       return XFMR_EINVAL;
   }
@@ -586,12 +586,14 @@ int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int
   GemmArgs g{};
   g.A = dy; g.B = w; g.C = dx; g.lda = N; g.ldb = K; g.ldc = K; g.M = M; g.N = K; g.K = N; g.k_chunk = 0;
   g.bias = nullptr; g.R = residual_grad; g.P = gelu_pre; g.C2 = nullptr;
-  g.s16 = s16 & (XF_S16_A | XF_S16_C | XF_S16_P);
+  g.s16 = s16 & (XF_S16_A | XF_S16_B | XF_S16_C | XF_S16_P);
   g.aux_grad = (s16 & XF_AUX_GELU_GRAD) != 0;
   g.drop = xf_make_dropout(0.f, 0, 0);
   if (gelu_pre)
-    return dispatch_gemm<false, true, EPI_GELU_GRAD, (XF_S16_A | XF_S16_C | XF_S16_P)>(g, 1, precision, st);
-  return dispatch_gemm<false, true, EPI_STORE, XF_S16_A, (XF_S16_A | XF_S16_C)>(g, 1, precision, st);
+    return dispatch_gemm<false, true, EPI_GELU_GRAD, (XF_S16_A | XF_S16_C | XF_S16_P),
+                         (XF_S16_A | XF_S16_B | XF_S16_C | XF_S16_P)>(g, 1, precision, st);
+  return dispatch_gemm<false, true, EPI_STORE, XF_S16_A, (XF_S16_A | XF_S16_C), (XF_S16_A | XF_S16_B),
+                       (XF_S16_A | XF_S16_B | XF_S16_C)>(g, 1, precision, st);
 }
 
 int xfmr_linear_bwd_dx(const float* dy, const float* w, float* dx, int64_t M, int32_t N, int32_t K,
