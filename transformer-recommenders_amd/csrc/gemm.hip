@@ -48,22 +48,25 @@ struct OperandTile {
   static constexpr int IMG_ELEMS = TRANS ? BK * LD : ROWS * LD;
   float4 reg[N4];
 
-  // bf16 storage (dims are multiples of 4, so there are no partial quads): the raw 8 bytes ride in reg[i].x/.y
+  // bf16 storage: 16-byte pieces (8 elements along the contiguous dimension, which is a feature dimension: a multiple
+  // of 8) -- N8 pieces per thread, the raw bytes ride in reg[i]. (8-byte pieces moved half the bytes per vector
+  // memory instruction; these GEMMs are bound by the CU's memory-instruction throughput, not by HBM or L2.)
+  static constexpr int N8 = ROWS * BK / 8 / 256;
   __device__ __forceinline__ void load16(const __bf16* src, int64_t ld, int64_t row0, int64_t rows_total, int k0,
                                          int kend) {
+    static_assert(N8 >= 1, "tile too small for 16-byte bf16 pieces");
     const int tid = threadIdx.x;
-    constexpr int CH = TRANS ? ROWS / 4 : BK / 4;
+    constexpr int CH = TRANS ? ROWS / 8 : BK / 8;
 #pragma unroll
-    for (int i = 0; i < N4; ++i) {
+    for (int i = 0; i < N8; ++i) {
       const int c = tid + i * 256;
-      const int a = c / CH, b4 = (c % CH) * 4;
-      const int64_t gr = row0 + (TRANS ? b4 : a);
-      const int gk = k0 + (TRANS ? a : b4);
-      uint2 raw = make_uint2(0u, 0u);
+      const int a = c / CH, b8 = (c % CH) * 8;
+      const int64_t gr = row0 + (TRANS ? b8 : a);
+      const int gk = k0 + (TRANS ? a : b8);
+      uint4 raw = make_uint4(0u, 0u, 0u, 0u);
       if (gr < rows_total && gk < kend)
-        raw = *reinterpret_cast<const uint2*>(TRANS ? src + (int64_t)gk * ld + gr : src + gr * ld + gk);
-      reg[i].x = __uint_as_float(raw.x);
-      reg[i].y = __uint_as_float(raw.y);
+        raw = *reinterpret_cast<const uint4*>(TRANS ? src + (int64_t)gk * ld + gr : src + gr * ld + gk);
+      reg[i] = *reinterpret_cast<const float4*>(&raw);
     }
   }
   template <bool S16>
@@ -111,26 +114,42 @@ struct OperandTile {
   }
   // TRANS tiles only: every thread's pieces cover the SAME 4 operand rows (256 % (ROWS/4) == 0) at different k:
   // acc += the pieces in flight = this thread's share of the row sums over k (the bias gradient when A' = dy^T)
+  // (fp32 pieces: 4 rows -> acc[0]; bf16 pieces: 8 rows -> acc[0], acc[1])
   template <bool S16>
-  __device__ __forceinline__ void add_rowsum(float4& acc) const {
+  __device__ __forceinline__ void add_rowsum(float4 (&acc)[2]) const {
+    if (S16) {
 #pragma unroll
-    for (int i = 0; i < N4; ++i) {
-      float4 v = reg[i];
-      if (S16) v = xf_bf16x4_to_f32(make_uint2(__float_as_uint(reg[i].x), __float_as_uint(reg[i].y)));
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      for (int i = 0; i < N8; ++i) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(&reg[i]);
+        const float4 lo = xf_bf16x4_to_f32(make_uint2(raw.x, raw.y)), hi = xf_bf16x4_to_f32(make_uint2(raw.z, raw.w));
+        acc[0].x += lo.x; acc[0].y += lo.y; acc[0].z += lo.z; acc[0].w += lo.w;
+        acc[1].x += hi.x; acc[1].y += hi.y; acc[1].z += hi.z; acc[1].w += hi.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N4; ++i) {
+        const float4 v = reg[i];
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+      }
     }
   }
   template <bool S16>
   __device__ __forceinline__ void commit(elem* dst) const {
     const int tid = threadIdx.x;
-    constexpr int CH = TRANS ? ROWS / 4 : BK / 4;
+    if (S16) {
+      constexpr int CH = TRANS ? ROWS / 8 : BK / 8;
 #pragma unroll
-    for (int i = 0; i < N4; ++i) {
-      const int c = tid + i * 256;
-      elem* d = dst + (c / CH) * LD + (c % CH) * 4;
-      if (S16)
-        *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(reg[i].x), __float_as_uint(reg[i].y));
-      else xf_store4<P>(d, reg[i]);
+      for (int i = 0; i < N8; ++i) {
+        const int c = tid + i * 256;
+        *reinterpret_cast<float4*>(dst + (c / CH) * LD + (c % CH) * 8) = reg[i];
+      }
+    } else {
+      constexpr int CH = TRANS ? ROWS / 4 : BK / 4;
+#pragma unroll
+      for (int i = 0; i < N4; ++i) {
+        const int c = tid + i * 256;
+        xf_store4<P>(dst + (c / CH) * LD + (c % CH) * 4, reg[i]);
+      }
     }
   }
 };
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   TileA ta;
   TileB tb;
   const bool do_bias = (EPI == EPI_SPLITK) && TA && g.bias_part != nullptr && tix.n == 0;
-  float4 bsum = make_float4(0, 0, 0, 0);
+  float4 bsum[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
     ta.template load<a16>(g.A, g.lda, m0, g.M, kbeg, kend);
@@ -292,24 +311,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // covers the wave's whole column range: full 128-byte lines even for bf16 outputs when the wave owns 64 columns
   // (one wave instruction = 4-8 rows x 128-256 B instead of 2 rows x 32 scattered 4- or 2-byte elements).
   __syncthreads();  // everyone is done with the operand images the scratch aliases
-  if (do_bias) {  // combine the 256 / (BM/4) threads that share an operand row quad, fixed order
-    constexpr int R4 = BM / 4, G = 256 / R4;
+  if (do_bias) {  // combine the threads that share an operand row group (4 rows fp32, 8 rows bf16), fixed order
+    constexpr int RQ = a16 ? 8 : 4, RG = BM / RQ, G = 256 / RG;
     float4* red = reinterpret_cast<float4*>(smem);
-    red[threadIdx.x] = bsum;
+    red[threadIdx.x] = bsum[0];
+    if (a16) red[256 + threadIdx.x] = bsum[1];
     __syncthreads();
-    if (threadIdx.x < R4) {
-      float4 s = red[threadIdx.x];
+    if (threadIdx.x < RG) {
 #pragma unroll
-      for (int q = 1; q < G; ++q) {
-        const float4 v = red[threadIdx.x + q * R4];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      for (int half = 0; half < (a16 ? 2 : 1); ++half) {
+        float4 s = red[half * 256 + threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < G; ++q) {
+          const float4 v = red[half * 256 + threadIdx.x + q * RG];
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int64_t m = m0 + RQ * threadIdx.x + 4 * half;
+        float* dst = g.bias_part + (int64_t)tix.z * g.M + m;
+        if (m < g.M) dst[0] = s.x;
+        if (m + 1 < g.M) dst[1] = s.y;
+        if (m + 2 < g.M) dst[2] = s.z;
+        if (m + 3 < g.M) dst[3] = s.w;
       }
-      const int64_t m = m0 + 4 * threadIdx.x;
-      float* dst = g.bias_part + (int64_t)tix.z * g.M + m;
-      if (m < g.M) dst[0] = s.x;
-      if (m + 1 < g.M) dst[1] = s.y;
-      if (m + 2 < g.M) dst[2] = s.z;
-      if (m + 3 < g.M) dst[3] = s.w;
     }
     __syncthreads();
   }
@@ -475,6 +498,7 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   const TileOverride ov = tile_override();
   if (ov.bm) { bm = ov.bm; bn = ov.bn; }
   dim3 block(256);
+  static const int pad_lds = [] { const char* e = getenv("XFMR_GEMM_PAD_LDS"); return e ? atoi(e) : 0; }();
   GemmArgs ga = g;
   ga.nt_n = (int)((g.N + bn - 1) / bn);
   ga.nt_m = (int)((g.M + bm - 1) / bm);
@@ -484,10 +508,10 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   const int64_t per = splits > 1 ? (int64_t)ga.nt_n * ga.nt_m : ga.nt_n;
   if (groups * per * 8 > 0x7fffffffll) return XFMR_EUNSUPPORTED;
   dim3 grid((unsigned)(groups * per * 8));
-  if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI, S>), grid, block, 0, st, ga);
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI, S>), grid, block, 0, st, ga);
-  else if (bm == 64) hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI, S>), grid, block, 0, st, ga);
-  else hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI, S>), grid, block, 0, st, ga);
+  if (bm == 64 && bn == 128) hipLaunchKernelGGL((gemm_kernel<P, 64, 128, BK, TA, TB, EPI, S>), grid, block, pad_lds, st, ga);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((gemm_kernel<P, 128, 64, BK, TA, TB, EPI, S>), grid, block, pad_lds, st, ga);
+  else if (bm == 64) hipLaunchKernelGGL((gemm_kernel<P, 64, 64, BK, TA, TB, EPI, S>), grid, block, pad_lds, st, ga);
+  else hipLaunchKernelGGL((gemm_kernel<P, 128, 128, BK, TA, TB, EPI, S>), grid, block, pad_lds, st, ga);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
@@ -548,6 +572,7 @@ int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, 
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(x) || !xf_aligned16(w) || !xf_aligned16(y)) return XFMR_EALIGN;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if ((s16 & (XF_S16_A | XF_S16_B)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
   GemmArgs g{};
   g.A = x; g.B = w; g.C = y; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K; g.k_chunk = 0;
   g.bias = bias; g.R = residual; g.C2 = aux_out; g.P = nullptr; g.s16 = s16 & (XF_S16_A | XF_S16_B | XF_S16_C);
@@ -582,6 +607,7 @@ int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(w) || !xf_aligned16(dx)) return XFMR_EALIGN;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if ((s16 & (XF_S16_A | XF_S16_B)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
   // dx[M,K] = dy[M,N] * w[N,K]: contraction over N; B' [K rows][N] = w^T -> w is stored [N][K] = K-major
   GemmArgs g{};
   g.A = dy; g.B = w; g.C = dx; g.lda = N; g.ldb = K; g.ldc = K; g.M = M; g.N = K; g.K = N; g.k_chunk = 0;
@@ -614,6 +640,7 @@ int xf_linear_bwd_dw_ex(const void* dy, const void* x, float* dw, int64_t M, int
   if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(workspace)) return XFMR_EALIGN;
   if (workspace_bytes < xfmr_linear_bwd_dw_workspace(M, N, K)) return XFMR_EWORKSPACE;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if ((s16 & (XF_S16_A | XF_S16_B)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
   // dw[N,K] = dy^T[N,M] * x[M,K]: contraction over M. A' = dy^T (dy stored [M][N]), B'[K rows][M] = x^T.
   int k_chunk;
   int splits = dw_split_plan(M, N, K, &k_chunk);
@@ -636,6 +663,7 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(slabs)) return XFMR_EALIGN;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if ((s16 & (XF_S16_A | XF_S16_B)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
   int k_chunk;
   const int splits = dw_split_plan(M, N, K, &k_chunk);
   GemmArgs g{};
