@@ -337,31 +337,59 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
   constexpr int CW = NI * 32;        // columns this wave owns
-  constexpr int LPR = CW / 4;        // lanes per row (4 columns each)
+  // columns per lane: one 16-byte piece of the OUTPUT row -- 4 fp32 or 8 bf16 (8-byte bf16 pieces moved half the
+  // bytes per vector-memory instruction)
+  constexpr bool out16 = c16 && EPI != EPI_SPLITK;
+  constexpr int CPL = out16 ? 8 : 4, Q = CPL / 4;
+  constexpr int LPR = CW / CPL;      // lanes per row
   constexpr int RPP = 64 / LPR;      // rows per pass
   constexpr int NPASS = 16 / RPP;    // passes per half strip (16 rows: the scratch stays below the operand images)
   float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
   const int64_t zoff = (EPI == EPI_SPLITK) ? (int64_t)tix.z * g.M * g.ldc : 0;
-  const int prow = lane / LPR, c4 = (lane % LPR) * 4;
-  const float* aux_src = reinterpret_cast<const float*>((EPI == EPI_GELU_GRAD) ? g.P : (const void*)g.R);
+  const int prow = lane / LPR, c0 = (lane % LPR) * CPL;
+  const void* aux_src = (EPI == EPI_GELU_GRAD) ? g.P : (const void*)g.R;
   constexpr bool aux16 = (EPI == EPI_GELU_GRAD) && p16;
   constexpr bool has_aux = (EPI == EPI_STORE || EPI == EPI_DROP_RES || EPI == EPI_GELU_GRAD);
-  const int n = n0 + wc * WN + c4;
-  const bool ncol = n < g.N;
-  float4 bias = make_float4(0, 0, 0, 0);
-  if (EPI != EPI_SPLITK && EPI != EPI_GELU_GRAD && g.bias && ncol) bias = *reinterpret_cast<const float4*>(g.bias + n);
+  const int n = n0 + wc * WN + c0;
+  const bool ncol = n < g.N;  // (N is a multiple of CPL: checked by the callers)
+  float4 bias[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    bias[q] = make_float4(0, 0, 0, 0);
+    if (EPI != EPI_SPLITK && EPI != EPI_GELU_GRAD && g.bias && ncol)
+      bias[q] = *reinterpret_cast<const float4*>(g.bias + n + 4 * q);
+  }
+  auto ld_aux = [&](int64_t idx, float4 (&dst)[Q]) {
+    if (aux16 && Q == 2) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(aux_src) + idx);
+      dst[0] = xf_bf16x4_to_f32(make_uint2(raw.x, raw.y));
+      dst[Q - 1] = xf_bf16x4_to_f32(make_uint2(raw.z, raw.w));
+    } else {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) dst[q] = xf_ld4<aux16>(aux_src, idx + 4 * q);
+    }
+  };
+  auto st_out = [&](void* base, int64_t idx, const float4 (&v)[Q]) {
+    if (out16) {  // Q == 2: eight bf16 = one 16-byte store
+      const uint2 lo = xf_f32x4_to_bf16(v[0]), hi = xf_f32x4_to_bf16(v[Q - 1]);
+      *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + idx) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v[0];
+    }
+  };
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {  // accumulator registers 8*hf .. 8*hf+7 hold the strip's rows 16*hf .. 16*hf+15
       const int64_t mb = m0 + wr * WM + i * 32 + 16 * hf;
       // issue the epilogue operand loads first: their latency hides under the LDS round trip
-      float4 aux[NPASS];
+      float4 aux[NPASS][Q];
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
-        aux[ps] = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) aux[ps][q] = make_float4(0, 0, 0, 0);
         const int64_t m = mb + prow + RPP * ps;
-        if (has_aux && aux_src && ncol && m < g.M) aux[ps] = xf_ld4<aux16>(aux_src, m * g.ldc + n);
+        if (has_aux && aux_src && ncol && m < g.M) ld_aux(m * g.ldc + n, aux[ps]);
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j)
@@ -375,37 +403,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const int row = prow + RPP * ps;
         const int64_t m = mb + row;
         if (!ncol || m >= g.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4);
-        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
         const int64_t o = m * g.ldc + n;
-        if (EPI == EPI_STORE) {
-          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
-        } else if (EPI == EPI_GELU) {
-          if (g.aux_grad) {  // C2 <- gelu'(pre): both values from one erf / exp
-            float4 d;
-            v.x = xf_gelu_both(v.x, d.x); v.y = xf_gelu_both(v.y, d.y);
-            v.z = xf_gelu_both(v.z, d.z); v.w = xf_gelu_both(v.w, d.w);
-            xf_st4<c16>(g.C2, o, d);
-          } else {
-            xf_st4<c16>(g.C2, o, v);
-            v.x = xf_gelu(v.x); v.y = xf_gelu(v.y); v.z = xf_gelu(v.z); v.w = xf_gelu(v.w);
-          }
-        } else if (EPI == EPI_DROP_RES) {
-          if (g.drop.on) {
-            const uint32_t e = (uint32_t)(m * g.N + n);
-            v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
-            v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
-          }
-          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
-        } else if (EPI == EPI_GELU_GRAD) {
-          if (g.aux_grad) {
-            v.x *= aux[ps].x; v.y *= aux[ps].y; v.z *= aux[ps].z; v.w *= aux[ps].w;
-          } else {
-            v.x *= xf_gelu_grad(aux[ps].x); v.y *= xf_gelu_grad(aux[ps].y);
-            v.z *= xf_gelu_grad(aux[ps].z); v.w *= xf_gelu_grad(aux[ps].w);
+        float4 v[Q], d[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          v[q] = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0 + 4 * q);
+          v[q].x += bias[q].x; v[q].y += bias[q].y; v[q].z += bias[q].z; v[q].w += bias[q].w;
+          const float4 ax = aux[ps][q];
+          if (EPI == EPI_STORE) {
+            v[q].x += ax.x; v[q].y += ax.y; v[q].z += ax.z; v[q].w += ax.w;
+          } else if (EPI == EPI_GELU) {
+            if (g.aux_grad) {  // C2 <- gelu'(pre): both values from one erf / exp
+              v[q].x = xf_gelu_both(v[q].x, d[q].x); v[q].y = xf_gelu_both(v[q].y, d[q].y);
+              v[q].z = xf_gelu_both(v[q].z, d[q].z); v[q].w = xf_gelu_both(v[q].w, d[q].w);
+            } else {
+              d[q] = v[q];
+              v[q].x = xf_gelu(v[q].x); v[q].y = xf_gelu(v[q].y); v[q].z = xf_gelu(v[q].z); v[q].w = xf_gelu(v[q].w);
+            }
+          } else if (EPI == EPI_DROP_RES) {
+            if (g.drop.on) {
+              const uint32_t e = (uint32_t)(m * g.N + n + 4 * q);
+              v[q].x *= xf_keep_scale(g.drop, e); v[q].y *= xf_keep_scale(g.drop, e + 1);
+              v[q].z *= xf_keep_scale(g.drop, e + 2); v[q].w *= xf_keep_scale(g.drop, e + 3);
+            }
+            v[q].x += ax.x; v[q].y += ax.y; v[q].z += ax.z; v[q].w += ax.w;
+          } else if (EPI == EPI_GELU_GRAD) {
+            if (g.aux_grad) {
+              v[q].x *= ax.x; v[q].y *= ax.y; v[q].z *= ax.z; v[q].w *= ax.w;
+            } else {
+              v[q].x *= xf_gelu_grad(ax.x); v[q].y *= xf_gelu_grad(ax.y);
+              v[q].z *= xf_gelu_grad(ax.z); v[q].w *= xf_gelu_grad(ax.w);
+            }
           }
         }
-        xf_st4<(c16 && EPI != EPI_SPLITK)>(g.C, zoff + o, v);
+        if (EPI == EPI_GELU) st_out(g.C2, o, d);
+        st_out(g.C, zoff + o, v);
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();  // the next half strip overwrites the scratch
@@ -572,7 +604,7 @@ int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, 
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(x) || !xf_aligned16(w) || !xf_aligned16(y)) return XFMR_EALIGN;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
-  if ((s16 & (XF_S16_A | XF_S16_B)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
+  if ((s16 & (XF_S16_A | XF_S16_B | XF_S16_C | XF_S16_P)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
   GemmArgs g{};
   g.A = x; g.B = w; g.C = y; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K; g.k_chunk = 0;
   g.bias = bias; g.R = residual; g.C2 = aux_out; g.P = nullptr; g.s16 = s16 & (XF_S16_A | XF_S16_B | XF_S16_C);
@@ -607,7 +639,7 @@ int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(w) || !xf_aligned16(dx)) return XFMR_EALIGN;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
-  if ((s16 & (XF_S16_A | XF_S16_B)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
+  if ((s16 & (XF_S16_A | XF_S16_B | XF_S16_C | XF_S16_P)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
   // dx[M,K] = dy[M,N] * w[N,K]: contraction over N; B' [K rows][N] = w^T -> w is stored [N][K] = K-major
   GemmArgs g{};
   g.A = dy; g.B = w; g.C = dx; g.lda = N; g.ldb = K; g.ldc = K; g.M = M; g.N = K; g.K = N; g.k_chunk = 0;
@@ -640,7 +672,7 @@ int xf_linear_bwd_dw_ex(const void* dy, const void* x, float* dw, int64_t M, int
   if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(workspace)) return XFMR_EALIGN;
   if (workspace_bytes < xfmr_linear_bwd_dw_workspace(M, N, K)) return XFMR_EWORKSPACE;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
-  if ((s16 & (XF_S16_A | XF_S16_B)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
+  if ((s16 & (XF_S16_A | XF_S16_B | XF_S16_C | XF_S16_P)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
   // dw[N,K] = dy^T[N,M] * x[M,K]: contraction over M. A' = dy^T (dy stored [M][N]), B'[K rows][M] = x^T.
   int k_chunk;
   int splits = dw_split_plan(M, N, K, &k_chunk);
@@ -663,7 +695,7 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(slabs)) return XFMR_EALIGN;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
-  if ((s16 & (XF_S16_A | XF_S16_B)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
+  if ((s16 & (XF_S16_A | XF_S16_B | XF_S16_C | XF_S16_P)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
   int k_chunk;
   const int splits = dw_split_plan(M, N, K, &k_chunk);
   GemmArgs g{};
