@@ -456,12 +456,15 @@ struct CombineArgs {
   int k_hard, skip_train_head, lse_from_grad;
 };
 
+constexpr int kCombineRows = 8;  // query rows per workgroup of loss_combine_kernel (two per wave)
 __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
-  __shared__ double sAcc[4][BP];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // a HALF wave per query row: 32 lanes x 16 bytes cover 128 columns per access (4-byte accesses, one row per wave,
+  // ran at 113 us for 260 MB: the kernel is bound by the number of vector-memory instructions)
+  __shared__ double sAcc[kCombineRows][BP];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
   const int Nq = a.counts[1];
   const int N = (a.mode == XFMR_NEG_CATALOG) ? (int)a.n_rows : a.counts[0];
-  const int qi = blockIdx.x * 4 + wid;
+  const int qi = blockIdx.x * kCombineRows + wid * 2 + half;
   const int H = a.H;
   double acc[BP];
 #pragma unroll
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       acc[20] = pos_dot; acc[21] = pos_dot; acc[22] = V.smin; acc[23] = V.smax;
     }
     // gradient-side quantities
-    const float M = G.M, sw = G.sw;
+    const float M = G.M, sw_ = G.sw;
     const float epos = exp2f(z2pos - M);  // M >= z2pos
     const float ltot = G.l + epos;
     const float inv_d = 1.f / (G.cnt_d + 1e-9f), inv_c = 1.f / (G.cnt_c + 1e-9f);
@@ -532,52 +535,81 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       const bool cosh = head <= XFMR_LOSS_CONTRASTIVE;
       // first pass for cosine heads: q_hat . dq_hat
       float dotp = 0.f;
-      for (int c0 = 0; c0 < H; c0 += 64) {
-        const int c = c0 + lane;
-        if (c >= H) break;
-        float O = 0.f;
+      float4 gk[2];  // the row's gradient pieces of this lane (H <= 256: at most two 128-column sweeps)
+#pragma unroll
+      for (int sw = 0; sw < 2; ++sw) {
+        const int c = sw * 128 + 4 * hl;
+        gk[sw] = make_float4(0, 0, 0, 0);
+        if (c >= H) continue;
+        float4 O = make_float4(0, 0, 0, 0);
         if (head != XFMR_LOSS_ALIGNMENT) {
           for (int s = 0; s < a.nsplit; ++s) {
-            float v = a.partO[((int64_t)s * a.T + qi) * H + c];
-            if (head == XFMR_LOSS_INFONCE) v *= exp2f(a.part[((int64_t)s * a.T + qi) * REC + R_M] - M);
-            O += v;
+            float4 v = *reinterpret_cast<const float4*>(&a.partO[((int64_t)s * a.T + qi) * H + c]);
+            float f = 1.f;
+            if (head == XFMR_LOSS_INFONCE) f = exp2f(a.part[((int64_t)s * a.T + qi) * REC + R_M] - M);
+            O.x += v.x * f; O.y += v.y * f; O.z += v.z * f; O.w += v.w * f;
           }
         }
-        const float e = ep[c];
-        float g;
-        switch (head) {
-          case XFMR_LOSS_INFONCE: g = a.scale * (O / ltot - (1.f - epos / ltot) * e); break;
-          case XFMR_LOSS_NCE: g = -xf_sigmoid(-pos_dot) * e + O * inv_d; break;
-          case XFMR_LOSS_PAIRWISE_HINGE:
-          case XFMR_LOSS_PAIRWISE_LOGISTIC: g = (O - (1.f - a.margin) * sw * e) * inv_d; break;
-          case XFMR_LOSS_ALIGNMENT: g = -rcpos * e; break;
-          case XFMR_LOSS_CONTRASTIVE: g = O * inv_c; break;
-          default: g = -rcpos * e + O * inv_c; break;  // ALIGNMENT_CONTRASTIVE
+        const float4 e4 = *reinterpret_cast<const float4*>(ep + c);
+        const float Ov[4] = {O.x, O.y, O.z, O.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+        float gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float Ou = Ov[u], e = ev[u];
+          float g;
+          switch (head) {
+            case XFMR_LOSS_INFONCE: g = a.scale * (Ou / ltot - (1.f - epos / ltot) * e); break;
+            case XFMR_LOSS_NCE: g = -xf_sigmoid(-pos_dot) * e + Ou * inv_d; break;
+            case XFMR_LOSS_PAIRWISE_HINGE:
+            case XFMR_LOSS_PAIRWISE_LOGISTIC: g = (Ou - (1.f - a.margin) * sw_ * e) * inv_d; break;
+            case XFMR_LOSS_ALIGNMENT: g = -rcpos * e; break;
+            case XFMR_LOSS_CONTRASTIVE: g = Ou * inv_c; break;
+            default: g = -rcpos * e + Ou * inv_c; break;  // ALIGNMENT_CONTRASTIVE
+          }
+          gv[u] = g;
         }
-        if (cosh) dotp += g * qp[c] * rq;
-        dst[c] = g;  // for cosine heads this is dq_hat, fixed up below
+        gk[sw] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        if (cosh) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qp + c);
+          dotp += (gv[0] * q4.x + gv[1] * q4.y + gv[2] * q4.z + gv[3] * q4.w) * rq;
+        } else {
+          *reinterpret_cast<float4*>(dst + c) = gk[sw];
+        }
       }
-      if (cosh) {
-        dotp = xf_wave_sum(dotp);
+      if (cosh) {  // (every lane of the half wave runs the same branch: head is uniform)
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dotp += __shfl_xor(dotp, o, 64);
         const bool clamped = sqrtf(qq) < 1e-8f;  // norm clamped: q_hat = q/eps, no projection term
-        for (int c = lane; c < H; c += 64) {
-          const float g = dst[c];
-          dst[c] = clamped ? g * rq : rq * (g - qp[c] * rq * dotp);
+#pragma unroll
+        for (int sw = 0; sw < 2; ++sw) {
+          const int c = sw * 128 + 4 * hl;
+          if (c >= H) continue;
+          const float4 q4 = *reinterpret_cast<const float4*>(qp + c);
+          float4 g = gk[sw];
+          if (clamped) { g.x *= rq; g.y *= rq; g.z *= rq; g.w *= rq; }
+          else {
+            g.x = rq * (g.x - q4.x * rq * dotp); g.y = rq * (g.y - q4.y * rq * dotp);
+            g.z = rq * (g.z - q4.z * rq * dotp); g.w = rq * (g.w - q4.w * rq * dotp);
+          }
+          *reinterpret_cast<float4*>(dst + c) = g;
         }
       }
     }
   }
-  if (lane == 0) {
+  if (hl == 0) {
 #pragma unroll
-    for (int k = 0; k < BP; ++k) sAcc[wid][k] = acc[k];
+    for (int k = 0; k < BP; ++k) sAcc[wid * 2 + half][k] = acc[k];
   }
   __syncthreads();
   if (threadIdx.x < BP) {
     const int k = threadIdx.x;
-    double v;
-    if (k == 20 || k == 22) v = fmin(fmin(sAcc[0][k], sAcc[1][k]), fmin(sAcc[2][k], sAcc[3][k]));
-    else if (k == 21 || k == 23) v = fmax(fmax(sAcc[0][k], sAcc[1][k]), fmax(sAcc[2][k], sAcc[3][k]));
-    else v = sAcc[0][k] + sAcc[1][k] + sAcc[2][k] + sAcc[3][k];
+    double v = sAcc[0][k];
+#pragma unroll
+    for (int w = 1; w < kCombineRows; ++w) {
+      if (k == 20 || k == 22) v = fmin(v, sAcc[w][k]);
+      else if (k == 21 || k == 23) v = fmax(v, sAcc[w][k]);
+      else v += sAcc[w][k];
+    }
     a.blockpart[(int64_t)k * gridDim.x + blockIdx.x] = v;  // [BP][blocks]: the final kernel reads coalesced
   }
 }
@@ -668,7 +700,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   if (ns > tiles) ns = tiles;
   if (ns < 1) ns = 1;
   p.nsplit = (int)ns;
-  p.nblocks = (int)((T + 3) / 4);
+  p.nblocks = (int)((T + kCombineRows - 1) / kCombineRows);
   size_t o = 0;
   p.off_counts = o; o += 256;
   p.off_blockcnt = o; o += up256((size_t)((T + PREP - 1) / PREP) * sizeof(int2));
@@ -842,7 +874,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   c.lse_from_grad = lse_from_grad ? 1 : 0;
   hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
-  return xf_loss_finalize(c.blockpart, p.nblocks, 4, counts, cfg->mode, n_rows, losses, stats,
+  return xf_loss_finalize(c.blockpart, p.nblocks, kCombineRows, counts, cfg->mode, n_rows, losses, stats,
                           (double*)(ws + p.off_tot), st);
 }
 
