@@ -58,6 +58,7 @@ LayerParams layer_params(const xfmr_encoder_cfg* c, int i) {
 struct LayerActs {
   void *qkv, *ctx, *f1, *g;                                           // bf16 when mixed
   float *lse, *pre1, *mean1, *rstd1, *x1, *pre2, *mean2, *rstd2, *x2;  // always fp32
+  void *x1b, *x2b;  // mixed storage: bf16 copies of the LayerNorm outputs (GEMM operands; x1 / x2 stay the residuals)
 };
 // Per-layer reduction inputs of the backward pass, reduced by ONE launch at its end (xf_multi_rowsum): split-K slabs
 // of the four weight gradients, partial rows of the two bias gradients that are column sums (b1, bqkv -- produced by
@@ -67,6 +68,7 @@ struct RedBufs {
 };
 struct Acts {
   float *emb_pre, *emb_mean, *emb_rstd, *x0;
+  void* x0b;      // bf16 copy of x0 (mixed storage)
   float* emb_ln;  // embedding LayerNorm partial records
   float *dA, *dB;
   void *dLin, *dCtx, *dI, *dQKV;  // bf16 when mixed
@@ -106,6 +108,8 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   auto take = [&](size_t nfloats) -> float* { return reinterpret_cast<float*>(take_bytes(nfloats * sizeof(float))); };
   Acts a{};
   a.emb_pre = take(T * H); a.emb_mean = take(T); a.emb_rstd = take(T); a.x0 = take(T * H);
+  const size_t xb = mixed_storage(c) ? T * H * 2 : 0;
+  a.x0b = take_bytes(xb);
   a.dA = take(T * H); a.dB = take(T * H);
   a.dLin = take_bytes(T * H * es); a.dCtx = take_bytes(T * H * es);
   a.dI = take_bytes(T * I * es); a.dQKV = take_bytes(T * 3 * H * es);
@@ -142,6 +146,7 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
     l.pre1 = take(T * H); l.mean1 = take(T); l.rstd1 = take(T); l.x1 = take(T * H);
     l.f1 = take_bytes(T * I * es); l.g = take_bytes(T * I * es);
     l.pre2 = take(T * H); l.mean2 = take(T); l.rstd2 = take(T); l.x2 = take(T * H);
+    l.x1b = take_bytes(xb); l.x2b = take_bytes(i + 1 < c->layers ? xb : 0);
     if (i == layer && la) *la = l;
   }
   a.total = o;
@@ -234,10 +239,12 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
   hipStream_t st = (hipStream_t)stream;
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
-  XF_TRY(xfmr_embed_ln_fwd(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
-                           params + pl.eb, a.x0, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask, B, L, H, cfg->ln_eps,
-                           cfg->hidden_dropout, cfg->seed, SITE_EMB, stream));
+  XF_TRY(xf_embed_ln_fwd_ex(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
+                            params + pl.eb, a.x0, mix ? a.x0b : nullptr, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask, B,
+                            L, H, cfg->ln_eps, cfg->hidden_dropout, cfg->seed, SITE_EMB, st));
   const float* x = a.x0;
+  const void* xg = mix ? a.x0b : (const void*)a.x0;  // the same activations as the GEMM operand
+  const uint32_t sA = mix ? XF_S16_A : 0;
   if (mix) {
     const int64_t n4 = pl.total / 4;  // (every tensor size is a multiple of 4: H, I multiples of 32)
     hipLaunchKernelGGL(params_to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, params,
@@ -253,21 +260,24 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     carve(cfg, base, i, &l);
     const LayerParams p = layer_params(cfg, i);
     float* out = (i == cfg->layers - 1) ? tok : l.x2;
-    XF_TRY(xf_linear_fwd_ex(x, W(p.wqkv), params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
-                            0.f, 0, 0, prec, (mix ? XF_S16_C : 0) | sB, st));
+    XF_TRY(xf_linear_fwd_ex(xg, W(p.wqkv), params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
+                            0.f, 0, 0, prec, (mix ? XF_S16_C : 0) | sA | sB, st));
     XF_TRY(xf_attn_fwd_ex(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, cfg->seed, site_attn(i), prec,
                           mix, st));
     XF_TRY(xf_linear_fwd_ex(l.ctx, W(p.wo), params + p.bo, l.pre1, T, H, H, XFMR_EPI_BIAS_DROP_RES, x, nullptr,
                             cfg->hidden_dropout, cfg->seed, site_out(i), prec, (mix ? XF_S16_A : 0) | sB, st));
-    XF_TRY(xfmr_layernorm_fwd(l.pre1, params + p.ln1g, params + p.ln1b, l.x1, l.mean1, l.rstd1, T, H, cfg->ln_eps,
-                              stream));
-    XF_TRY(xf_linear_fwd_ex(l.x1, W(p.w1), params + p.b1, l.g, T, I, H, XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f,
-                            0, 0, prec, (mix ? XF_S16_C : 0) | sB | XF_AUX_GELU_GRAD, st));  // f1 <- gelu'(pre)
+    XF_TRY(xf_layernorm_fwd_ex(l.pre1, params + p.ln1g, params + p.ln1b, l.x1, mix ? l.x1b : nullptr, l.mean1,
+                               l.rstd1, T, H, cfg->ln_eps, st));
+    XF_TRY(xf_linear_fwd_ex(mix ? (const void*)l.x1b : (const void*)l.x1, W(p.w1), params + p.b1, l.g, T, I, H,
+                            XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f, 0, 0, prec,
+                            (mix ? XF_S16_C : 0) | sA | sB | XF_AUX_GELU_GRAD, st));  // f1 <- gelu'(pre)
     XF_TRY(xf_linear_fwd_ex(l.g, W(p.w2), params + p.b2, l.pre2, T, H, I, XFMR_EPI_BIAS_DROP_RES, l.x1, nullptr,
                             cfg->hidden_dropout, cfg->seed, site_ffn(i), prec, (mix ? XF_S16_A : 0) | sB, st));
-    XF_TRY(xfmr_layernorm_fwd(l.pre2, params + p.ln2g, params + p.ln2b, out, l.mean2, l.rstd2, T, H, cfg->ln_eps,
-                              stream));
+    const bool last = i == cfg->layers - 1;
+    XF_TRY(xf_layernorm_fwd_ex(l.pre2, params + p.ln2g, params + p.ln2b, out, (mix && !last) ? l.x2b : nullptr,
+                               l.mean2, l.rstd2, T, H, cfg->ln_eps, st));
     x = out;
+    xg = mix ? (const void*)l.x2b : (const void*)out;
   }
   return XFMR_OK;
 }
@@ -305,10 +315,10 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     carve(cfg, base, i, &l, &r);
     const LayerParams p = layer_params(cfg, i);
     LayerActs prev;
-    const float* x_in = a.x0;
+    const void* x_in_g = mix ? a.x0b : (const void*)a.x0;  // the dW operand: the bf16 copy under mixed storage
     if (i > 0) {
       carve(cfg, base, i - 1, &prev);
-      x_in = prev.x2;
+      x_in_g = mix ? prev.x2b : (const void*)prev.x2;
     }
     int blocks = 0, splits = 0;
     // LayerNorm 2 -> dA = d(pre2); d_lin = gradient of the FFN output Linear (dropout-scaled copy of it)
@@ -323,7 +333,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, st));
     seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), a.dI, T, H, I, nullptr, l.f1, prec, sA | sC | sP | sB | XF_AUX_GELU_GRAD, st));
-    XF_TRY(xf_linear_bwd_dw_deferred(a.dI, l.x1, T, I, H, prec, sA, r.w1, r.b1, &splits, st));  // + b1 partial rows
+    XF_TRY(xf_linear_bwd_dw_deferred(a.dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, st));  // + b1 partial rows
     seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
     seg(r.b1, grads + p.b1, splits, I, I);
     XF_TRY(xf_linear_bwd_dx_ex(a.dI, W(p.w1), a.dA, T, I, H, a.dA, nullptr, prec, sA | sB, st));  // += d(pre2)
@@ -340,7 +350,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
     XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, a.dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
                           site_attn(i), prec, mix, st));
-    XF_TRY(xf_linear_bwd_dw_deferred(a.dQKV, x_in, T, 3 * H, H, prec, sA, r.wqkv, r.bqkv, &splits, st));
+    XF_TRY(xf_linear_bwd_dw_deferred(a.dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, st));
     seg(r.wqkv, grads + p.wqkv, splits, (int64_t)3 * H * H, (int64_t)3 * H * H);
     seg(r.bqkv, grads + p.bqkv, splits, 3 * H, 3 * H);
     XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, W(p.wqkv), dX, T, 3 * H, H, dX, nullptr, prec, sA | sB, st));  // += d(pre1)

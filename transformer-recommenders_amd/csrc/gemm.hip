@@ -613,10 +613,12 @@ int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, 
   switch (epilogue) {
     case XFMR_EPI_BIAS:
       g.R = nullptr;
-      return dispatch_gemm<false, false, EPI_STORE, XF_S16_C, (XF_S16_C | XF_S16_B)>(g, 1, precision, st);
+      return dispatch_gemm<false, false, EPI_STORE, XF_S16_C, (XF_S16_C | XF_S16_B),
+                           (XF_S16_A | XF_S16_B | XF_S16_C)>(g, 1, precision, st);
     case XFMR_EPI_BIAS_GELU:
       if (!aux_out) return XFMR_EINVAL;
-      return dispatch_gemm<false, false, EPI_GELU, XF_S16_C, (XF_S16_C | XF_S16_B)>(g, 1, precision, st);
+      return dispatch_gemm<false, false, EPI_GELU, XF_S16_C, (XF_S16_C | XF_S16_B),
+                           (XF_S16_A | XF_S16_B | XF_S16_C)>(g, 1, precision, st);
     case XFMR_EPI_BIAS_DROP_RES:
       if (!residual) return XFMR_EINVAL;
       return dispatch_gemm<false, false, EPI_DROP_RES, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, 1, precision, st);

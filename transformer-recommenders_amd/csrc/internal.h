@@ -49,6 +49,14 @@ int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, c
 // d_lin (optional): the gradient of the Linear output feeding this LayerNorm (dropout-scaled dx), bf16 if lin16
 // d_gamma == d_beta == d_bias == nullptr defers the reduction of `partials` ([blocks][3][H], blocks returned in
 // *blocks_out) to the caller (xf_multi_rowsum)
+// LayerNorm forward variants that also write a bf16 copy of the output (the operand of the GEMMs that consume it;
+// the fp32 output stays the residual stream). y16 / out16 may be null.
+int xf_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, float* y, void* y16, float* mean,
+                        float* rstd, int64_t rows, int32_t H, float eps, hipStream_t stream);
+int xf_embed_ln_fwd_ex(const int64_t* item_idx, const float* table, int64_t n_rows, const float* pos_emb,
+                       const float* type_emb, const float* gamma, const float* beta, float* out, void* out16,
+                       float* pre, float* mean, float* rstd, uint8_t* key_mask, int32_t B, int32_t L, int32_t H,
+                       float eps, float dropout_p, uint64_t seed, uint32_t site, hipStream_t stream);
 int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           float* dx, void* d_lin, bool lin16, float* d_gamma, float* d_beta, float* d_bias,
                           int64_t rows, int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials,

@@ -22,6 +22,7 @@ struct LnFwdArgs {
   float* y; float* pre; float* mean; float* rstd; uint8_t* key_mask;
   int64_t rows; int H; float eps;
   XfDropout drop;
+  __bf16* y16;             // optional bf16 copy of y: the A / B operand of the GEMMs that consume the output
 };
 
 template <int NPL, bool GATHER>
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
       float o = (v[i] - mean) * rstd * a.gamma[c] + a.beta[c];
       if (a.drop.on) o *= xf_keep_scale(a.drop, (uint32_t)(row * H + c));
       a.y[row * H + c] = o;
+      if (a.y16) a.y16[row * H + c] = (__bf16)o;
     }
   }
 }
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256) void ln_fwd_v4_kernel(LnFwdArgs a) {
     o.z *= xf_keep_scale(a.drop, e + 2); o.w *= xf_keep_scale(a.drop, e + 3);
   }
   *reinterpret_cast<float4*>(a.y + row * H + c) = o;
+  if (a.y16) xf_st4<true>(a.y16, row * H + c, o);
 }
 
 template <int LPR>
@@ -506,6 +509,14 @@ int xfmr_embed_ln_fwd(const int64_t* item_idx, const float* table, int64_t n_row
                       const float* type_emb, const float* gamma, const float* beta, float* out, float* pre,
                       float* mean, float* rstd, uint8_t* key_mask, int32_t B, int32_t L, int32_t H, float eps,
                       float dropout_p, uint64_t seed, uint32_t site, void* stream) {
+  return xf_embed_ln_fwd_ex(item_idx, table, n_rows, pos_emb, type_emb, gamma, beta, out, nullptr, pre, mean, rstd,
+                            key_mask, B, L, H, eps, dropout_p, seed, site, (hipStream_t)stream);
+}
+
+int xf_embed_ln_fwd_ex(const int64_t* item_idx, const float* table, int64_t n_rows, const float* pos_emb,
+                       const float* type_emb, const float* gamma, const float* beta, float* out, void* out16,
+                       float* pre, float* mean, float* rstd, uint8_t* key_mask, int32_t B, int32_t L, int32_t H,
+                       float eps, float dropout_p, uint64_t seed, uint32_t site, hipStream_t stream) {
   if (!item_idx || !table || !pos_emb || !type_emb || !gamma || !beta || !out || !pre || !mean || !rstd || !key_mask)
     return XFMR_EINVAL;
   if (B <= 0 || L <= 0 || H <= 0 || n_rows <= 0) return XFMR_EINVAL;
@@ -514,17 +525,24 @@ int xfmr_embed_ln_fwd(const int64_t* item_idx, const float* table, int64_t n_row
   a.L = L; a.gamma = gamma; a.beta = beta; a.y = out; a.pre = pre; a.mean = mean; a.rstd = rstd;
   a.key_mask = key_mask; a.rows = (int64_t)B * L; a.H = H; a.eps = eps;
   a.drop = xf_make_dropout(dropout_p, seed, site);
-  return launch_ln_fwd<true>(a, (hipStream_t)stream);
+  a.y16 = reinterpret_cast<__bf16*>(out16);
+  return launch_ln_fwd<true>(a, stream);
 }
 
 int xfmr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int64_t rows, int32_t H, float eps, void* stream) {
+  return xf_layernorm_fwd_ex(x, gamma, beta, y, nullptr, mean, rstd, rows, H, eps, (hipStream_t)stream);
+}
+
+int xf_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, float* y, void* y16, float* mean,
+                        float* rstd, int64_t rows, int32_t H, float eps, hipStream_t stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || H <= 0) return XFMR_EINVAL;
   LnFwdArgs a{};
   a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.rows = rows; a.H = H;
   a.eps = eps; a.L = 1;
   a.drop = xf_make_dropout(0.f, 0, 0);
-  return launch_ln_fwd<false>(a, (hipStream_t)stream);
+  a.y16 = reinterpret_cast<__bf16*>(y16);
+  return launch_ln_fwd<false>(a, stream);
 }
 
 size_t xfmr_layernorm_bwd_workspace(int64_t rows, int32_t H) {
