@@ -20,4 +20,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o loss -- \
     python3 "$ROOT/scripts/bench_loss.py" --reps 4 > "$OUT/pmc_$c.log" 2>&1
 done
+# matrix-core busy cycles of the same kernel (its own pass; GRBM_GUI_ACTIVE = cycles the GPU was active)
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
+  -d "$OUT/pmc_MFMA" -o loss -- python3 "$ROOT/scripts/bench_loss.py" --reps 4 > "$OUT/pmc_MFMA.log" 2>&1
 echo done > "$OUT/DONE"

@@ -70,6 +70,18 @@ def main():
                 "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 scripts/bench_loss.py --reps 4",
                 "round": a.tag,
             }
+            mf = find(src / "pmc_MFMA" / "**" / "*counter_collection.csv")
+            if mf:
+                busy = pmc_mean(mf, "SQ_VALU_MFMA_BUSY_CYCLES", a.kernel)
+                active = pmc_mean(mf, "GRBM_GUI_ACTIVE", a.kernel)
+                if busy and active:
+                    # SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md), summed
+                    # over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs (8 x the launch's cycles)
+                    rec |= {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": active,
+                            "mfma_instructions_per_launch": busy / 32.0,
+                            "mfma_busy_fraction": busy / (1024.0 * active / 8.0),
+                            "mfma_note": "matrix-core busy cycles summed over 1024 SIMDs / (1024 x active cycles of "
+                                         "the launch, GRBM_GUI_ACTIVE / 8 XCDs); its own --pmc pass"}
             (prof / "loss_main_traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
             print(rec)
     print("profiles/ updated from", src)
