@@ -252,15 +252,16 @@ def main():
     flops_reference = 4.0 * n_query * n_valid * H
     achieved = flops / (kern_avg * 1e-3) / 1e12 if kern_avg > 0 else 0.0
     peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
-    traffic = None
+    traffic = mfma_busy = None
     pmc = ROOT / "profiles" / "loss_main_traffic.json"
     if pmc.exists():
         try:
             rec = json.loads(pmc.read_text())
             if rec.get("batch") == B and rec.get("precision") == args.precision:
                 traffic = rec.get("hbm_bytes_per_launch")
+                mfma_busy = rec.get("mfma_busy_fraction")
         except Exception:  # noqa: BLE001
-            traffic = None
+            traffic = mfma_busy = None
 
     if rank == 0:
         seqs = B * world * args.steps
@@ -291,6 +292,8 @@ def main():
             "roofline": {
                 "kernel": "loss_main_dma_kernel (gradient pass of the fused sampled loss)", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
+                "hbm_gbps": None if traffic is None or kern_avg <= 0 else round(traffic / (kern_avg * 1e-3) / 1e9, 1),
+                "mfma_busy_fraction_pmc": mfma_busy,
                 "avg_launch_ms": round(kern_avg, 4), "algorithmic_flops_per_launch": flops,
                 "columns": int(n_cols), "sampled_negative_columns": int(n_valid),
                 "reference_form_flops_per_launch": flops_reference,
