@@ -721,6 +721,110 @@ __device__ __forceinline__ AttnBlock attn_seq_block(const AttnArgs& a) {  // as 
   return AttnBlock{0, b * a.A + slot % a.A, b < a.B};
 }
 
+// ---- forward, one workgroup per (batch, head) (L <= 256) -----------------------------------------------------------
+// K and V are staged once for the whole sequence (the two-block form staged the first 128 keys twice) and the query
+// tiles are dealt so that every wave walks the same number of key blocks: tile t has t + 1 of them, wave w takes tiles
+// (tiles - 1 - w) and (tiles - 8 + w). The output goes straight from the accumulator layout (lane = query row) to
+// global memory, so no wave waits for the others before it stores.
+template <bool S16>
+__global__ __launch_bounds__(256) void attn_fwd_seq_bf16_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const AttnBlock blk = attn_seq_block(a);
+  if (!blk.valid) return;  // (whole workgroup)
+  const int b = blk.by / a.A, h = blk.by % a.A;
+  const int Lp = ((L + 31) / 32) * 32, nt = Lp / 32;
+  __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* sV = sK + Lp * DH;
+  uint32_t* sBits = reinterpret_cast<uint32_t*>(sV + Lp * DH);  // key mask, one bit per key
+
+  const int64_t tok0 = (int64_t)b * L;
+  const int lane = xf_lane(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5;
+  // the wave's (at most two) query tiles; their query rows are in flight while K / V are staged
+  const int qt[2] = {nt - 1 - wid, nt - 8 + wid};
+  RegRows<PrecBF16, DH> qreg[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = qt[i] * 32 + (lane & 31);
+    qreg[i].template load_at<S16>(a.qkv, (tok0 + q) * 3 * H + h * DH, qt[i] >= 0 && q < L);
+  }
+  stage2_rows_swz<S16>(sK, a.qkv, tok0 * 3 * H + H + h * DH, 3 * H, sV, a.qkv, tok0 * 3 * H + 2 * H + h * DH, 3 * H, 0,
+                       Lp, L);
+  stage_key_bits(sBits, a.key_mask + tok0, Lp, L);
+  __syncthreads();
+
+  const float sc = 0.17677669529663687f * kLog2e;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (qt[i] < 0) continue;
+    const int q0 = qt[i] * 32, q = q0 + (lane & 31);
+    float m = -INFINITY, lsum = 0.f;
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + q));
+    for (int kb = 0; kb <= qt[i]; ++kb) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      AI::tile_nreg(s, sK, kb * 32, qreg[i].regs());
+      float bmax = -INFINITY;
+      const uint32_t kword = sBits[kb];
+      // interior tile: every key is before the wave's first query and none is padding -- no per-score masking
+      const bool interior = kb < qt[i] && __builtin_amdgcn_readfirstlane(kword) == 0xFFFFFFFFu;
+      if (interior) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, s[r]);
+        bmax *= sc;
+      } else {
+        const uint32_t kbits = kword >> (4 * hh);  // this half-wave's keys: bit (r&3) + 8*(r>>2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + xf_acc_row(r, lane);
+          const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
+          s[r] = vis ? s[r] : -INFINITY;
+          bmax = fmaxf(bmax, s[r]);
+        }
+        bmax *= sc;  // (sc > 0; -inf stays -inf)
+      }
+      bmax = fmaxf(bmax, xf_half_swap(bmax));
+      const float mnew = fmaxf(m, bmax);
+      if (__all(mnew == -INFINITY)) continue;
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = xf_exp2(m - msafe);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = xf_exp2(fmaf(s[r], sc, -msafe));
+        psum += p;
+        s[r] = a.drop.on
+                   ? p * xf_keep_scale_rc(a.drop, rowkey, (uint32_t)(kb * 32 + xf_acc_row(r, lane)) * kDropColMul)
+                   : p;
+      }
+      lsum = lsum * alpha + psum;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+      m = mnew;
+      AI::tile_xb_tr(o, sV, 0, kb * 32, s);
+    }
+    const float ltot = lsum + xf_half_swap(lsum);
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if (q < L) {  // o[r] <-> (d = acc_row(r), query = lane & 31): 4 consecutive d per register group
+      const int64_t off = (tok0 + q) * H + h * DH;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        xf_st4<S16>(a.ctx, off + 8 * g + 4 * hh,
+                    make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv));
+      if (lane < 32) a.lse[((int64_t)blk.by) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
+    }
+  }
+}
+
+size_t bf16_smem_fwd_seq(int L) {  // K + V images of the whole sequence, key mask bits
+  const size_t Lp = ((size_t)L + 31) / 32 * 32;
+  return 2 * Lp * DH * 2 + (Lp / 32 + 2) * sizeof(uint32_t);
+}
+
 template <bool S16>
 __global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -991,6 +1095,17 @@ constexpr size_t kLdsLimit = 160 * 1024;
 
 template <bool S16>
 int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
+  static const int two_blocks = [] { const char* e = getenv("XFMR_ATTN_FWD_SPLIT"); return e ? atoi(e) : 0; }();
+  if (!two_blocks && a.L <= kFusedMaxL) {
+    const size_t sf = bf16_smem_fwd_seq(a.L);
+    if (hipFuncSetAttribute((const void*)attn_fwd_seq_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sf) != hipSuccess)
+      return XFMR_EHIP;
+    hipLaunchKernelGGL((attn_fwd_seq_bf16_kernel<S16>), dim3((unsigned)(a.A * ((a.B + 7) / 8) * 8)), dim3(256), sf, st,
+                       a);
+    XF_LAUNCH_CHECK();
+    return XFMR_OK;
+  }
   dim3 grid((unsigned)(((a.L + 127) / 128) * a.A * ((a.B + 7) / 8) * 8));  // see attn_block
   const size_t sm = bf16_smem_fwd(a.L);
   if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
