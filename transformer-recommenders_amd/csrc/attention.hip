@@ -727,7 +727,7 @@ __device__ __forceinline__ AttnBlock attn_seq_block(const AttnArgs& a) {  // as 
 // (tiles - 1 - w) and (tiles - 8 + w). The output goes straight from the accumulator layout (lane = query row) to
 // global memory, so no wave waits for the others before it stores.
 template <bool S16>
-__global__ __launch_bounds__(256) void attn_fwd_seq_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_seq_block(a);
