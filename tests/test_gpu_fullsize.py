@@ -125,6 +125,21 @@ def test_config4_full_catalogue_softmax_equals_dense_cross_entropy(XL, ops):
         want.backward()
         assert abs(got.item() - want.item()) <= TOL[prec]["loss_rel"] * abs(want.item()), (prec, got.item(), want.item())
         assert rel_l2(qd.grad, qr.grad) <= TOL[prec]["grad_l2"], prec
+    # the training step's form (positions, every head + statistics in the same call): the logging pass runs first and
+    # the gradient pass pins its running maximum from the logging records (HEAD_INFONCE_PINNED) -- same value, same
+    # gradient as the single-head evaluation with its online maximum, and as the dense closed form
+    from xfmr_rec_amd import _native as N
+
+    mask = torch.ones(Np, dtype=torch.uint8, device=DEV)
+    kw = dict(train_head="InfoNCELoss", mask_false_negatives=False, mode=N.NEG_CATALOG, precision="bf16", table_bf16=tb)
+    l_all, s_all, d_all = ops.sampled_loss(q, mask, pos, None, table, rn, all_heads=True, **kw)
+    l_one, _s, d_one = ops.sampled_loss(q, mask, pos, None, table, rn, all_heads=False, **kw)
+    i = N.LOSS_IDS["InfoNCELoss"]
+    assert float(l_all[i]) == pytest.approx(float(l_one[i]), rel=1e-5)
+    assert rel_l2(d_all, d_one) <= 1e-3  # (the softmax weights enter the second MFMA as bf16, scaled differently)
+    assert abs(float(l_all[i]) - want.item()) <= TOL["bf16"]["loss_rel"] * abs(want.item())
+    assert rel_l2(d_all, qr.grad) <= TOL["bf16"]["grad_l2"]
+    assert int(s_all[N.STAT["neg_distinct"]]) == V + 1
 
 
 def test_config5_million_item_gather_is_bit_exact_and_ccl_runs(XL, ops):

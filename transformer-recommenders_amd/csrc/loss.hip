@@ -832,6 +832,24 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
     // no negative term) and, when every head is wanted or no gradient is, the values-only logging pass.
     const bool all = cfg->all_heads != 0;
     const bool grad_pass = a.need_grad && cfg->train_head != XFMR_LOSS_ALIGNMENT;
+    // unmasked InfoNCE with the logging pass in the same call: logging first, then the gradient pass with the row
+    // maximum pinned from the logging records (lean epilogue, see HEAD_INFONCE_PINNED)
+    const bool pinned = grad_pass && cfg->all_heads == 1 && cfg->train_head == XFMR_LOSS_INFONCE &&
+                        !cfg->mask_false_negatives;
+    if (pinned) {
+      LossArgs b = a;
+      b.part = (float*)(ws + p.off_part2);
+      b.need_grad = 0;
+      rc = launch_dma_h(b, table_bf16, H, -2, grid, st);  // (the InfoNCE value comes from the gradient records)
+      if (rc) return rc;
+      part_loss = b.part;
+      lse_from_grad = true;
+      a.pin_part = b.part;
+      if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
+      rc = launch_dma_h(a, table_bf16, H, cfg->train_head, grid, st);
+      if (rc) return rc;
+      if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
+    } else {
     if (grad_pass) {
       if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
       rc = launch_dma_h(a, table_bf16, H, cfg->train_head, grid, st);
@@ -854,6 +872,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       if (rc) return rc;
       if (!grad_pass && ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
       if (grad_pass) part_loss = b.part;
+    }
     }
   } else {
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;

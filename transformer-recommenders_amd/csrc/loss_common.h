@@ -16,6 +16,10 @@ enum { R_CNTD = 0, R_M, R_L, R_NCE, R_HINGE, R_LOGI, R_CNTC, R_CONTR, R_SSUM, R_
 constexpr int BP = 24;        // doubles per block-partial record
 // kernel-template head code of the InfoNCE gradient pass with false-negative masking (the lean epilogue below)
 constexpr int HEAD_INFONCE_MASKED = XFMR_NUM_LOSSES;
+// InfoNCE WITHOUT false-negative masking (full-catalogue softmax) when the logging pass of the same call has already
+// run: the row maximum of the counted logits is in its records (R_SMAX), so the running maximum is pinned at
+// max(scale * pos, scale * smax) and the lean epilogue applies -- no online rescaling of the dQ accumulators.
+constexpr int HEAD_INFONCE_PINNED = XFMR_NUM_LOSSES + 1;
 
 struct LossArgs {
   const float* tok; const float* table; const float* rnorm; int64_t n_rows;
@@ -34,6 +38,7 @@ struct LossArgs {
   // (dump[qi * dump_ld + j] = S^T tile values, qinfo[qi] = {pos_dot, 1/|q|}); `tau` != null restricts the negatives of
   // row qi to those at / above its thresholds tau[qi] = {tau_dot, rho_dot, tau_cos, rho_cos}
   float* dump; int64_t dump_ld; float2* qinfo; const float4* tau;
+  const float* pin_part;  // HEAD_INFONCE_PINNED: the logging pass's split records (row maxima)
   int T; int nsplit;
   int train_head, mask_fn, mode, need_grad;
   float scale, margin;
@@ -194,6 +199,34 @@ __device__ __forceinline__ void loss_epilogue_infonce_masked(f32x16& s, float& l
       if (CHECK_VALID) counted &= nn[u] >= 0;  // only the last tile of the range can hold past-the-end columns
       cnt += counted ? mu[u] : 0.f;
       const float e = xf_exp2(counted ? fmaf(s[r], sc2, -m) : -INFINITY) * mu[u];
+      l += e;
+      s[r] = e;
+    }
+  }
+}
+
+// The unmasked counterpart (HEAD_INFONCE_PINNED): every valid column counts (the positive's own item only in the
+// in-batch form, with the positive's logit, as losses.py has it); m >= every counted logit by construction.
+template <bool CHECK_VALID>
+__device__ __forceinline__ void loss_epilogue_infonce_pinned(f32x16& s, float& l, float& cnt, float pos_dot, float sc2,
+                                                             float m, int pos_item, bool catalog, const int* nid_sb,
+                                                             const float* mu_sb, int hh) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[8 * g + 4 * hh]);
+    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+    const float4 m4 = *reinterpret_cast<const float4*>(&mu_sb[8 * g + 4 * hh]);
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * g + u;
+      const bool same = nn[u] == pos_item;
+      const float sv = same ? pos_dot : s[r];
+      bool counted = !(catalog & same);
+      if (CHECK_VALID) counted &= nn[u] >= 0;
+      const float w = counted ? mu[u] : 0.f;
+      cnt += w;
+      const float e = xf_exp2(fminf(fmaf(sv, sc2, -m), 0.f)) * w;
       l += e;
       s[r] = e;
     }

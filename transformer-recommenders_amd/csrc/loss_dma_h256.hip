@@ -6,7 +6,7 @@
 int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st) {
   const __bf16* tbf = (const __bf16*)table_bf16;
   dim3 block(256);
-  if (head == XFMR_LOSS_INFONCE && !a.mask_fn) grid.z = 2;  // two dQ column halves (loss_dma.inc)
+  if (head == XFMR_LOSS_INFONCE && !a.mask_fn && !a.pin_part) grid.z = 2;  // two dQ column halves (loss_dma.inc)
   switch (head) {
     case -1: hipLaunchKernelGGL((loss_main_dma_kernel<256, -1>), grid, block, 0, st, a, tbf); break;
     case -2: hipLaunchKernelGGL((loss_main_dma_kernel<256, -2>), grid, block, 0, st, a, tbf); break;
@@ -16,6 +16,7 @@ int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, 
       hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_INFONCE:
       if (a.mask_fn) hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_INFONCE_MASKED>), grid, block, 0, st, a, tbf);
+      else if (a.pin_part) hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_INFONCE_PINNED>), grid, block, 0, st, a, tbf);
       else hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_INFONCE>), grid, block, 0, st, a, tbf);
       break;
     case XFMR_LOSS_NCE:

@@ -15,6 +15,7 @@ int xf_launch_loss_dma_64(const LossArgs& a, const void* table_bf16, int head, d
       hipLaunchKernelGGL((loss_main_dma_kernel<64, XFMR_LOSS_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_INFONCE:
       if (a.mask_fn) hipLaunchKernelGGL((loss_main_dma_kernel<64, HEAD_INFONCE_MASKED>), grid, block, 0, st, a, tbf);
+      else if (a.pin_part) hipLaunchKernelGGL((loss_main_dma_kernel<64, HEAD_INFONCE_PINNED>), grid, block, 0, st, a, tbf);
       else hipLaunchKernelGGL((loss_main_dma_kernel<64, XFMR_LOSS_INFONCE>), grid, block, 0, st, a, tbf);
       break;
     case XFMR_LOSS_NCE:

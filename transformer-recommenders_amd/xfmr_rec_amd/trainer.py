@@ -160,7 +160,10 @@ class RecommenderLightningModule(_Base):
                     mode=N.NEG_CATALOG if catalogue else N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision,
                     table_bf16=m.table_bf16, num_hard_negatives=c.num_hard_negatives)
         overlap = (defer_logging and c.log_all_losses and tok.requires_grad and torch.is_grad_enabled()
-                   and m.table_bf16 is not None and c.precision == "bf16" and c.num_hard_negatives == 0)
+                   and m.table_bf16 is not None and c.precision == "bf16" and c.num_hard_negatives == 0
+                   # unmasked InfoNCE: ONE call runs the logging pass first and pins the gradient pass's running
+                   # maximum from its records (lean epilogue) -- worth more than the overlap
+                   and not (c.train_loss == "InfoNCELoss" and not c.mask_false_negatives))
         if overlap:
             # The six logging heads + statistics do not feed the gradient: evaluate them on a side stream so the
             # (VALU-bound) logging pass runs underneath the (latency-bound) encoder backward. The caller joins
