@@ -158,8 +158,12 @@ def _attention_reference(qkv, key_mask, A):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,L,A,lengths", [(3, 12, 1, [12, 7, 1]), (2, 40, 2, [33, 40]), (2, 130, 2, [130, 77]),
-                                           (2, 200, 4, [200, 150]), (1, 256, 1, [250])])
+                                           (2, 200, 4, [200, 150]), (1, 256, 1, [250]),
+                                           # L > 256: the two-block forward and the two-kernel backward
+                                           (2, 320, 2, [320, 301]), (1, 512, 1, [512])])
 def test_attention_fwd_bwd(ops, prec, B, L, A, lengths):
+    if prec == "fp32" and L > 256:
+        pytest.skip("fp32 parity policy: its kernels keep whole fp32 panels in LDS (L <= 256); see DESIGN.md section 2")
     H = 32 * A
     qkv = _rand(B, L, 3 * H, seed=3)
     mask = torch.zeros(B, L, dtype=torch.uint8)
