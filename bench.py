@@ -72,6 +72,11 @@ def parse():
                     help="catalogue = full-catalogue softmax (BASELINE config 4; SURVEY F9)")
     ap.add_argument("--preset", default=None, choices=["config2", "config3", "config4", "config5"],
                     help="the other BASELINE.json configs as sanity workloads (the bench line is config2, the default)")
+    ap.add_argument("--spinup-steps", type=int, default=300,
+                    help="untimed steps of the same workload BEFORE the --warmup steps (same count on every rank): a "
+                         "fresh box can take > 100 ms of sustained load to reach its steady clocks -- first runs on "
+                         "cold boxes measured 20-40 %% low with 5 warmup steps alone; the metric is steady-state "
+                         "throughput (SURVEY section 8d)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=12)
     args = ap.parse_args()
@@ -219,6 +224,9 @@ def main():
         mod.sync_logging()
         return loss, out
 
+    for i in range(args.spinup_steps):  # device spin-up (clocks, caches, allocator pools): untimed, not the warmup
+        step(i)
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     ev = HipEvents(args.steps)
@@ -272,6 +280,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "spinup_steps": args.spinup_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",

@@ -13,9 +13,9 @@ cd "$ROOT"
 timeout -k 10 420 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- \
-  python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --overlap off > "$OUT/trace.log" 2>&1
+  python3 "$ROOT/bench.py" --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline --overlap off > "$OUT/trace.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_overlap" -o bench -- \
-  python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --overlap on > "$OUT/trace_overlap.log" 2>&1
+  python3 "$ROOT/bench.py" --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline --overlap on > "$OUT/trace_overlap.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o loss -- \
     python3 "$ROOT/scripts/bench_loss.py" --reps 4 > "$OUT/pmc_$c.log" 2>&1

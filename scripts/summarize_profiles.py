@@ -53,7 +53,7 @@ def main():
             shutil.copy(stats, prof / f"{a.tag}_kernel_stats.csv")
         md = subprocess.run([sys.executable, str(ROOT / "scripts" / "rocpd_stats.py"), stats, "--steps", str(a.steps),
                              "--top", "40", "--md"], capture_output=True, text=True, check=True).stdout
-        head = (f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+        head = (f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline"
                 f"{' --overlap on' if suffix else ' --overlap off'}  ({a.tag}; {a.steps} steps profiled)\n")
         (prof / f"{a.tag}_kernel_stats{suffix}.md").write_text(head + md)
     f = find(src / "pmc_FETCH_SIZE" / "**" / "*counter_collection.csv")
