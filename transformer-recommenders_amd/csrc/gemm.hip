@@ -526,7 +526,18 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   // (scripts/bench_gemm.py): many small workgroups win -- 64x64 tiles with 32-deep slices for the forward /
   // dX GEMMs (64x128 once N >= 256), 128x128 tiles with 128-deep slices only for the split-K dW GEMMs.
   int bm = 64, bn = (g.N >= 256 && EPI != EPI_GELU_GRAD) ? 128 : 64;
-  if (EPI == EPI_SPLITK && g.M > 64 && g.N > 64) { bm = 128; bn = 128; }
+  if (EPI == EPI_SPLITK && g.M > 64 && g.N > 64) {
+    // 128 x 64: twice the workgroups of 128 x 128 at half the LDS and registers each -- the split-K GEMMs are a
+    // latency chain of a dozen K slices per workgroup and want co-resident workgroups (measured +1.4 ... 2 % of the
+    // step at batch 512 / 128 against 128 x 128; 64 x 64 no better). XFMR_DW_TILE="bm,bn" for experiments.
+    bm = 128; bn = 64;
+    static const TileOverride dw = [] {
+      TileOverride o{0, 0, 0};
+      if (const char* e = getenv("XFMR_DW_TILE")) sscanf(e, "%d,%d", &o.bm, &o.bn);
+      return o;
+    }();
+    if (dw.bm) { bm = dw.bm; bn = dw.bn; }
+  }
   const TileOverride ov = tile_override();
   if (ov.bm) { bm = ov.bm; bn = ov.bn; }
   dim3 block(256);
