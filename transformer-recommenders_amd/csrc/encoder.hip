@@ -133,8 +133,8 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
     r.w1 = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)I, (int32_t)H) / sizeof(float));
     r.wo = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)H, (int32_t)H) / sizeof(float));
     r.wqkv = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)(3 * H), (int32_t)H) / sizeof(float));
-    r.b1 = take(64 * I);      // <= 64 splits (dw_split_plan)
-    r.bqkv = take(64 * 3 * H);
+    r.b1 = take(256 * I);      // <= 256 splits (dw_split_plan)
+    r.bqkv = take(256 * 3 * H);
     r.ln2 = take(xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float));
     r.ln1 = take(xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float));
     if (i == layer && rb) *rb = r;

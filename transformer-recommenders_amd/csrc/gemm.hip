@@ -587,10 +587,17 @@ int dispatch_gemm(const GemmArgs& g, int splits, int precision, hipStream_t st) 
 }
 
 int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
-  // reduction dimension = M (tokens): <= 64 deterministic slabs, ~256-512 workgroups in total
+  // reduction dimension = M (tokens): <= 128 deterministic slabs
   int64_t tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  // <= 128 slabs: the 128 x 128 / 384 x 128 weights have few output tiles and need the splits for parallelism
+  // (64 -> 128: +0.9 % of the step at batch 512; 256 no better). XFMR_DW_MAXSPLIT for experiments (<= 256).
+  static const int max_split = [] {
+    const char* e = getenv("XFMR_DW_MAXSPLIT");
+    const int v = e ? atoi(e) : 128;
+    return v < 1 ? 1 : (v > 256 ? 256 : v);
+  }();
   int64_t want = (1024 + tiles - 1) / tiles;
-  if (want > 64) want = 64;
+  if (want > max_split) want = max_split;
   if (want < 1) want = 1;
   int64_t chunk = (M + want - 1) / want;
   chunk = ((chunk + 127) / 128) * 128;  // multiple of the deep K slice
