@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="logging heads on a side stream under the encoder backward: pays off once the logging pass is "
-                         "long enough (B*L >= 51200: +2 %% at B=512; -2 %% at B=128); auto decides by that")
+                         "long enough (B*L >= 102400: +0.6 %% at B=512, -1.4 %% at B=256, -2 %% at B=128); auto decides by that")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)  # former default switch; no effect
     ap.add_argument("--heads", type=int, default=0, help="attention heads (default hidden/32: head size 32)")
     ap.add_argument("--negatives", default="in_batch", choices=["in_batch", "catalogue"],
@@ -208,7 +208,7 @@ def main():
         batches.append({k: v.to(dev) for k, v in b.items()})
     tokens_per_seq = sum(lens) / len(lens)
 
-    overlap = args.overlap == "on" or (args.overlap == "auto" and B * L >= 51200)
+    overlap = args.overlap == "on" or (args.overlap == "auto" and B * L >= 102400)
 
     def step(i):
         batch = batches[i % n_batches]
