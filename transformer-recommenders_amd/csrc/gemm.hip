@@ -522,9 +522,9 @@ static TileOverride tile_override() {
 
 template <class P, int BK, bool TA, bool TB, int EPI, uint32_t S>
 int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
-  // These GEMMs are skinny (K <= 1024) and latency-bound, not MFMA-bound. Measured on MI355X at T = 25 600
-  // (scripts/bench_gemm.py): many small workgroups win -- 64x64 tiles with 32-deep slices for the forward /
-  // dX GEMMs (64x128 once N >= 256), 128x128 tiles with 128-deep slices only for the split-K dW GEMMs.
+  // These GEMMs are skinny (K <= 1024): bound by the CU's memory-instruction throughput and by how many workgroups
+  // are co-resident, not by the matrix core. Many small workgroups win -- 64x64 tiles with
+  // 64-deep slices for the forward / dX GEMMs (64x128 once N >= 256), 128-deep slices only for the split-K dW GEMMs.
   int bm = 64, bn = (g.N >= 256 && EPI != EPI_GELU_GRAD) ? 128 : 64;
   if (EPI == EPI_SPLITK && g.M > 64 && g.N > 64) {
     // 128 x 64: twice the workgroups of 128 x 128 at half the LDS and registers each -- the split-K GEMMs are a
