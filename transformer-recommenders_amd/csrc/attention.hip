@@ -826,7 +826,7 @@ size_t bf16_smem_fwd_seq(int L) {  // K + V images of the whole sequence, key ma
 }
 
 template <bool S16>
-__global__ __launch_bounds__(256) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_seq_block(a);
