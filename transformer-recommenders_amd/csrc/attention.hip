@@ -410,7 +410,7 @@ __device__ __forceinline__ float dot16(const void* x, const void* y, int64_t off
 }
 
 template <bool S16>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_block(a);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
 }
 
 template <bool S16>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_block(a);
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 }
 
 template <bool S16>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_block(a);
