@@ -267,6 +267,56 @@ def test_attention_dropout_keep_rate(ops, prec):
     assert float(kept[:, -1, :].mean()) / L == pytest.approx(1 - p, abs=0.02)
 
 
+@pytest.mark.parametrize("K,M,p_drop", [(128, 300, 0.0), (512, 1000, 0.0), (128, 4096 + 17, 0.2)])
+@pytest.mark.parametrize("bf16_storage", [False, True])
+def test_linear_with_layernorm_in_the_epilogue(ops, K, M, p_drop, bf16_storage):
+    """xf_linear_ln_fwd_ex (internal entry point of the encoder forward at T >= 16 384: out-proj / FFN2 Linear +
+    bias + dropout + residual + LayerNorm in ONE kernel) against the two-kernel form it replaces: same pre-LayerNorm
+    sum bit for bit (same GEMM arithmetic, same dropout mask), LayerNorm output / mean / rstd to fp32 rounding, and the
+    bf16 copy = the rounded fp32 output. Partial last tile (M not a multiple of 64) included."""
+    import ctypes as C
+
+    from xfmr_rec_amd import _native as N
+
+    lib = N.load()
+    Nn = 128
+    g = torch.Generator().manual_seed(K + M)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(Nn, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(Nn, generator=g).to(DEV)
+    res = torch.randn(M, Nn, generator=g).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(Nn, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(Nn, generator=g)).to(DEV)
+    # reference: the public two-kernel path (bf16 MFMA policy)
+    pre_ref = ops.linear_fwd(x, w, b, epilogue=N.EPI_BIAS_DROP_RES, residual=res, dropout_p=p_drop, seed=5, site=9,
+                             precision="bf16")
+    y_ref, mean_ref, rstd_ref = ops.layernorm_fwd(pre_ref, gamma, beta)
+    xs, ws, s16 = x, w, 0
+    if bf16_storage:  # the encoder's storage: bf16 A and B operands (identical products)
+        xs, ws, s16 = x.to(torch.bfloat16), w.to(torch.bfloat16), 3
+        pre_ref = ops.linear_fwd(xs.float(), ws.float(), b, epilogue=N.EPI_BIAS_DROP_RES, residual=res,
+                                 dropout_p=p_drop, seed=5, site=9, precision="bf16")
+        y_ref, mean_ref, rstd_ref = ops.layernorm_fwd(pre_ref, gamma, beta)
+    pre = torch.empty(M, Nn, device=DEV)
+    y = torch.empty(M, Nn, device=DEV)
+    y16 = torch.empty(M, Nn, device=DEV, dtype=torch.bfloat16)
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    fn = lib.xf_linear_ln_fwd_ex
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32,
+                                      C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 4 + [C.c_int32, C.c_uint32,
+                                                                                               C.c_void_p]
+    rc = fn(N.ptr(xs), N.ptr(ws), N.ptr(b), N.ptr(pre), M, Nn, K, N.ptr(res), p_drop, 5, 9, N.ptr(gamma), N.ptr(beta),
+            1e-12, N.ptr(y), N.ptr(y16), N.ptr(mean), N.ptr(rstd), N.precision_id("bf16"), s16, N.stream())
+    assert rc == 0, rc
+    assert torch.equal(pre, pre_ref)
+    torch.testing.assert_close(mean, mean_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd, rstd_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(y, y_ref, rtol=1e-5, atol=2e-6)
+    assert torch.equal(y16, y.to(torch.bfloat16))
+
+
 def test_adamw_matches_torch(ops):
     n = 10007
     p, g = _rand(n, seed=1), _rand(n, seed=2)

@@ -14,7 +14,10 @@
 
 namespace {
 
-enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DROP_RES = 2, EPI_GELU_GRAD = 3, EPI_SPLITK = 4 };
+// EPI_DROP_RES_LN: EPI_DROP_RES whose tile spans whole output rows (BN == N): the LayerNorm that follows the Linear
+// (TF:modeling_bert.py:292,349) is applied in the epilogue -- C = pre-LayerNorm sum (the backward needs it), Y / Y16 =
+// the normalised output (fp32 residual stream + bf16 GEMM operand), mean / rstd per row.
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DROP_RES = 2, EPI_GELU_GRAD = 3, EPI_SPLITK = 4, EPI_DROP_RES_LN = 5 };
 
 struct GemmArgs {
   const void* A; const void* B; void* C;  // fp32, or bf16 where the storage mask says so
@@ -30,6 +33,9 @@ struct GemmArgs {
   uint32_t s16;           // XF_S16_* storage mask (bf16 policy only)
   float* bias_part;       // EPI_SPLITK with A' = dy^T: row sums of A' over this split's K range -> [splits][M]
   XfDropout drop;
+  // EPI_DROP_RES_LN
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  float* Y; void* Y16; float* ln_mean; float* ln_rstd;
 };
 
 // One operand tile (ROWS x BK, fp32 in memory) in flight in registers, then committed to an LDS image of the
@@ -311,6 +317,112 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // covers the wave's whole column range: full 128-byte lines even for bf16 outputs when the wave owns 64 columns
   // (one wave instruction = 4-8 rows x 128-256 B instead of 2 rows x 32 scattered 4- or 2-byte elements).
   __syncthreads();  // everyone is done with the operand images the scratch aliases
+  if constexpr (EPI == EPI_DROP_RES_LN) {
+    if constexpr (BM == 64 && BN == 128) {
+      // The wave owns 32 rows x 64 columns; a row's other 64 columns are with the partner wave (wc ^ 1). Lane ->
+      // (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3): 16 lanes per row, 8 rows per lane, all kept in registers.
+      constexpr int LPRL = 16, RPPL = 4, NPL = 4;
+      float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
+      float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 wr][2 wc][32 rows] x 2 (sum, sumsq)
+      const int prow = lane / LPRL, li = lane % LPRL, c0 = li * 4;
+      const int n = wc * WN + c0;  // (n0 == 0: one N tile)
+      const float4 bias = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0, 0, 0, 0);
+      float4 vv[2][NPL];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int64_t mb = m0 + wr * WM + 16 * hf;
+        float4 aux[NPL];
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          aux[ps] = make_float4(0, 0, 0, 0);
+          const int64_t m = mb + prow + RPPL * ps;
+          if (m < g.M) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * g.ldc + n);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[0][j][8 * hf + r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          const int row = prow + RPPL * ps;
+          const int64_t m = mb + row;
+          float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
+          v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+          if (g.drop.on) {
+            const uint32_t e = (uint32_t)(m * g.N + n);
+            v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
+            v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
+          }
+          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
+          if (m >= g.M) v = make_float4(0, 0, 0, 0);
+          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = v;
+          vv[hf][ps] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();  // every wave is done with its scratch strip before `red` (behind the strips) is written
+      auto row_reduce = [&](float x) {  // over the 16 lanes that hold a row's 64 columns of this wave
+        x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+        return x;
+      };
+      float mean[2][NPL];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          const float4 v = vv[hf][ps];
+          const float s = row_reduce((v.x + v.y) + (v.z + v.w));
+          if (li == 0) red[(wr * 2 + wc) * 32 + 16 * hf + prow + RPPL * ps] = s;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          const int rr = 16 * hf + prow + RPPL * ps;
+          mean[hf][ps] = (red[(wr * 2) * 32 + rr] + red[(wr * 2 + 1) * 32 + rr]) * (1.f / 128.f);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          float4& v = vv[hf][ps];
+          const float mu = mean[hf][ps];
+          v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+          const float s = row_reduce((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+          if (li == 0) red[(wr * 2 + wc) * 32 + 16 * hf + prow + RPPL * ps] = s;
+        }
+      __syncthreads();
+      const float4 gm = *reinterpret_cast<const float4*>(g.ln_gamma + n);
+      const float4 bt = *reinterpret_cast<const float4*>(g.ln_beta + n);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          const int rr = 16 * hf + prow + RPPL * ps;
+          const int64_t m = m0 + wr * WM + rr;
+          const float var = (red[(wr * 2) * 32 + rr] + red[(wr * 2 + 1) * 32 + rr]) * (1.f / 128.f);
+          const float rs = rsqrtf(var + g.ln_eps);
+          if (m >= g.M) continue;
+          const float4 d = vv[hf][ps];
+          float4 o;
+          o.x = d.x * rs * gm.x + bt.x; o.y = d.y * rs * gm.y + bt.y;
+          o.z = d.z * rs * gm.z + bt.z; o.w = d.w * rs * gm.w + bt.w;
+          *reinterpret_cast<float4*>(g.Y + m * g.ldc + n) = o;
+          if (g.Y16) xf_st4<true>(g.Y16, m * g.ldc + n, o);
+          if (wc == 0 && li == 0) {
+            g.ln_mean[m] = mean[hf][ps];
+            g.ln_rstd[m] = rs;
+          }
+        }
+    }
+    return;
+  }
   if (do_bias) {  // combine the threads that share an operand row group (4 rows fp32, 8 rows bf16), fixed order
     constexpr int RQ = a16 ? 8 : 4, RG = BM / RQ, G = 256 / RG;
     float4* red = reinterpret_cast<float4*>(smem);
@@ -526,6 +638,7 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   // are co-resident, not by the matrix core. Many small workgroups win -- 64x64 tiles with
   // 64-deep slices for the forward / dX GEMMs (64x128 once N >= 256), 128-deep slices only for the split-K dW GEMMs.
   int bm = 64, bn = (g.N >= 256 && EPI != EPI_GELU_GRAD) ? 128 : 64;
+  if (EPI == EPI_DROP_RES_LN) bn = 128;  // whole rows (N == 128, checked by the caller)
   if (EPI == EPI_SPLITK && g.M > 64 && g.N > 64) {
     // 128 x 64: twice the workgroups of 128 x 128 at half the LDS and registers each -- the split-K GEMMs are a
     // latency chain of a dozen K slices per workgroup and want co-resident workgroups (measured +1.4 ... 2 % of the
@@ -539,7 +652,7 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
     if (dw.bm) { bm = dw.bm; bn = dw.bn; }
   }
   const TileOverride ov = tile_override();
-  if (ov.bm) { bm = ov.bm; bn = ov.bn; }
+  if (ov.bm && EPI != EPI_DROP_RES_LN) { bm = ov.bm; bn = ov.bn; }
   dim3 block(256);
   static const int pad_lds = [] { const char* e = getenv("XFMR_GEMM_PAD_LDS"); return e ? atoi(e) : 0; }();
   GemmArgs ga = g;
@@ -643,6 +756,23 @@ int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, 
     default:
       return XFMR_EINVAL;
   }
+}
+
+int xf_linear_ln_fwd_ex(const void* x, const float* w, const float* bias, float* pre, int64_t M, int32_t N, int32_t K,
+                        const float* residual, float dropout_p, uint64_t seed, uint32_t site, const float* gamma,
+                        const float* beta, float eps, float* y, void* y16, float* mean, float* rstd, int32_t precision,
+                        uint32_t s16, hipStream_t st) {
+  if (!x || !w || !pre || !residual || !gamma || !beta || !y || !mean || !rstd || M <= 0 || K <= 0)
+    return XFMR_EINVAL;
+  if (N != 128 || (K & 7)) return XFMR_EUNSUPPORTED;  // the tile spans one whole 128-column row
+  if (precision != XFMR_PREC_BF16) return XFMR_EUNSUPPORTED;
+  if (!xf_aligned16(x) || !xf_aligned16(w) || !xf_aligned16(pre) || !xf_aligned16(y)) return XFMR_EALIGN;
+  GemmArgs g{};
+  g.A = x; g.B = w; g.C = pre; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K; g.k_chunk = 0;
+  g.bias = bias; g.R = residual; g.s16 = s16 & (XF_S16_A | XF_S16_B);
+  g.drop = xf_make_dropout(dropout_p, seed, site);
+  g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps; g.Y = y; g.Y16 = y16; g.ln_mean = mean; g.ln_rstd = rstd;
+  return dispatch_gemm<false, false, EPI_DROP_RES_LN, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, 1, precision, st);
 }
 
 int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,

@@ -49,6 +49,12 @@ int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, c
 // d_lin (optional): the gradient of the Linear output feeding this LayerNorm (dropout-scaled dx), bf16 if lin16
 // d_gamma == d_beta == d_bias == nullptr defers the reduction of `partials` ([blocks][3][H], blocks returned in
 // *blocks_out) to the caller (xf_multi_rowsum)
+// Linear (+ bias, dropout, residual) with the LayerNorm that follows it applied in the GEMM epilogue (N == 128, bf16
+// policy): pre = the LayerNorm input (saved for the backward), y / y16 = the output, mean / rstd per row.
+int xf_linear_ln_fwd_ex(const void* x, const float* w, const float* bias, float* pre, int64_t M, int32_t N, int32_t K,
+                        const float* residual, float dropout_p, uint64_t seed, uint32_t site, const float* gamma,
+                        const float* beta, float eps, float* y, void* y16, float* mean, float* rstd, int32_t precision,
+                        uint32_t s16, hipStream_t st);
 // LayerNorm forward variants that also write a bf16 copy of the output (the operand of the GEMMs that consume it;
 // the fp32 output stays the residual stream). y16 / out16 may be null.
 int xf_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, float* y, void* y16, float* mean,
