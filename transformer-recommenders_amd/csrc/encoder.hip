@@ -135,8 +135,13 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
     r.wqkv = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)(3 * H), (int32_t)H) / sizeof(float));
     r.b1 = take(256 * I);      // <= 256 splits (dw_split_plan)
     r.bqkv = take(256 * 3 * H);
-    r.ln2 = take(xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float));
-    r.ln1 = take(xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float));
+    // LayerNorm partial records [blocks][3][H]: from the LayerNorm backward kernel, or one per 64-row tile from
+    // the dX GEMM that applies the LayerNorm backward in its epilogue
+    size_t lnrec = xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float);
+    const size_t lnrec_fused = ((T + 63) / 64) * 3 * H;
+    if (lnrec_fused > lnrec) lnrec = lnrec_fused;
+    r.ln2 = take(lnrec);
+    r.ln1 = take(lnrec);
     if (i == layer && rb) *rb = r;
   }
   for (int i = 0; i < c->layers; ++i) {
@@ -254,7 +259,7 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     XF_LAUNCH_CHECK();
   }
   const uint32_t sB = mix ? XF_S16_B : 0;
-  static const bool no_fuse = [] { const char* e = getenv("XFMR_LN_UNFUSED"); return e && *e && *e != '0'; }();
+  const bool no_fuse = [] { const char* e = getenv("XFMR_LN_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
   // out-proj / FFN2 GEMM + LayerNorm as one kernel: its 64 x 128 tiles are T / 64 workgroups -- below one per CU
   // (T < 16 384) the two-kernel form with 64 x 64 tiles is faster (batch 32: -1.5 % fused; batch 128: +0.9 %; 512: +1.8 %)
   const bool fuse_ln = mix && H == 128 && T >= 16384 && !no_fuse;
@@ -327,6 +332,12 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     segs[nseg++] = XfReduceSeg{src, dst, rows, (int)cols, (int)ld, 0};
   };
   if (cfg->layers > 64) return XFMR_EUNSUPPORTED;
+  // LayerNorm backward in the epilogue of the dX GEMM that produces its input gradient (whole-row 64 x 128 tiles: same
+  // conditions as the forward fusion): LN1 with the FFN1 dX GEMM of its layer, LN2 of layer i-1 with the QKV dX GEMM of
+  // layer i. The top layer's LN2 and the embedding LayerNorm keep their own launches.
+  const bool no_fuse = [] { const char* e = getenv("XFMR_LN_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
+  const bool fuse_lnb = mix && H == 128 && T >= 16384 && !no_fuse;
+  bool ln2_done = false;  // layer i's LN2 backward already ran inside layer i+1's QKV dX GEMM
   for (int i = cfg->layers - 1; i >= 0; --i) {
     LayerActs l;
     RedBufs r;
@@ -341,12 +352,14 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     int blocks = 0, splits = 0;
     // LayerNorm 2 -> dA = d(pre2); d_lin = gradient of the FFN output Linear (dropout-scaled copy of it)
     const bool lin_copy = hdrop || mix;  // without dropout and with fp32 storage d_lin IS dx
-    XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, lin_copy ? a.dLin : nullptr, mix,
-                                 nullptr, nullptr, nullptr, T, H, off,
-                                 xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_ffn(i)), r.ln2, st, &blocks));
-    seg(r.ln2, grads + p.ln2g, blocks, H, 3 * H);
-    seg(r.ln2 + H, grads + p.ln2b, blocks, H, 3 * H);
-    seg(r.ln2 + 2 * H, grads + p.b2, blocks, H, 3 * H);
+    if (!ln2_done) {
+      XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, lin_copy ? a.dLin : nullptr,
+                                   mix, nullptr, nullptr, nullptr, T, H, off,
+                                   xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_ffn(i)), r.ln2, st, &blocks));
+      seg(r.ln2, grads + p.ln2g, blocks, H, 3 * H);
+      seg(r.ln2 + H, grads + p.ln2b, blocks, H, 3 * H);
+      seg(r.ln2 + 2 * H, grads + p.b2, blocks, H, 3 * H);
+    }
     const void* dlin = lin_copy ? a.dLin : (const void*)a.dA;
     XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, st));
     seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
@@ -354,11 +367,17 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     XF_TRY(xf_linear_bwd_dw_deferred(a.dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, st));  // + b1 partial rows
     seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
     seg(r.b1, grads + p.b1, splits, I, I);
-    XF_TRY(xf_linear_bwd_dx_ex(a.dI, W(p.w1), a.dA, T, I, H, a.dA, nullptr, prec, sA | sB, st));  // += d(pre2)
-    // LayerNorm 1 -> dX = d(pre1)
-    XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, lin_copy ? a.dLin : nullptr, mix,
-                                 nullptr, nullptr, nullptr, T, H, off,
-                                 xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_out(i)), r.ln1, st, &blocks));
+    if (fuse_lnb) {  // dX of FFN1 (+= d(pre2)) and LayerNorm 1 backward in one kernel -> dX = d(pre1), dLin
+      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(a.dI, W(p.w1), T, I, H, a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g,
+                                       cfg->hidden_dropout, cfg->seed, site_out(i), dX, a.dLin, r.ln1, &blocks, prec,
+                                       sA | sB, st));
+    } else {
+      XF_TRY(xf_linear_bwd_dx_ex(a.dI, W(p.w1), a.dA, T, I, H, a.dA, nullptr, prec, sA | sB, st));  // += d(pre2)
+      // LayerNorm 1 -> dX = d(pre1)
+      XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, lin_copy ? a.dLin : nullptr,
+                                   mix, nullptr, nullptr, nullptr, T, H, off,
+                                   xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_out(i)), r.ln1, st, &blocks));
+    }
     seg(r.ln1, grads + p.ln1g, blocks, H, 3 * H);
     seg(r.ln1 + H, grads + p.ln1b, blocks, H, 3 * H);
     seg(r.ln1 + 2 * H, grads + p.bo, blocks, H, 3 * H);
@@ -371,7 +390,21 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     XF_TRY(xf_linear_bwd_dw_deferred(a.dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, st));
     seg(r.wqkv, grads + p.wqkv, splits, (int64_t)3 * H * H, (int64_t)3 * H * H);
     seg(r.bqkv, grads + p.bqkv, splits, 3 * H, 3 * H);
-    XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, W(p.wqkv), dX, T, 3 * H, H, dX, nullptr, prec, sA | sB, st));  // += d(pre1)
+    ln2_done = false;
+    if (fuse_lnb && i > 0) {  // dX of QKV (+= d(pre1)) and layer i-1's LayerNorm 2 backward -> dA = d(pre2), dLin
+      RedBufs rp;
+      carve(cfg, base, i - 1, &prev, &rp);
+      const LayerParams pp = layer_params(cfg, i - 1);
+      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(a.dQKV, W(p.wqkv), T, 3 * H, H, dX, prev.pre2, prev.mean2, prev.rstd2,
+                                       params + pp.ln2g, cfg->hidden_dropout, cfg->seed, site_ffn(i - 1), a.dA, a.dLin,
+                                       rp.ln2, &blocks, prec, sA | sB, st));
+      seg(rp.ln2, grads + pp.ln2g, blocks, H, 3 * H);
+      seg(rp.ln2 + H, grads + pp.ln2b, blocks, H, 3 * H);
+      seg(rp.ln2 + 2 * H, grads + pp.b2, blocks, H, 3 * H);
+      ln2_done = true;
+    } else {
+      XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, W(p.wqkv), dX, T, 3 * H, H, dX, nullptr, prec, sA | sB, st));  // += d(pre1)
+    }
   }
   ParamLayout pl;
   layer_base(cfg, 0, &pl);

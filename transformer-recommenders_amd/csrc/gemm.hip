@@ -17,7 +17,11 @@ namespace {
 // EPI_DROP_RES_LN: EPI_DROP_RES whose tile spans whole output rows (BN == N): the LayerNorm that follows the Linear
 // (TF:modeling_bert.py:292,349) is applied in the epilogue -- C = pre-LayerNorm sum (the backward needs it), Y / Y16 =
 // the normalised output (fp32 residual stream + bf16 GEMM operand), mean / rstd per row.
-enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DROP_RES = 2, EPI_GELU_GRAD = 3, EPI_SPLITK = 4, EPI_DROP_RES_LN = 5 };
+// EPI_DX_LNBWD: a dX GEMM (+ residual gradient) whose output rows are the gradient of a LayerNorm OUTPUT: the LayerNorm
+// backward runs in the epilogue -- C = gradient of the LayerNorm input, D16 = its dropout-scaled bf16 copy (the
+// gradient of the Linear that fed the LayerNorm), one partial record [3][128] (d gamma, d beta, d bias) per workgroup.
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DROP_RES = 2, EPI_GELU_GRAD = 3, EPI_SPLITK = 4, EPI_DROP_RES_LN = 5,
+       EPI_DX_LNBWD = 6 };
 
 struct GemmArgs {
   const void* A; const void* B; void* C;  // fp32, or bf16 where the storage mask says so
@@ -36,6 +40,9 @@ struct GemmArgs {
   // EPI_DROP_RES_LN
   const float* ln_gamma; const float* ln_beta; float ln_eps;
   float* Y; void* Y16; float* ln_mean; float* ln_rstd;
+  // EPI_DX_LNBWD (ln_gamma as above; `drop` = the dropout of the Linear that fed the LayerNorm)
+  const float* lnb_x; const float* lnb_mean; const float* lnb_rstd;  // saved LayerNorm input and statistics
+  void* D16; float* lnb_partials;
 };
 
 // One operand tile (ROWS x BK, fp32 in memory) in flight in registers, then committed to an LDS image of the
@@ -241,7 +248,10 @@ __device__ __forceinline__ TileIdx tile_of(const int nt_n, const int nt_m, const
 // S = XF_S16_* storage mask (compile time: a runtime switch between the fp32 and bf16 load paths cost the
 // forward / dX GEMMs 15-80 %).
 template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+// (The two LayerNorm-fused epilogues are held to <= 170 registers: with the default bound hipcc parked their row
+//  values in AGPRs across the workgroup barriers and single rows came out slightly wrong in ~40 % of the launches --
+//  not reproducible once no AGPR copies are involved; tests/test_gpu_fullsize.py checks run-to-run bit equality.)
+__global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? 3 : 1) void gemm_kernel(GemmArgs g) {
   using elem = typename P::elem;
   using TileA = OperandTile<P, BM, BK, TA>;
   using TileB = OperandTile<P, BN, BK, TB>;
@@ -420,6 +430,114 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             g.ln_rstd[m] = rs;
           }
         }
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_DX_LNBWD) {
+    if constexpr (BM == 64 && BN == 128) {
+      // Same lane map as EPI_DROP_RES_LN: lane -> (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3). A half strip
+      // (16 rows) at a time: the two row sums of the LayerNorm backward are exchanged with the partner wave per half.
+      constexpr int LPRL = 16, RPPL = 4, NPL = 4;
+      float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
+      float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 hf][2 wr][2 wc][16 rows][2]
+      float* const colred = red + 2 * 2 * 2 * 16 * 2;                       // [2 wr][3][128]
+      const int prow = lane / LPRL, li = lane % LPRL, c0 = li * 4;
+      const int n = wc * WN + c0;
+      const float4 gam = *reinterpret_cast<const float4*>(g.ln_gamma + n);
+      float4 dgam = make_float4(0, 0, 0, 0), dbet = dgam, dbias = dgam;
+      auto row_reduce = [&](float x) {
+        x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+        return x;
+      };
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int64_t mb = m0 + wr * WM + 16 * hf;
+        float4 aux[NPL], xv[NPL];
+        float mu[NPL], rs[NPL];
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          aux[ps] = xv[ps] = make_float4(0, 0, 0, 0);
+          mu[ps] = rs[ps] = 0.f;
+          const int64_t m = mb + prow + RPPL * ps;
+          if (m < g.M) {
+            if (g.R) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * g.ldc + n);
+            xv[ps] = *reinterpret_cast<const float4*>(g.lnb_x + m * g.ldc + n);
+            mu[ps] = g.lnb_mean[m];
+            rs[ps] = g.lnb_rstd[m];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[0][j][8 * hf + r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float4 gv[NPL], xh[NPL];
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          const int row = prow + RPPL * ps;
+          const int64_t m = mb + row;
+          float4 dy = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
+          dy.x += aux[ps].x; dy.y += aux[ps].y; dy.z += aux[ps].z; dy.w += aux[ps].w;
+          if (m >= g.M) dy = make_float4(0, 0, 0, 0);
+          float4 h;
+          h.x = (xv[ps].x - mu[ps]) * rs[ps]; h.y = (xv[ps].y - mu[ps]) * rs[ps];
+          h.z = (xv[ps].z - mu[ps]) * rs[ps]; h.w = (xv[ps].w - mu[ps]) * rs[ps];
+          dgam.x += dy.x * h.x; dgam.y += dy.y * h.y; dgam.z += dy.z * h.z; dgam.w += dy.w * h.w;
+          dbet.x += dy.x; dbet.y += dy.y; dbet.z += dy.z; dbet.w += dy.w;
+          float4 gg;
+          gg.x = dy.x * gam.x; gg.y = dy.y * gam.y; gg.z = dy.z * gam.z; gg.w = dy.w * gam.w;
+          gv[ps] = gg; xh[ps] = h;
+          const float s1 = row_reduce((gg.x + gg.y) + (gg.z + gg.w));
+          const float s2 = row_reduce((gg.x * h.x + gg.y * h.y) + (gg.z * h.z + gg.w * h.w));
+          if (li == 0) {
+            float* rp = red + ((((hf * 2 + wr) * 2 + wc) * 16) + row) * 2;
+            rp[0] = s1; rp[1] = s2;
+          }
+        }
+        __syncthreads();  // (also: the scratch strip may be overwritten by the next half)
+#pragma unroll
+        for (int ps = 0; ps < NPL; ++ps) {
+          const int row = prow + RPPL * ps;
+          const int64_t m = mb + row;
+          const float* r0 = red + ((((hf * 2 + wr) * 2 + 0) * 16) + row) * 2;
+          const float* r1 = red + ((((hf * 2 + wr) * 2 + 1) * 16) + row) * 2;
+          const float mg = (r0[0] + r1[0]) * (1.f / 128.f), mgx = (r0[1] + r1[1]) * (1.f / 128.f);
+          if (m >= g.M) continue;
+          const float4 gg = gv[ps], h = xh[ps];
+          float4 d;
+          d.x = rs[ps] * (gg.x - mg - h.x * mgx); d.y = rs[ps] * (gg.y - mg - h.y * mgx);
+          d.z = rs[ps] * (gg.z - mg - h.z * mgx); d.w = rs[ps] * (gg.w - mg - h.w * mgx);
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = d;
+          float4 dl = d;
+          if (g.drop.on) {
+            const uint32_t e = (uint32_t)(m * g.N + n);
+            dl.x *= xf_keep_scale(g.drop, e); dl.y *= xf_keep_scale(g.drop, e + 1);
+            dl.z *= xf_keep_scale(g.drop, e + 2); dl.w *= xf_keep_scale(g.drop, e + 3);
+          }
+          if (g.D16) xf_st4<true>(g.D16, m * g.ldc + n, dl);
+          dbias.x += dl.x; dbias.y += dl.y; dbias.z += dl.z; dbias.w += dl.w;
+        }
+      }
+      // column sums of the workgroup's 64 rows: the 4 row groups of the wave (lanes with equal li), then the two
+      // waves that share the columns (wr = 0, 1), fixed order
+      auto fold = [&](float4& v) {
+#pragma unroll
+        for (int o = LPRL; o < 64; o <<= 1) {
+          v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+          v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+        }
+      };
+      fold(dgam); fold(dbet); fold(dbias);
+      if (prow == 0) {
+        *reinterpret_cast<float4*>(&colred[(wr * 3 + 0) * 128 + n]) = dgam;
+        *reinterpret_cast<float4*>(&colred[(wr * 3 + 1) * 128 + n]) = dbet;
+        *reinterpret_cast<float4*>(&colred[(wr * 3 + 2) * 128 + n]) = dbias;
+      }
+      __syncthreads();
+      for (int o = threadIdx.x; o < 3 * 128; o += 256)
+        g.lnb_partials[(int64_t)tix.m * 3 * 128 + o] = colred[o] + colred[3 * 128 + o];
     }
     return;
   }
@@ -638,7 +756,7 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   // are co-resident, not by the matrix core. Many small workgroups win -- 64x64 tiles with
   // 64-deep slices for the forward / dX GEMMs (64x128 once N >= 256), 128-deep slices only for the split-K dW GEMMs.
   int bm = 64, bn = (g.N >= 256 && EPI != EPI_GELU_GRAD) ? 128 : 64;
-  if (EPI == EPI_DROP_RES_LN) bn = 128;  // whole rows (N == 128, checked by the caller)
+  if (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) bn = 128;  // whole rows (N == 128, checked by the caller)
   if (EPI == EPI_SPLITK && g.M > 64 && g.N > 64) {
     // 128 x 64: twice the workgroups of 128 x 128 at half the LDS and registers each -- the split-K GEMMs are a
     // latency chain of a dozen K slices per workgroup and want co-resident workgroups (measured +1.4 ... 2 % of the
@@ -652,7 +770,7 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
     if (dw.bm) { bm = dw.bm; bn = dw.bn; }
   }
   const TileOverride ov = tile_override();
-  if (ov.bm && EPI != EPI_DROP_RES_LN) { bm = ov.bm; bn = ov.bn; }
+  if (ov.bm && EPI != EPI_DROP_RES_LN && EPI != EPI_DX_LNBWD) { bm = ov.bm; bn = ov.bn; }
   dim3 block(256);
   static const int pad_lds = [] { const char* e = getenv("XFMR_GEMM_PAD_LDS"); return e ? atoi(e) : 0; }();
   GemmArgs ga = g;
@@ -802,6 +920,26 @@ int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int
                          (XF_S16_A | XF_S16_B | XF_S16_C | XF_S16_P)>(g, 1, precision, st);
   return dispatch_gemm<false, true, EPI_STORE, XF_S16_A, (XF_S16_A | XF_S16_C), (XF_S16_A | XF_S16_B),
                        (XF_S16_A | XF_S16_B | XF_S16_C)>(g, 1, precision, st);
+}
+
+int xf_linear_bwd_dx_lnbwd_ex(const void* dy, const float* w, int64_t M, int32_t N, int32_t K,
+                              const float* residual_grad, const float* ln_x, const float* ln_mean, const float* ln_rstd,
+                              const float* ln_gamma, float dropout_p, uint64_t seed, uint32_t site, float* dx,
+                              void* d_lin16, float* partials, int* blocks_out, int32_t precision, uint32_t s16,
+                              hipStream_t st) {
+  if (!dy || !w || !dx || !ln_x || !ln_mean || !ln_rstd || !ln_gamma || !partials || !blocks_out || M <= 0 || N <= 0)
+    return XFMR_EINVAL;
+  if (K != 128 || (N & 7)) return XFMR_EUNSUPPORTED;  // output rows = whole 128-wide LayerNorm rows
+  if (precision != XFMR_PREC_BF16) return XFMR_EUNSUPPORTED;
+  if (!xf_aligned16(dy) || !xf_aligned16(w) || !xf_aligned16(dx) || !xf_aligned16(ln_x)) return XFMR_EALIGN;
+  GemmArgs g{};
+  g.A = dy; g.B = w; g.C = dx; g.lda = N; g.ldb = K; g.ldc = K; g.M = M; g.N = K; g.K = N; g.k_chunk = 0;
+  g.R = residual_grad; g.s16 = s16 & (XF_S16_A | XF_S16_B);
+  g.drop = xf_make_dropout(dropout_p, seed, site);
+  g.ln_gamma = ln_gamma; g.lnb_x = ln_x; g.lnb_mean = ln_mean; g.lnb_rstd = ln_rstd; g.D16 = d_lin16;
+  g.lnb_partials = partials;
+  *blocks_out = (int)((M + 63) / 64);
+  return dispatch_gemm<false, true, EPI_DX_LNBWD, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, 1, precision, st);
 }
 
 int xfmr_linear_bwd_dx(const float* dy, const float* w, float* dx, int64_t M, int32_t N, int32_t K,
