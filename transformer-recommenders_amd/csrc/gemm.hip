@@ -721,20 +721,23 @@ __global__ __launch_bounds__(256) void multi_rowsum_kernel(MultiSegs m) {
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + c;
   if (blockIdx.x * 64 >= sg.cols) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // 16 loads in flight per thread: the LayerNorm partial records of the fused dX GEMMs are 1600 rows of 128 columns
+  // (T / 64 workgroups) -- with 4 in flight such a segment was a 100-iteration latency chain and set the kernel's time
+  float s[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) s[u] = 0.f;
   if (col < sg.cols) {
     const float* src = sg.src + col;
     const int64_t ld = sg.ld;
     int r = rg;
-    for (; r + 12 < sg.rows; r += 16) {
-      s0 += src[r * ld];
-      s1 += src[(r + 4) * ld];
-      s2 += src[(r + 8) * ld];
-      s3 += src[(r + 12) * ld];
+    for (; r + 60 < sg.rows; r += 64) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s[u] += src[(r + 4 * u) * ld];
     }
-    for (; r < sg.rows; r += 4) s0 += src[r * ld];
+    for (; r < sg.rows; r += 4) s[0] += src[r * ld];
   }
-  red[rg][c] = (s0 + s1) + (s2 + s3);
+  red[rg][c] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) +
+               (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
   __syncthreads();
   if (rg == 0 && col < sg.cols) sg.dst[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
