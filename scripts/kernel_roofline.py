@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-kernel achieved rates of the default bench line (config 2, batch 512) from a rocprofv3 kernel_stats CSV.
+
+    python scripts/kernel_roofline.py profiles/r01_kernel_stats.csv > profiles/r01_kernel_roofline.md
+
+Algorithmic bytes = the tensors a launch must read and write once (DESIGN.md section 3 says which are bf16);
+re-reads that hit L2 / Infinity Cache are not counted. HBM peak 8 TB/s nominal (MI355X_MICROARCH.md); a plain
+streaming kernel on tensors of these sizes measures 5-6.6 TB/s (scripts/bw_probe.py, scripts/probe/tile_copy.hip).
+MFMA peak 2.5 PFLOP/s dense bf16.
+"""
+import csv
+import sys
+
+B, L, H, I, A, NL, ND = 512, 200, 128, 512, 4, 4, 3883
+T = B * L
+MB = 1e6
+f32, b16 = 4, 2
+TH, TI, T3H = T * H, T * I, T * 3 * H
+
+# kernel-name fragment -> (description, algorithmic bytes per launch (average over the launches that share the name), flops)
+K = [
+    ("gemm_kernel<PrecBF16, 64, 128, 64, false, false, 0,", "QKV Linear fwd", TH * b16 + T3H * b16, 2 * T * 3 * H * H),
+    ("gemm_kernel<PrecBF16, 64, 128, 64, false, false, 1,", "FFN1 Linear fwd + GELU (+ gelu')", TH * b16 + 2 * TI * b16, 2 * T * I * H),
+    ("gemm_kernel<PrecBF16, 64, 128, 64, false, false, 5,", "out-proj / FFN2 Linear fwd + dropout + residual + LayerNorm (avg)",
+     ((TH * b16 + TH * f32 * 3 + TH * b16) + (TI * b16 + TH * f32 * 3 + TH * b16)) / 2, (2 * T * H * H + 2 * T * H * I) / 2),
+    ("gemm_kernel<PrecBF16, 64, 128, 64, false, true, 6,", "FFN1 / QKV dX + residual grad + LayerNorm bwd (avg)",
+     ((TI * b16 + TH * f32 * 3 + TH * b16) + (T3H * b16 + TH * f32 * 3 + TH * b16)) / 2, (2 * T * H * I + 2 * T * H * 3 * H) / 2),
+    ("gemm_kernel<PrecBF16, 64, 64, 64, false, true, 3,", "FFN2 dX x gelu'", TH * b16 + 2 * TI * b16, 2 * T * I * H),
+    ("gemm_kernel<PrecBF16, 64, 64, 64, false, true, 0, 7u", "out-proj dX", 2 * TH * b16, 2 * T * H * H),
+    ("gemm_kernel<PrecBF16, 64, 64, 64, false, true, 0, 3u", "QKV dX + residual grad (layer 0)", T3H * b16 + 2 * TH * f32, 2 * T * H * 3 * H),
+    ("gemm_kernel<PrecBF16, 128, 64, 128, true, true, 4,", "dW split-K (avg of the 4 weights; operands only, + 14 MB of slabs)",
+     ((TH + TI) * b16 * 2 + (TH + TH) * b16 + (T3H + TH) * b16) / 4, (2 * 2 * T * H * I + 2 * T * H * H + 2 * T * 3 * H * H) / 4),
+    ("attn_fwd_seq_bf16_kernel", "attention fwd (per layer)", T3H * b16 + TH * b16 + B * A * L * f32, 4 * B * A * L * (L + 1) / 2 * 32),
+    ("attn_bwd_fused_bf16_kernel", "attention bwd (per layer)", 2 * T3H * b16 + 2 * TH * b16, 10 * B * A * L * (L + 1) / 2 * 32),
+    ("ln_bwd_v4_kernel", "LayerNorm bwd (top layer / embedding)", TH * f32 * 3 + TH * b16 / 2, 0),
+    ("ln_fwd_v4_kernel<32, true>", "embedding gather + LayerNorm", TH * f32 * 3 + TH * b16, 0),
+    ("loss_main_dma_kernel<128, 7>", "loss gradient pass", 0, 4.0 * T * ND * H),
+    ("loss_main_dma_kernel<128, -2>", "loss logging pass (6 heads + statistics)", 0, 2.0 * T * ND * H),
+    ("loss_combine_kernel", "loss combine", 2 * TH * f32 + TH * f32 + TH * f32, 0),
+    ("multi_rowsum_kernel", "split-K slab / partial-record reduction", 0, 0),
+    ("scale_kernel", "d_tok *= upstream gradient", 2 * TH * f32, 0),
+]
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+print("| kernel | launches/step | avg µs | algorithmic MB | TB/s (of 8 nominal; 5–6.6 measured stream) | TFLOP/s (of 2500) |")
+print("|---|---|---|---|---|---|")
+steps = 13
+for frag, desc, nbytes, flops in K:
+    hit = [r for r in rows if frag in r["Name"]]
+    if not hit:
+        continue
+    calls = sum(int(r["Calls"]) for r in hit)
+    tot = sum(float(r["TotalDurationNs"]) for r in hit)
+    avg = tot / calls / 1e3
+    tb = f"{nbytes / (avg * 1e-6) / 1e12:.2f}" if nbytes else "—"
+    tf = f"{flops / (avg * 1e-6) / 1e12:.0f}" if flops else "—"
+    print(f"| {desc} (`{frag.strip(', ')}`) | {calls / steps:.1f} | {avg:.1f} | {nbytes / MB:.0f} | {tb} | {tf} |")
