@@ -126,7 +126,11 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   a.scratch = base ? base + o : nullptr;
   a.scratch_bytes = sc;
   o += up256(sc);
-  a.emb_ln = take(xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float));
+  {
+    size_t rec = xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float);
+    const size_t rec_fused = ((T + 63) / 64) * 3 * H;  // one record per 64-row tile of the fused dX GEMM
+    a.emb_ln = take(rec_fused > rec ? rec_fused : rec);
+  }
   for (int i = 0; i < c->layers; ++i) {
     RedBufs r;
     r.w2 = take(xf_linear_bwd_dw_slab_bytes((int64_t)T, (int32_t)H, (int32_t)I) / sizeof(float));
@@ -338,6 +342,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   const bool no_fuse = [] { const char* e = getenv("XFMR_LN_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
   const bool fuse_lnb = mix && H == 128 && T >= 16384 && !no_fuse;
   bool ln2_done = false;  // layer i's LN2 backward already ran inside layer i+1's QKV dX GEMM
+  bool emb_ln_done = false;  // ... and the embedding LayerNorm's inside layer 0's
   for (int i = cfg->layers - 1; i >= 0; --i) {
     LayerActs l;
     RedBufs r;
@@ -402,13 +407,22 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       seg(rp.ln2 + H, grads + pp.ln2b, blocks, H, 3 * H);
       seg(rp.ln2 + 2 * H, grads + pp.b2, blocks, H, 3 * H);
       ln2_done = true;
+    } else if (fuse_lnb) {  // layer 0: dX of QKV (+= d(pre1)) and the EMBEDDING LayerNorm backward -> dA
+      ParamLayout pe;
+      layer_base(cfg, 0, &pe);
+      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(a.dQKV, W(p.wqkv), T, 3 * H, H, dX, a.emb_pre, a.emb_mean, a.emb_rstd,
+                                       params + pe.eg, 0.f, cfg->seed, 0, a.dA, nullptr, a.emb_ln, &blocks, prec,
+                                       sA | sB, st, cfg->hidden_dropout, SITE_EMB));
+      seg(a.emb_ln, grads + pe.eg, blocks, H, 3 * H);
+      seg(a.emb_ln + H, grads + pe.eb, blocks, H, 3 * H);
+      emb_ln_done = true;
     } else {
       XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, W(p.wqkv), dX, T, 3 * H, H, dX, nullptr, prec, sA | sB, st));  // += d(pre1)
     }
   }
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
-  {
+  if (!emb_ln_done) {
     int blocks = 0;
     XF_TRY(xf_layernorm_bwd_impl(dX, a.emb_pre, a.emb_mean, a.emb_rstd, params + pl.eg, a.dA, nullptr, false, nullptr,
                                  nullptr, nullptr, T, H, xf_make_dropout(cfg->hidden_dropout, cfg->seed, SITE_EMB), off,

@@ -43,6 +43,7 @@ struct GemmArgs {
   // EPI_DX_LNBWD (ln_gamma as above; `drop` = the dropout of the Linear that fed the LayerNorm)
   const float* lnb_x; const float* lnb_mean; const float* lnb_rstd;  // saved LayerNorm input and statistics
   void* D16; float* lnb_partials;
+  XfDropout drop2;  // EPI_DX_LNBWD: dropout that was applied to the LayerNorm OUTPUT (embedding site); off otherwise
 };
 
 // One operand tile (ROWS x BK, fp32 in memory) in flight in registers, then committed to an LDS image of the
@@ -480,6 +481,11 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
           const int64_t m = mb + row;
           float4 dy = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
           dy.x += aux[ps].x; dy.y += aux[ps].y; dy.z += aux[ps].z; dy.w += aux[ps].w;
+          if (g.drop2.on) {
+            const uint32_t e = (uint32_t)(m * g.N + n);
+            dy.x *= xf_keep_scale(g.drop2, e); dy.y *= xf_keep_scale(g.drop2, e + 1);
+            dy.z *= xf_keep_scale(g.drop2, e + 2); dy.w *= xf_keep_scale(g.drop2, e + 3);
+          }
           if (m >= g.M) dy = make_float4(0, 0, 0, 0);
           float4 h;
           h.x = (xv[ps].x - mu[ps]) * rs[ps]; h.y = (xv[ps].y - mu[ps]) * rs[ps];
@@ -929,7 +935,7 @@ int xf_linear_bwd_dx_lnbwd_ex(const void* dy, const float* w, int64_t M, int32_t
                               const float* residual_grad, const float* ln_x, const float* ln_mean, const float* ln_rstd,
                               const float* ln_gamma, float dropout_p, uint64_t seed, uint32_t site, float* dx,
                               void* d_lin16, float* partials, int* blocks_out, int32_t precision, uint32_t s16,
-                              hipStream_t st) {
+                              hipStream_t st, float out_dropout_p, uint32_t out_site) {
   if (!dy || !w || !dx || !ln_x || !ln_mean || !ln_rstd || !ln_gamma || !partials || !blocks_out || M <= 0 || N <= 0)
     return XFMR_EINVAL;
   if (K != 128 || (N & 7)) return XFMR_EUNSUPPORTED;  // output rows = whole 128-wide LayerNorm rows
@@ -941,6 +947,7 @@ int xf_linear_bwd_dx_lnbwd_ex(const void* dy, const float* w, int64_t M, int32_t
   g.drop = xf_make_dropout(dropout_p, seed, site);
   g.ln_gamma = ln_gamma; g.lnb_x = ln_x; g.lnb_mean = ln_mean; g.lnb_rstd = ln_rstd; g.D16 = d_lin16;
   g.lnb_partials = partials;
+  g.drop2 = xf_make_dropout(out_dropout_p, seed, out_site);
   *blocks_out = (int)((M + 63) / 64);
   return dispatch_gemm<false, true, EPI_DX_LNBWD, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, 1, precision, st);
 }

@@ -58,11 +58,12 @@ int xf_linear_ln_fwd_ex(const void* x, const float* w, const float* bias, float*
 // dx_ln_in[M,128] = LayerNormBackward(dy[M,N] * w[N,128] + residual_grad) in one kernel (bf16 policy): the dX GEMM whose
 // output is the gradient of a LayerNorm output applies that LayerNorm's backward in its epilogue. d_lin16 (bf16,
 // optional) = the dropout-scaled copy; partials[*blocks_out][3][128] = d gamma / d beta / d bias partial records.
+// out_dropout_p / out_site: dropout that was applied to the LayerNorm OUTPUT (the embedding LayerNorm).
 int xf_linear_bwd_dx_lnbwd_ex(const void* dy, const float* w, int64_t M, int32_t N, int32_t K,
                               const float* residual_grad, const float* ln_x, const float* ln_mean, const float* ln_rstd,
                               const float* ln_gamma, float dropout_p, uint64_t seed, uint32_t site, float* dx,
                               void* d_lin16, float* partials, int* blocks_out, int32_t precision, uint32_t s16,
-                              hipStream_t st);
+                              hipStream_t st, float out_dropout_p = 0.f, uint32_t out_site = 0);
 // LayerNorm forward variants that also write a bf16 copy of the output (the operand of the GEMMs that consume it;
 // the fp32 output stays the residual stream). y16 / out16 may be null.
 int xf_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, float* y, void* y16, float* mean,
