@@ -205,3 +205,23 @@ def test_saved_directory_is_a_loadable_hf_bert_with_the_sentence_transformer_lay
     assert cfg2.pooling_mode == "max" and cfg2.is_normalized and cfg2.max_seq_length == L
     for k, v in params.items():
         assert torch.equal(state[k], v.detach()), k
+
+
+def test_bench_presets_name_the_baseline_configs(monkeypatch):
+    """bench.py's --preset flags reproduce the shapes of BASELINE.json's configs 2-5 (the default line is config 2)."""
+    import importlib
+    import sys
+
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.items, a.seq_len, a.hidden, a.layers, a.loss, a.batch, a.negatives) == (3883, 200, 128, 4, "InfoNCELoss", 512, "in_batch")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--preset", "config3"])
+    assert bench.parse().loss == "PairwiseLogisticLoss"
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--preset", "config4"])
+    a = bench.parse()
+    assert (a.items, a.hidden, a.layers, a.inter, a.negatives) == (27278, 256, 6, 1024, "catalogue")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--preset", "config5"])
+    a = bench.parse()
+    assert (a.items, a.seq_len, a.hidden, a.loss) == (1_000_000, 512, 256, "AlignmentContrastiveLoss")
+    assert bench.METRIC.startswith("user-sequences/sec")
