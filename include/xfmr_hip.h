@@ -23,8 +23,15 @@
  *   - item indices are int64 as the reference's batches carry them (xfmr_rec/data.py:534-540).
  *   - return value: 0 on success, a negative XFMR_E* code otherwise (never throws, never aborts).
  *     Asynchronous HIP errors surface at the caller's next synchronisation.
- *   - stateless and re-entrant: safe for one process per GPU and for several host threads on
- *     different streams.
+ *   - re-entrant: no device-side state survives a call, nothing is retained between calls; safe for one process
+ *     per GPU and for several host threads on different streams. Two qualifications, neither touching results:
+ *     (1) the measurement hook xfmr_sampled_loss_profile_* arms a one-shot, PER-HOST-THREAD event pair; (2) kernel
+ *     selection reads a few XFMR_* environment variables (tuning / A-B switches listed in DESIGN.md section 5; most
+ *     are read once per process, XFMR_LN_UNFUSED and XFMR_LOSS_NSPLIT per call) -- every setting computes the same
+ *     function to rounding, none is needed in production.
+ *   - the data-parallel gradient exchange (SURVEY.md section 8b lists an `allreduce_flat` op) is deliberately NOT an
+ *     entry point here: the flat gradient is one contiguous device buffer, and torch.distributed's all_reduce over
+ *     RCCL (xfmr_rec_amd/distributed.py) is the exchange -- there is no kernel of ours in it to export.
  */
 #ifndef XFMR_HIP_H
 #define XFMR_HIP_H
@@ -283,7 +290,7 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
                             float* losses, float* stats, float* d_query, void* workspace, size_t workspace_bytes, void* stream);
 /* Dense-candidate form: EmbedLoss.forward(query_embed (N,H), candidate_embed (N,C,H), target) exactly as the
  * reference declares it (xfmr_rec/losses.py:128-155), for candidate tensors that exist in memory (C <= 8192,
- * H <= 256, H % 4 == 0): dot / cosine logits (:179-208), target from target_position "first" / "diagonal" or an
+ * H <= 1024, H % 4 == 0): dot / cosine logits (:179-208), target from target_position "first" / "diagonal" or an
  * explicit `target` (N) of column indices (:211-261), false-negative mask (:263-293), top-k hard negatives
  * (:295-330, ties at the k-th logit share the remaining weight), the seven heads + LogitsStatistics, and
  * d_query (N,H) = dL(train_head)/dquery (may be NULL). Candidates are treated as constants (the reference's
@@ -294,10 +301,15 @@ size_t xfmr_dense_loss_workspace(int64_t N, int32_t C, int32_t H);
 int xfmr_dense_loss(const xfmr_loss_cfg* cfg, const float* query, const float* cand, const int64_t* target,
                     int32_t target_mode, int64_t N, int32_t C, int32_t H, float* losses, float* stats, float* d_query,
                     void* workspace, size_t workspace_bytes, void* stream);
-/* Measurement hook (bench.py): the next xfmr_sampled_loss[_lists] call made by THIS host thread records the two
- * hipEvent_t (passed as void*) on its stream immediately before and after the dominant kernel
- * (loss_main_kernel), then forgets them. Pass NULL, NULL to cancel. Has no effect on results. */
+/* Measurement hook (bench.py) -- the ONE piece of per-host-thread state in the library: the next
+ * xfmr_sampled_loss[_lists] call made by THIS host thread records the two hipEvent_t (passed as void*) on its stream
+ * immediately before and after one main-kernel launch, then forgets them. Pass NULL, NULL to cancel. No effect on
+ * results. _profile_next = _profile_pass(..., XFMR_PROFILE_GRADIENT_PASS): the gradient pass (or the call's only
+ * pass). XFMR_PROFILE_LOGGING_PASS: the values-only pass over all seven heads + statistics (trainer.py:250-264) of the
+ * next call that runs one (all_heads != 0 on the bf16 path); calls without one leave the request pending. */
+enum { XFMR_PROFILE_GRADIENT_PASS = 0, XFMR_PROFILE_LOGGING_PASS = 1 };
 int xfmr_sampled_loss_profile_next(void* start_event, void* stop_event);
+int xfmr_sampled_loss_profile_pass(void* start_event, void* stop_event, int32_t which);
 /* table_rnorm[r] = 1 / max(||table[r]||, 1e-8): per-item inverse norms for the cosine heads
  * (torch cosine_similarity, losses.py:206-208); computed once because the table is frozen. */
 int xfmr_table_rnorm(const float* table, float* table_rnorm, int64_t n_rows, int32_t H, void* stream);
@@ -336,7 +348,7 @@ int xfmr_seq_sample(const int64_t* items, const uint8_t* labels, const int64_t* 
  *   returned); exclude / exclude_offsets: CSR of item indices to leave out per query (NULL, NULL: none);
  *   metric XFMR_METRIC_* (index.py:47, default cosine); out_idx (n_query,k) item indices best first, -1 where fewer
  *   than k items remain; out_score = 1 - distance (index.py:248-251): cosine similarity, dot, or 1 - |q - e|^2.
- *   Ties are broken by the lower item index. k <= 1024, H <= 256.
+ *   Ties are broken by the lower item index. k <= 1024, H <= 1024.
  *   xfmr_retrieval_metrics: rec_idx (n_query,k) as above; targets / target_offsets: CSR of each query's positive
  *   item indices; out (n_query,7) = nDCG, MAP, AUROC, precision, recall, hit rate, MRR at top_k (XFMR_RM_*);
  *   valid[q] = 0 when the query has no target (the reference reports nothing for it, metrics.py:58-59).

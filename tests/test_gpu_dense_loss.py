@@ -79,13 +79,13 @@ def test_dense_logits_statistics_match_reference_goldens(L, g1):
             assert got[name] == pytest.approx(want[name], rel=2e-5, abs=2e-6), (key, name)
 
 
-@pytest.mark.parametrize("k", [1, 7, 50])
+@pytest.mark.parametrize("k,H", [(1, 64), (7, 64), (50, 64), (7, 384)])  # 384: the reference's default d_model
 @pytest.mark.parametrize("kind", OL.LOSS_KINDS)
-def test_dense_hard_negatives_with_duplicate_candidates_vs_oracle(L, kind, k):
+def test_dense_hard_negatives_with_duplicate_candidates_vs_oracle(L, kind, k, H):
     """Duplicated candidate rows put exact ties at the k-th logit: the selected multiset (and so the loss and the
     gradient) must not depend on which of the equal candidates a top-k picks."""
     g = torch.Generator().manual_seed(11)
-    N, C, H = 33, 300, 64
+    N, C = 33, 300
     base = torch.randn(N, 40, H, generator=g)
     pick = torch.randint(0, 40, (N, C), generator=g)
     cand = torch.gather(base, 1, pick[..., None].expand(-1, -1, H)).contiguous()

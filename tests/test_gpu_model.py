@@ -99,6 +99,52 @@ def test_encoder_config2_shape_vs_oracle(X, prec):
     assert enc.num_layers_of(params) == nL
 
 
+@pytest.mark.parametrize("prec,L,lengths", [("fp32", 200, [200, 131, 17]), ("bf16", 200, [200, 131, 17])])
+def test_encoder_config4_shape_vs_oracle(X, prec, L, lengths):
+    """BASELINE config 4's layer shape (L=200, H=256, 8 heads, I=1024; 2 of its 6 layers) on ragged rows against the
+    CPU oracle: every trainable tensor's gradient. These shapes take other code than config 2: no LayerNorm-fused GEMM
+    epilogues (H != 128), ln_*_v4_kernel<64 lanes per row>, 64x128 forward tiles for N = 768 / 1024, K = 1024 dX."""
+    _encoder_shape_vs_oracle(X, prec, B=3, L=L, H=256, A=8, I=1024, nL=2, V=300, lengths=lengths)
+
+
+@pytest.mark.parametrize("prec,L,lengths", [("bf16", 512, [512, 300, 5]), ("fp32", 256, [256, 131, 1])])
+def test_encoder_config5_shape_vs_oracle(X, prec, L, lengths):
+    """BASELINE config 5's layer shape (H=256, 8 heads, I=1024) at L=512 in bf16 (two-block attention forward and the
+    dQ + dK/dV backward pair: the fused one-workgroup forms stop at L=256) and at L=256 in the fp32 parity policy
+    (its attention keeps whole fp32 panels in LDS: L <= 256)."""
+    _encoder_shape_vs_oracle(X, prec, B=3, L=L, H=256, A=8, I=1024, nL=2, V=300, lengths=lengths)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_encoder_reference_default_shape_vs_oracle(X, prec):
+    """The reference's own default model (config.yaml:46-52 + models.py:80-91 with the all-MiniLM table): d_model 384,
+    12 heads, intermediate 48, 1 layer, max_seq_length 32. K = 48 takes the 32-deep K slices."""
+    _encoder_shape_vs_oracle(X, prec, B=5, L=32, H=384, A=12, I=48, nL=1, V=200, lengths=[32, 31, 17, 2, 1])
+
+
+def _encoder_shape_vs_oracle(X, prec, *, B, L, H, A, I, nL, V, lengths):
+    from oracle import model as OM
+
+    table = unit_table(V, H)
+    batch, lengths = ragged_batch(B, L, V, lengths=lengths, seed=2)
+    m = _model(X, H=H, A=A, I=I, nL=nL, Lmax=L, prec=prec, table=table)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.encoder_state_dict().items()}
+    ref = OM.forward(params, table, batch["history_item_idx"], num_heads=A, max_seq_length=L)
+    out = m(batch["history_item_idx"].to(DEV))
+    valid = ref["attention_mask"].bool()
+    assert torch.equal(out["attention_mask"].cpu().bool(), valid)
+    assert_close("tok", out["token_embeddings"].cpu()[valid], ref["token_embeddings"].detach()[valid], prec)
+    assert_close("sentence_embedding", out["sentence_embedding"], ref["sentence_embedding"].detach(), prec)
+    w = torch.linspace(-1, 1, H)
+    (ref["token_embeddings"] * w * valid[..., None]).sum().backward()
+    (out["token_embeddings"] * w.to(DEV) * valid.to(DEV)[..., None]).sum().backward()
+    got = m.grad_state_dict()
+    for k, p in params.items():
+        if k.endswith("key.bias"):
+            continue
+        assert_close(k, got[k], p.grad, prec, "grad")
+
+
 def test_truncation_to_max_seq_length(X):
     """models.py:334-337: only the last max_seq_length items are encoded."""
     H, V = 64, 40
@@ -265,7 +311,8 @@ def test_loss_api_errors_mirror_reference(X):
 
 # ------------------------------------------------------------------------------------------ fused loss, positions form
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("T_shape,H,V", [((4, 50), 64, 60), ((5, 200), 128, 500), ((2, 96), 256, 100)])
+@pytest.mark.parametrize("T_shape,H,V", [((4, 50), 64, 60), ((5, 200), 128, 500), ((2, 96), 256, 100),
+                                         ((6, 32), 384, 150)])  # 384 = the reference's default d_model (all-MiniLM table)
 def test_fused_loss_positions_form_vs_oracle(X, prec, T_shape, H, V):
     """All seven heads + statistics + d_tok from ONE launch sequence, on ragged positions, vs the oracle that
     materialises the (Np, 1+N, H) candidates like models.py:408-416. Several tiles and splits are exercised."""
@@ -402,6 +449,56 @@ def test_normalized_queries_and_hard_negatives_in_the_training_step_vs_oracle(X,
         assert rel_l2(g, params[name].grad) <= 5e-4, name
         checked += 1
     assert checked >= 10
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"])
+def test_reference_default_lightning_config_trains(X, prec, train_loss):
+    """The reference's own defaults (config.yaml:46-52, models.py:37-48, 80-91; params.py:11 all-MiniLM-L6-v2 item
+    embeddings => d_model 384, no projection): 12 heads, intermediate 48, 1 layer, max_seq_length 32, batch 32. Only
+    `hidden_size` is given (the reference resolves it to 384 by downloading the model). Three optimizer steps against the
+    CPU oracle of the same step: every head's value, the train head's parameter gradients, the parameters afterwards."""
+    from oracle import model as OM
+
+    conf = X.LightningConfig(hidden_size=384, train_loss=train_loss, precision=prec)
+    assert (conf.num_attention_heads, conf.intermediate_size, conf.num_hidden_layers, conf.max_seq_length) == (12, 48, 1, 32)
+    V, B, L, H = 500, 32, 32, 384
+    table = unit_table(V, H)
+    g = torch.Generator().manual_seed(4)
+    lengths = torch.randint(1, L + 1, (B,), generator=g).tolist()
+    lengths[0] = L
+    batch, _ = ragged_batch(B, L, V, lengths=lengths, seed=5)
+    mod = X.RecommenderLightningModule(conf)
+    mod.configure_model()
+    mod.model.set_table(table.to(DEV))
+    mod.eval()  # dropout off: parity is only defined without it
+    tr = OM.OracleTrainer({k: v.detach().cpu().clone() for k, v in mod.model.encoder_state_dict().items()}, table,
+                          num_heads=12, max_seq_length=L, train_loss=train_loss)
+    opt = mod.configure_optimizers()
+    tol = TOL[prec]
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        tr.opt.zero_grad(set_to_none=True)
+        want = OM.compute_losses(tr.params, table, batch, num_heads=12, max_seq_length=L, loss_cfg={}, resolve_ties=True)
+        want[f"loss/{train_loss}"].backward()
+        loss = mod.training_step(batch)
+        loss.backward()
+        for cls in X.LOSS_CLASSES:
+            k = f"loss/{cls.__name__}"
+            w = float(want[k].detach())
+            lim = tol["loss_rel"] * max(1.0, abs(w)) * (3 if prec == "bf16" else 1)
+            assert abs(float(mod.logged[k]) - w) <= lim, (step, k, float(mod.logged[k]), w)
+        got = mod.model.grad_state_dict()
+        for k, p_ in tr.params.items():
+            if k.endswith("key.bias"):
+                continue
+            e = rel_l2(got[k], p_.grad)
+            assert e <= tol["grad_l2"] * (3 if prec == "bf16" else 1), (step, k, e)
+        opt.step()
+        tr.opt.step()
+    if prec == "fp32":
+        for k, v in mod.model.encoder_state_dict().items():
+            assert (v.cpu() - tr.params[k].detach()).abs().max().item() <= 3e-5, k
 
 
 @pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"])

@@ -72,7 +72,11 @@ def test_layernorm_bwd_dropout_consistency(ops):
     torch.testing.assert_close(d_lin, dx * keep / (1 - p), rtol=1e-5, atol=1e-7)
 
 
-SHAPES = [(100, 96, 32), (300, 128, 128), (513, 384, 128), (257, 128, 512), (64, 64, 64), (1000, 512, 128)]
+SHAPES = [(100, 96, 32), (300, 128, 128), (513, 384, 128), (257, 128, 512), (64, 64, 64), (1000, 512, 128),
+          # configs 4 / 5 (H = 256, I = 1024): QKV, FFN1, FFN2 / out-proj
+          (300, 768, 256), (257, 1024, 256), (200, 256, 1024), (130, 256, 256),
+          # the reference's default model (H = 384, I = 48): QKV, FFN1, FFN2 (K = 48: 32-deep slices + a 16-deep tail)
+          (150, 1152, 384), (150, 48, 384), (150, 384, 48)]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -267,7 +271,9 @@ def test_attention_dropout_keep_rate(ops, prec):
     assert float(kept[:, -1, :].mean()) / L == pytest.approx(1 - p, abs=0.02)
 
 
-@pytest.mark.parametrize("K,M,p_drop", [(128, 300, 0.0), (512, 1000, 0.0), (128, 4096 + 17, 0.2)])
+# K = 96: not a multiple of 64 -> 32-deep K slices, whose operand images are SMALLER than the epilogue's scratch strips
+# plus exchange records (the LDS allocation must be sized by the epilogue there)
+@pytest.mark.parametrize("K,M,p_drop", [(128, 300, 0.0), (512, 1000, 0.0), (128, 4096 + 17, 0.2), (96, 1000, 0.1)])
 @pytest.mark.parametrize("bf16_storage", [False, True])
 def test_linear_with_layernorm_in_the_epilogue(ops, K, M, p_drop, bf16_storage):
     """xf_linear_ln_fwd_ex (internal entry point of the encoder forward at T >= 16 384: out-proj / FFN2 Linear +
@@ -329,6 +335,36 @@ def test_adamw_matches_torch(ops):
         opt.step()
         ops.adamw_(pd, gs.to(DEV), m, v, lr=1e-3, weight_decay=0.01, step=step)
     torch.testing.assert_close(pd.cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_adamw_grad_scale_is_the_ddp_average(ops, world):
+    """DDP averages gradients (config.yaml:5-6,35: torch DDP divides the SUM by the world size). Here the flat gradient
+    is SUM-all-reduced and the 1/W rides in the AdamW launch (`grad_scale`): xfmr_adamw(g_sum, grad_scale=1/W) must be
+    torch.optim.AdamW on g_sum / W."""
+    n = 4099
+    p, g = _rand(n, seed=1), _rand(n, seed=2)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01)
+    pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        g_sum = g * step * world  # what the all-reduce leaves in the flat gradient
+        ref.grad = g_sum / world
+        opt.step()
+        ops.adamw_(pd, g_sum.to(DEV), m, v, lr=1e-3, weight_decay=0.01, step=step, grad_scale=1.0 / world)
+    torch.testing.assert_close(pd.cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
+    # and through the optimizer object the Trainer builds for world_size > 1
+    from xfmr_rec_amd.trainer import FusedAdamW
+
+    q = torch.nn.Parameter(p.clone().to(DEV))
+    fo = FusedAdamW([q], lr=1e-3, weight_decay=0.01, grad_scale=1.0 / world)
+    ref2 = torch.nn.Parameter(p.clone())
+    opt2 = torch.optim.AdamW([ref2], lr=1e-3, weight_decay=0.01)
+    q.grad = (g * world).to(DEV)
+    ref2.grad = g.clone()
+    fo.step()
+    opt2.step()
+    torch.testing.assert_close(q.detach().cpu(), ref2.detach(), rtol=1e-5, atol=1e-7)
 
 
 def test_errors_are_loud(ops):

@@ -28,12 +28,12 @@ def test_oracle_metrics_on_hand_computed_cases():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
-def test_topk_matches_exact_numpy_search(metric):
+@pytest.mark.parametrize("metric,H", [("cosine", 64), ("dot", 64), ("l2", 64), ("cosine", 384), ("l2", 384)])
+def test_topk_matches_exact_numpy_search(metric, H):
     from xfmr_rec_amd.retrieval import ExactItemIndex
 
     g = torch.Generator().manual_seed(0)
-    V, H, B, k = 777, 64, 9, 20
+    V, B, k = 777, 9, 20
     table = torch.randn(V + 1, H, generator=g)
     table[0] = 0
     table[5] = table[9]  # exact ties

@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int DENSE_MAX_C = 8192;
+constexpr int DENSE_MAX_H = 1024;  // gradient: four columns per thread
 
 struct DenseArgs {
   const float* q; const float* cand; const int64_t* target;
@@ -239,29 +240,43 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(DenseArgs a) {
   // ---- 4. gradient of the train head w.r.t. the query ---------------------------------------------------------
   if (!a.d_query) return;
   const bool cosh = head <= XFMR_LOSS_CONTRASTIVE;
-  float g = 0.f;
-  const int h = tid;
-  if (h < H) {
+  constexpr int HPT = DENSE_MAX_H / 256;  // columns per thread: h = tid + 256 u
+  float g[HPT];
+  float dot_part = 0.f;
+#pragma unroll
+  for (int u = 0; u < HPT; ++u) {
+    const int h = tid + 256 * u;
+    g[u] = 0.f;
+    if (h >= H) continue;
     float O = 0.f;
     if (head != XFMR_LOSS_ALIGNMENT)
       for (int c = 0; c < C; ++c) O = fmaf(sW[c], cand[(int64_t)c * H + h], O);
     const float e = cand[(int64_t)tgt * H + h];
     switch (head) {
-      case XFMR_LOSS_INFONCE: g = a.scale * (O / ltot - (1.f - epos / ltot) * e); break;
-      case XFMR_LOSS_NCE: g = -xf_sigmoid(-pos_dot) * e + O * inv_d; break;
+      case XFMR_LOSS_INFONCE: g[u] = a.scale * (O / ltot - (1.f - epos / ltot) * e); break;
+      case XFMR_LOSS_NCE: g[u] = -xf_sigmoid(-pos_dot) * e + O * inv_d; break;
       case XFMR_LOSS_PAIRWISE_HINGE:
-      case XFMR_LOSS_PAIRWISE_LOGISTIC: g = (O - (1.f - a.margin) * sw * e) * inv_d; break;
-      case XFMR_LOSS_ALIGNMENT: g = -rcpos * e; break;
-      case XFMR_LOSS_CONTRASTIVE: g = O * inv_c; break;
-      default: g = -rcpos * e + O * inv_c; break;  // ALIGNMENT_CONTRASTIVE
+      case XFMR_LOSS_PAIRWISE_LOGISTIC: g[u] = (O - (1.f - a.margin) * sw * e) * inv_d; break;
+      case XFMR_LOSS_ALIGNMENT: g[u] = -rcpos * e; break;
+      case XFMR_LOSS_CONTRASTIVE: g[u] = O * inv_c; break;
+      default: g[u] = -rcpos * e + O * inv_c; break;  // ALIGNMENT_CONTRASTIVE
     }
+    dot_part += g[u] * sQ[h] * rq;
   }
   if (cosh) {  // g is dL/dq_hat: apply the Jacobian of q / max(|q|, eps)
-    const float dotp = br.sum(h < H ? g * sQ[h] * rq : 0.f);
+    const float dotp = br.sum(dot_part);
     const bool clamped = sqrtf(qq) < 1e-8f;
-    if (h < H) g = clamped ? g * rq : rq * (g - sQ[h] * rq * dotp);
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+      const int h = tid + 256 * u;
+      if (h < H) g[u] = clamped ? g[u] * rq : rq * (g[u] - sQ[h] * rq * dotp);
+    }
   }
-  if (h < H) a.d_query[row * H + h] = g;
+#pragma unroll
+  for (int u = 0; u < HPT; ++u) {
+    const int h = tid + 256 * u;
+    if (h < H) a.d_query[row * H + h] = g[u];
+  }
 }
 
 __global__ void dense_counts_kernel(int* counts, int c, int n) {
@@ -289,7 +304,7 @@ int xfmr_dense_loss(const xfmr_loss_cfg* cfg, const float* query, const float* c
   if ((target_mode == XFMR_TARGET_EXPLICIT) != (target != nullptr)) return XFMR_EINVAL;  // losses.py:233-238
   if (target_mode == XFMR_TARGET_DIAGONAL && N > C) return XFMR_EINVAL;
   if (cfg->train_head < 0 || cfg->train_head >= XFMR_NUM_LOSSES || cfg->num_hard_negatives < 0) return XFMR_EINVAL;
-  if ((H & 3) || H > 256 || C > DENSE_MAX_C) return XFMR_EUNSUPPORTED;
+  if ((H & 3) || H > DENSE_MAX_H || C > DENSE_MAX_C) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(query) || !xf_aligned16(cand) || !xf_aligned16(workspace)) return XFMR_EALIGN;
   if (workspace_bytes < xfmr_dense_loss_workspace(N, C, H)) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;

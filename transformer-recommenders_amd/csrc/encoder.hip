@@ -192,7 +192,7 @@ const char* xfmr_strerror(int code) {
     case XFMR_OK: return "ok";
     case XFMR_EINVAL: return "invalid argument";
     case XFMR_EUNSUPPORTED:
-      return "shape not supported by the gfx950 kernels (head size must be 32; H in {64,128,256} for the loss; "
+      return "shape not supported by the gfx950 kernels (head size must be 32; H in {64,128,256,384} for the fused loss; "
              "attention panels must fit LDS: L <= 256 in the fp32 policy, L <= 1024 in bf16)";
     case XFMR_EWORKSPACE: return "workspace too small";
     case XFMR_EHIP: return "HIP launch failed";

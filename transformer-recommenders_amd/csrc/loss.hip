@@ -146,15 +146,22 @@ __global__ __launch_bounds__(PREP) void distinct_write_kernel(const int* hist, i
 }
 
 // ---- main kernel -------------------------------------------------------------------------------------
+// H > 256 (the reference's default d_model 384): the dQ product runs as H / 128 column parts (grid.z) -- the tile image
+// [64][H] for S^T is whole, the transposed image and the gradient accumulators cover 128 columns: 134 KB of LDS and 64
+// accumulator registers in the fp32 policy instead of 203 KB / 192. Scores and weights are recomputed per part.
+template <int H>
+constexpr int loss_main_hparts() { return H > 256 ? H / 128 : 1; }
 template <class P, int H, bool ALL>
 __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(LossArgs a) {
   using elem = typename P::elem;
   constexpr int LDE = xf_ld<P>(H);
   constexpr int NPASS = 2 * (H / 64);  // staging passes: 32 rows x 64 columns per pass per workgroup
+  constexpr int HP = loss_main_hparts<H>(), HW = H / HP, NO = HW / 32;
+  const int hpart = HP > 1 ? (int)blockIdx.z : 0;
   // With every head evaluated the epilogue needs the registers: the wave's query rows then live in LDS
   // (B operand read like the A operand) so the kernel still fits 2 waves/SIMD (<= 256 registers).
   constexpr bool Q_IN_LDS = ALL && (P::kId == XFMR_PREC_BF16) && (H <= 128);
-  constexpr size_t E_BYTES = BN * LDE * sizeof(elem), ET_BYTES = H * LDT * sizeof(elem);
+  constexpr size_t E_BYTES = BN * LDE * sizeof(elem), ET_BYTES = HW * LDT * sizeof(elem);
   constexpr size_t SCR_BYTES = 4 * 32 * 33 * sizeof(float);
   constexpr size_t MAIN_BYTES = (E_BYTES + ET_BYTES > SCR_BYTES) ? E_BYTES + ET_BYTES : SCR_BYTES;
   constexpr size_t Q_BYTES = Q_IN_LDS ? QB * LDE * sizeof(elem) : 0;
@@ -221,9 +228,9 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   }
   const bool dump = a.dump != nullptr;
   if (dump && split == 0 && lane < 32 && qvalid) a.qinfo[qi] = make_float2(pos_dot, rq);
-  f32x16 o[H / 32];
+  f32x16 o[NO];
 #pragma unroll
-  for (int i = 0; i < H / 32; ++i)
+  for (int i = 0; i < NO; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
 
@@ -264,8 +271,10 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
       const int r0 = (p & 1) * 32 + wid * 8 + 2 * st_rho;
       xf_store4<P>(sE + r0 * LDE + cc, pre[p][0]);
       xf_store4<P>(sE + (r0 + 1) * LDE + cc, pre[p][1]);
+      const int ct = cc - hpart * HW;  // column inside this part's transposed image (HP == 1: all of them)
+      if (HP > 1 && (ct < 0 || ct >= HW)) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xf_store2<P>(sET + (cc + j) * LDT + r0, xf_get(pre[p][0], j), xf_get(pre[p][1], j));
+      for (int j = 0; j < 4; ++j) xf_store2<P>(sET + (ct + j) * LDT + r0, xf_get(pre[p][0], j), xf_get(pre[p][1], j));
     }
     if (tid < BN) {
       sNid[tid] = pre_nid;
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   // PREFETCH_ACROSS: keep the next tile's gather in registers while this tile is multiplied (1 workgroup/CU
   // variants); otherwise gather-then-commit back to back and let the second resident workgroup of the CU
   // cover the latency (2 waves/SIMD variants: the 32 staging registers are not live across the math).
-  constexpr bool PREFETCH_ACROSS = (H > 128);
+  constexpr bool PREFETCH_ACROSS = (H > 128 && H <= 256);  // (H = 384: the 96 staging registers are not kept live)
   if (PREFETCH_ACROSS && t_beg < t_end) prefetch(t_beg);
   for (int tile = t_beg; tile < t_end; ++tile) {
     __syncthreads();
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
       else P::tile_nreg(s, sE, LDE, sb * 32, qreg.regs(), H);
 
       if (dump) {  // logits of this sub-block, as the epilogue would see them (tie resolution happens in the reader)
-        if (qvalid) {
+        if (qvalid && hpart == 0) {
           float* drow = a.dump + (int64_t)qi * a.dump_ld + tile * BN + sb * 32 + 4 * hh;
 #pragma unroll
           for (int g = 0; g < 4; ++g)
@@ -307,20 +316,20 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
       loss_epilogue<ALL, true>(s, st, o, kc, &sNid[sb * 32], &sRc[sb * 32], &sMul[sb * 32], hh);
       if (do_grad) {
 #pragma unroll
-        for (int i = 0; i < H / 32; ++i) P::tile_xb(o[i], sET, LDT, i * 32, sb * 32, s);
+        for (int i = 0; i < NO; ++i) P::tile_xb(o[i], sET, LDT, i * 32, sb * 32, s);
       }
     }
   }
 
   if (dump) return;
   // ---- write the (split, query) partial -----------------------------------------------------------
-  write_partial(st, a.part + ((int64_t)split * a.T + qi) * REC, lane < 32 && qvalid, pos_dot, rq, qq);
+  write_partial(st, a.part + ((int64_t)split * a.T + qi) * REC, lane < 32 && qvalid && hpart == 0, pos_dot, rq, qq);
   if (do_grad) {
     __syncthreads();  // sScratch aliases the tile images other waves may still be reading
     float* base = a.partO + (int64_t)split * a.T * H;
 #pragma unroll
-    for (int i = 0; i < H / 32; ++i)
-      xf_store_tile_T(sScratch + wid * 32 * 33, o[i], 1.f, base + i * 32, H, qb0 + wid * 32, Nq);
+    for (int i = 0; i < NO; ++i)
+      xf_store_tile_T(sScratch + wid * 32 * 33, o[i], 1.f, base + (hpart * NO + i) * 32, H, qb0 + wid * 32, Nq);
   }
 }
 
@@ -535,9 +544,10 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       const bool cosh = head <= XFMR_LOSS_CONTRASTIVE;
       // first pass for cosine heads: q_hat . dq_hat
       float dotp = 0.f;
-      float4 gk[2];  // the row's gradient pieces of this lane (H <= 256: at most two 128-column sweeps)
+      constexpr int NSW = 4;  // 128-column sweeps: H <= 512
+      float4 gk[NSW];         // the row's gradient pieces of this lane
 #pragma unroll
-      for (int sw = 0; sw < 2; ++sw) {
+      for (int sw = 0; sw < NSW; ++sw) {
         const int c = sw * 128 + 4 * hl;
         gk[sw] = make_float4(0, 0, 0, 0);
         if (c >= H) continue;
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
         for (int o = 16; o > 0; o >>= 1) dotp += __shfl_xor(dotp, o, 64);
         const bool clamped = sqrtf(qq) < 1e-8f;  // norm clamped: q_hat = q/eps, no projection term
 #pragma unroll
-        for (int sw = 0; sw < 2; ++sw) {
+        for (int sw = 0; sw < NSW; ++sw) {
           const int c = sw * 128 + 4 * hl;
           if (c >= H) continue;
           const float4 q4 = *reinterpret_cast<const float4*>(qp + c);
@@ -730,6 +740,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
 
 template <class P, int H>
 void launch_main(const LossArgs& a, bool all, dim3 grid, hipStream_t st) {
+  grid.z = (a.need_grad && !a.dump) ? loss_main_hparts<H>() : 1;  // dQ column parts (values-only launches: one)
   if (all) hipLaunchKernelGGL((loss_main_kernel<P, H, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((loss_main_kernel<P, H, false>), grid, dim3(256), 0, st, a);
 }
@@ -739,6 +750,7 @@ int launch_main_h(const LossArgs& a, int H, bool all, dim3 grid, hipStream_t st)
     case 64: launch_main<P, 64>(a, all, grid, st); break;
     case 128: launch_main<P, 128>(a, all, grid, st); break;
     case 256: launch_main<P, 256>(a, all, grid, st); break;
+    case 384: launch_main<P, 384>(a, all, grid, st); break;
     default: return XFMR_EUNSUPPORTED;
   }
   XF_LAUNCH_CHECK();
@@ -750,6 +762,7 @@ int launch_dma_h(const LossArgs& a, const void* tbf, int H, int head, dim3 grid,
     case 64: return xf_launch_loss_dma_64(a, tbf, head, grid, st);
     case 128: return xf_launch_loss_dma_128(a, tbf, head, grid, st);
     case 256: return xf_launch_loss_dma_256(a, tbf, head, grid, st);
+    case 384: return xf_launch_loss_dma_384(a, tbf, head, grid, st);
     default: return XFMR_EUNSUPPORTED;
   }
 }
@@ -757,6 +770,7 @@ int launch_dma_h(const LossArgs& a, const void* tbf, int H, int head, dim3 grid,
 // one-shot, per host thread: events recorded around the NEXT main-kernel launch (measurement only)
 thread_local hipEvent_t g_prof_start = nullptr;
 thread_local hipEvent_t g_prof_stop = nullptr;
+thread_local int g_prof_which = 0;  // XFMR_PROFILE_GRADIENT_PASS / XFMR_PROFILE_LOGGING_PASS
 
 }  // namespace
 
@@ -773,8 +787,13 @@ int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, c
 }
 
 int xfmr_sampled_loss_profile_next(void* start_event, void* stop_event) {
+  return xfmr_sampled_loss_profile_pass(start_event, stop_event, XFMR_PROFILE_GRADIENT_PASS);
+}
+int xfmr_sampled_loss_profile_pass(void* start_event, void* stop_event, int32_t which) {
+  if (which != XFMR_PROFILE_GRADIENT_PASS && which != XFMR_PROFILE_LOGGING_PASS) return XFMR_EINVAL;
   g_prof_start = (hipEvent_t)start_event;
   g_prof_stop = (hipEvent_t)stop_event;
+  g_prof_which = which;
   return XFMR_OK;
 }
 
@@ -804,8 +823,23 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   a.mode = cfg->mode; a.need_grad = d_tok != nullptr; a.scale = cfg->scale; a.margin = cfg->margin;
   dim3 grid((unsigned)((T + QB - 1) / QB), p.nsplit);
   int rc;
-  hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
-  g_prof_start = g_prof_stop = nullptr;  // one-shot
+  // one-shot measurement hook. XFMR_PROFILE_GRADIENT_PASS: events around the main kernel of THIS call (its gradient
+  // pass, or its only pass). XFMR_PROFILE_LOGGING_PASS: events around the values-only logging pass of a call that runs
+  // one beside a gradient pass, or alone with every head (all_heads != 0); other calls leave the request pending.
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, lev0 = nullptr, lev1 = nullptr;
+  if (g_prof_start) {
+    const bool dma = cfg->num_hard_negatives == 0 && cfg->precision == XFMR_PREC_BF16 && table_bf16;
+    const bool gp = d_tok != nullptr && cfg->train_head != XFMR_LOSS_ALIGNMENT;
+    const bool has_log = dma && cfg->all_heads != 0;
+    if (g_prof_which == XFMR_PROFILE_GRADIENT_PASS) {
+      ev0 = g_prof_start; ev1 = g_prof_stop;
+      g_prof_start = g_prof_stop = nullptr;
+    } else if (has_log) {
+      if (gp) { lev0 = g_prof_start; lev1 = g_prof_stop; }
+      else { ev0 = g_prof_start; ev1 = g_prof_stop; }  // the logging pass IS this call's only main kernel
+      g_prof_start = g_prof_stop = nullptr;
+    }
+  }
   const float* part_loss = nullptr;  // records the loss VALUES are read from (null: the same as the gradient's)
   bool lse_from_grad = false;        // InfoNCE value from the gradient pass's records (logging pass ran without it)
   const bool hard = cfg->num_hard_negatives > 0;
@@ -840,8 +874,10 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       LossArgs b = a;
       b.part = (float*)(ws + p.off_part2);
       b.need_grad = 0;
+      if (lev0 && hipEventRecord(lev0, st) != hipSuccess) return XFMR_EHIP;
       rc = launch_dma_h(b, table_bf16, H, -2, grid, st);  // (the InfoNCE value comes from the gradient records)
       if (rc) return rc;
+      if (lev1 && hipEventRecord(lev1, st) != hipSuccess) return XFMR_EHIP;
       part_loss = b.part;
       lse_from_grad = true;
       a.pin_part = b.part;
@@ -868,8 +904,10 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       const bool lse_elsewhere = cfg->train_head == XFMR_LOSS_INFONCE && (grad_pass || cfg->all_heads == 2);
       lse_from_grad = lse_elsewhere && grad_pass;
       const int code = lse_elsewhere ? -2 : -1;
+      if (grad_pass && lev0 && hipEventRecord(lev0, st) != hipSuccess) return XFMR_EHIP;
       rc = launch_dma_h(b, table_bf16, H, code, grid, st);
       if (rc) return rc;
+      if (grad_pass && lev1 && hipEventRecord(lev1, st) != hipSuccess) return XFMR_EHIP;
       if (!grad_pass && ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
       if (grad_pass) part_loss = b.part;
     }

@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int TOPK_MAX = 1024;
+constexpr int TOPK_MAX_H = 1024;
 
 struct TopkArgs {
   const float* q; const float* table; const float* rnorm; int64_t n_rows;
@@ -31,7 +32,7 @@ __device__ __forceinline__ unsigned key_of(float f) {
 }
 
 __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
-  __shared__ float sQ[256];
+  __shared__ __attribute__((aligned(16))) float sQ[TOPK_MAX_H];
   __shared__ unsigned hist[256];
   __shared__ int sh[4], wcnt[4], weq[4];
   __shared__ float sScore[TOPK_MAX];
@@ -42,9 +43,10 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
   const int64_t V = a.n_rows;
   float* sc = a.scores + qi * V;
   float qq = 0.f;
-  if (tid < H) {
-    sQ[tid] = a.q[qi * H + tid];
-    qq = sQ[tid] * sQ[tid];
+  for (int h = tid; h < H; h += 256) {
+    const float v = a.q[qi * H + h];
+    sQ[h] = v;
+    qq += v * v;
   }
   qq = xf_wave_sum(qq);
   if (lane == 0) sh[w] = __float_as_int(qq);
@@ -262,7 +264,7 @@ int xfmr_topk(const float* query, const float* table, const float* table_rnorm, 
   if (n_rows <= 0 || n_query <= 0 || H <= 0 || k <= 0) return XFMR_EINVAL;
   if ((exclude == nullptr) != (exclude_offsets == nullptr)) return XFMR_EINVAL;
   if (metric < XFMR_METRIC_COSINE || metric > XFMR_METRIC_L2) return XFMR_EINVAL;
-  if ((H & 3) || H > 256 || k > TOPK_MAX || n_rows >= (1ll << 31)) return XFMR_EUNSUPPORTED;
+  if ((H & 3) || H > TOPK_MAX_H || k > TOPK_MAX || n_rows >= (1ll << 31)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(table) || !xf_aligned16(workspace)) return XFMR_EALIGN;
   if (workspace_bytes < xfmr_topk_workspace(n_query, n_rows)) return XFMR_EWORKSPACE;
   TopkArgs a{};

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "xfmr_dense_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P,
                                   _P, _P, C.c_size_t, _P]),
     "xfmr_sampled_loss_profile_next": (C.c_int, [_P, _P]),
+    "xfmr_sampled_loss_profile_pass": (C.c_int, [_P, _P, C.c_int32]),
     "xfmr_table_rnorm": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "xfmr_table_prepare": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     "xfmr_seq_sample_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
