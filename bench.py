@@ -4,22 +4,26 @@
 MI355X of one node, data-parallel over RCCL.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5          # launches its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                # ... or is launched as one of N ranks
 
 One "step" = zero_grad -> gather+mask+BertEmbeddings -> 4 x BertLayer -> fused loss (all seven heads +
 LogitsStatistics + dL/dtok, as the reference's training_step evaluates them, xfmr_rec/trainer.py:250-264) ->
-encoder backward -> flat-gradient all-reduce (N > 1) -> AdamW, dropout 0.1 ON, on one batch of synthetic
-sequences already resident in HBM (the batch is 3 x B x 200 int64 = 0.6 MB at B=128; the PCIe-inclusive rate
-is noted in DESIGN.md). Rank 0 prints ONE JSON line; see the task contract for the fields. Extra objects:
+encoder backward -> flat-gradient all-reduce (N > 1) -> AdamW, dropout 0.1 ON. `value` is measured with the batch
+(3 x B x 200 int64) already resident in HBM; `h2d_inclusive` repeats the timed region with the three index tensors
+copied from pinned host memory inside every step (SURVEY section 8d counts that copy into the metric). Rank 0 prints
+ONE JSON line; see the task contract for the fields. Extra objects:
 
-  roofline     loss_main_dma_kernel, gradient pass (the negative-scoring logit GEMM with its fused epilogue and the
-               dQ GEMM): algorithmic flops per launch = 4 * Np * Nd * H (SURVEY section 8d with M = Nd, the distinct
-               negative items the kernel walks; the reference's N-column count is reported beside it) / average
-               launch duration measured with HIP events recorded on the launch stream around that kernel
-               inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
-  cpu_baseline the CPU oracle (oracle/, a restatement of the reference: 'port') timed on this host's cores
-               on a bounded sample (the reference's O(N^2 H) candidate tensor caps the batch it can run).
+  roofline     the DOMINANT kernel of the step by GPU time (profiles/: the values-only logging pass of the fused loss,
+               loss_main_dma_kernel<128,-2>, which evaluates the six logging heads + LogitsStatistics): executed flops
+               per launch = 2 * Np * Nd * H / average launch duration from HIP events recorded on its launch stream
+               inside the timed region, against the dense bf16 MFMA peak. `kernels` lists the same for the gradient
+               pass (the logit GEMM + dQ GEMM: 4 * Np * Nd * H); `step` = executed flops of the whole step / ms_per_step;
+               fields that come from a committed rocprof run instead of this run carry a `source`.
+  cpu_baseline the CPU oracle (oracle/, a restatement of the reference: 'port') timed on this host's cores on bounded
+               samples: reference-faithful fp32 (the headline), bf16-autocast (the reference's default precision),
+               reference-lean (train head only, GEMM-form logits) and BASELINE config 1 (ML-100K-shaped).
 """
 
 from __future__ import annotations
@@ -29,6 +33,8 @@ import ctypes
 import json
 import os
 import pathlib
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,14 +43,13 @@ for p in (ROOT, ROOT / "transformer-recommenders_amd"):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
 
-import torch  # noqa: E402
-
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_TBPS = 8.0
 METRIC = "user-sequences/sec (train step) MovieLens-1M seq200 d128 @1/2/4/8 GPU"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -70,34 +75,86 @@ def parse():
     ap.add_argument("--heads", type=int, default=0, help="attention heads (default hidden/32: head size 32)")
     ap.add_argument("--negatives", default="in_batch", choices=["in_batch", "catalogue"],
                     help="catalogue = full-catalogue softmax (BASELINE config 4; SURVEY F9)")
-    ap.add_argument("--preset", default=None, choices=["config2", "config3", "config4", "config5"],
+    ap.add_argument("--preset", default=None, choices=["config2", "config3", "config4", "config5", "reference-default"],
                     help="the other BASELINE.json configs as sanity workloads (the bench line is config2, the default)")
     ap.add_argument("--spinup-steps", type=int, default=300,
                     help="untimed steps of the same workload BEFORE the --warmup steps (same count on every rank): a "
-                         "fresh box can take > 100 ms of sustained load to reach its steady clocks -- first runs on "
-                         "cold boxes measured 20-40 %% low with 5 warmup steps alone; the metric is steady-state "
-                         "throughput (SURVEY section 8d)")
+                         "fresh box can take > 100 ms of sustained load to reach its steady clocks; the cold rate "
+                         "(--warmup steps only) is measured first and reported as `cold_start`")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=12)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=7.0, help="time budget of EACH cpu_baseline variant")
+    args = ap.parse_args(argv)
     presets = {
         "config2": {},
         "config3": dict(loss="PairwiseLogisticLoss"),
         "config4": dict(items=27278, hidden=256, layers=6, inter=1024, batch=64, negatives="catalogue"),
         "config5": dict(items=1_000_000, seq_len=512, hidden=256, layers=4, inter=1024, batch=64,
                         loss="AlignmentContrastiveLoss"),
+        # the reference's own config.yaml / ModelConfig defaults with the all-MiniLM (384-wide) item table
+        "reference-default": dict(hidden=384, heads=12, layers=1, inter=48, seq_len=32, batch=32),
     }
     for k, v in presets.get(args.preset or "config2", {}).items():
         setattr(args, k, v)
     return args
 
 
+# ----------------------------------------------------------------------------------------------- launching N ranks
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` started as ONE process: start N ranks of this script with torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, relay their output
+    (rank 0 prints the JSON line) and return the launcher's exit status -- non-zero if any rank failed."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(pathlib.Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args) -> int:
+    """XFMR_BENCH_DRY=1: the control flow of an N-rank run without a GPU -- rendezvous, barrier, one SUM all-reduce of
+    a flat buffer, MAX-over-ranks timing, rank 0's line -- over gloo. Used by the CPU test of the self-launch."""
+    import torch
+    import torch.distributed as dist
+
+    from xfmr_rec_amd import distributed as D
+
+    rank, _local, world = D.init_process_group_from_env(backend="gloo")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    flat = torch.full((1000,), float(rank + 1))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    D.allreduce_flat_grad_(flat)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = bool((flat == world * (world + 1) / 2).all())
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "dry": True, "n_gpus": world, "allreduce_ok": ok, "value": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ----------------------------------------------------------------------------------------------------- inputs
 def synth_batch(B, L, V, seed, lengths_mode):
+    import torch
+
     g = torch.Generator().manual_seed(seed)
     if lengths_mode == "dense":
         lens = [L] * B
     else:  # MovieLens-1M-like: log-normal, clipped to [16, L] (SURVEY section 8d)
-        lens = torch.exp(torch.randn(B, generator=g) * 1.0 + 4.35).round().clamp(16, L).long().tolist()
+        lens = torch.exp(torch.randn(B, generator=g) * 1.0 + 4.35).round().clamp(min(16, L), L).long().tolist()
     out = {k: torch.zeros(B, L, dtype=torch.int64) for k in ("history_item_idx", "pos_item_idx", "neg_item_idx")}
     for b, n in enumerate(lens):
         for k in out:
@@ -106,6 +163,8 @@ def synth_batch(B, L, V, seed, lengths_mode):
 
 
 def unit_table(V, H, seed=1234):
+    import torch
+
     g = torch.Generator().manual_seed(seed)
     t = torch.randn(V + 1, H, generator=g)
     t = t / t.norm(dim=-1, keepdim=True)
@@ -124,9 +183,11 @@ class HipEvents:
             assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
             self.pairs.append((a, b))
 
-    def elapsed_ms(self):
+    def elapsed_ms(self, idx=None):
         out = []
-        for a, b in self.pairs:
+        for i, (a, b) in enumerate(self.pairs):
+            if idx is not None and i not in idx:
+                continue
             ms = ctypes.c_float()
             if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0:
                 out.append(ms.value)
@@ -145,44 +206,103 @@ def usable_cpus() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(args):
-    """Reference-faithful CPU step (materialised (Np,1+N,H) candidates, 7 heads + stats, backward, AdamW)
-    through the oracle, on a bounded sample."""
+# ------------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_variant(args, *, B, L, H, V, layers, inter, faithful, autocast, seconds, label):
+    import torch
+
     from oracle import encoder as enc
     from oracle import model as OM
 
-    threads = usable_cpus()
-    torch.set_num_threads(threads)
-    B, L, H, V = args.cpu_batch, args.seq_len, args.hidden, args.items
-    params = enc.init_params(H, args.layers, args.inter, L, seed=0)
+    params = enc.init_params(H, layers, inter, L, seed=0)
     table = unit_table(V, H)
     batch, _ = synth_batch(B, L, V, 999, args.lengths)
     tr = OM.OracleTrainer(params, table, num_heads=H // 32, max_seq_length=L, train_loss=args.loss,
-                          dropout_p=0.0 if args.no_dropout else 0.1, faithful=not args.lean)
-    tr.step(batch)
+                          dropout_p=0.0 if args.no_dropout else 0.1, faithful=faithful)
+
+    def step():
+        if autocast:  # the reference's default precision: Lightning "bf16-mixed" = torch.autocast (trainer.py:449-455)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                tr.step(batch)
+        else:
+            tr.step(batch)
+
+    step()  # warm-up (allocator, oneDNN primitives)
     t0 = time.perf_counter()
     done = 0
-    while done < args.cpu_steps and (done == 0 or time.perf_counter() - t0 < 25.0):  # bounded: ~10-30 s of CPU
-        tr.step(batch)
+    while done < 50 and (done == 0 or time.perf_counter() - t0 < seconds):
+        step()
         done += 1
-    args.cpu_steps = done
     dt = (time.perf_counter() - t0) / done
     return {
-        "value": round(B / dt, 3), "unit": "sequences/s", "cores": threads, "kind": "port",
-        "sample": (f"{args.cpu_steps} steps of B={B} sequences x L={L} (N={B * L} in-batch negatives; the reference's "
-                   f"O(N^2 H) candidate tensor caps the CPU batch), fp32, {'7 heads + stats' if not args.lean else 'train head only'}, "
-                   f"{dt * 1e3:.0f} ms/step"),
+        "variant": label, "value": round(B / dt, 3), "unit": "sequences/s", "ms_per_step": round(dt * 1e3, 1),
+        "sample": f"{done} steps of B={B} x L={L} (H={H}, {layers} layers, V={V}; N={B * L} in-batch negatives)",
     }
+
+
+def cpu_baseline(args):
+    """The CPU oracle timed on this host (kind 'port': no reference file travels to the GPU box; the oracle is pinned to the
+    reference by tests/golden). Headline = reference-faithful fp32 on the bench workload's shape: materialised
+    (Np,1+N,H) candidates, 7 heads + statistics, backward, AdamW; the O(N^2 H) candidate tensor caps the CPU batch."""
+    import torch
+
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    L, H, V = args.seq_len, args.hidden, args.items
+    kw = dict(L=L, H=H, V=V, layers=args.layers, inter=args.inter, seconds=args.cpu_seconds)
+    variants = [
+        _cpu_variant(args, B=args.cpu_batch, faithful=not args.lean, autocast=False, label="reference-faithful fp32", **kw),
+        _cpu_variant(args, B=args.cpu_batch, faithful=not args.lean, autocast=True,
+                     label="reference-faithful bf16-autocast (the reference's default precision)", **kw),
+        _cpu_variant(args, B=args.cpu_batch, faithful=False, autocast=False,
+                     label="reference-lean fp32 (train head only, GEMM-form logits)", **kw),
+        _cpu_variant(args, B=32, faithful=False, autocast=False,
+                     label="reference-lean fp32 at the reference's default batch 32 (no O(N^2 H) tensor to cap it)", **kw),
+        _cpu_variant(args, B=32, L=50, H=64, V=1682, layers=2, inter=256, faithful=True, autocast=False,
+                     seconds=args.cpu_seconds, label="BASELINE config 1 (ML-100K-shaped, the reference's CPU-runnable case), faithful fp32"),
+    ]
+    head = variants[0]
+    return {
+        "value": head["value"], "unit": "sequences/s", "cores": threads, "kind": "port",
+        "sample": head["sample"] + f", fp32, {'7 heads + stats' if not args.lean else 'train head only'}, "
+                                   f"{head['ms_per_step']:.0f} ms/step",
+        "variants": variants,
+    }
+
+
+# ------------------------------------------------------------------------------------------------- the benchmark
+def encoder_flops_per_token(L, H, inter, layers):
+    """Executed encoder flops per token of a DENSE row, forward + backward (3x forward)."""
+    return 3 * layers * (8 * H * H + 4 * H * inter + 2 * (L + 1) * H)
+
+
+def static_profile(name):
+    p = ROOT / "profiles" / name
+    try:
+        return json.loads(p.read_text()) if p.exists() else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def main():
     args = parse()
+    if os.environ.get("XFMR_BENCH_DRY") == "1" and "WORLD_SIZE" in os.environ:
+        sys.exit(dry_run(args))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # one process was asked for N GPUs: become the launcher (no HIP call has been made in this process)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("XFMR_BENCH_DRY") == "1":
+        sys.exit(dry_run(args))
+
+    import torch
+
     import xfmr_rec_amd as X
     from xfmr_rec_amd import _native as N
     from xfmr_rec_amd import distributed as D
 
     rank, local, world = D.init_process_group_from_env()
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as "
+                         f"{args.gpus} GPUs")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -202,16 +322,38 @@ def main():
         mod.eval()
 
     n_batches = 4
-    batches = []
+    host_batches, batches = [], []
     for i in range(n_batches):
         b, lens = synth_batch(B, L, V, 1000 + rank * 97 + i, args.lengths)
+        host_batches.append({k: v.pin_memory() for k, v in b.items()})
         batches.append({k: v.to(dev) for k, v in b.items()})
     tokens_per_seq = sum(lens) / len(lens)
 
     overlap = args.overlap == "on" or (args.overlap == "auto" and B * L >= 102400)
 
-    def step(i):
-        batch = batches[i % n_batches]
+    copy_stream = torch.cuda.Stream(device=dev)
+    staged = {}
+
+    def upload(i):
+        """Batch i: three (B, L) int64 tensors from pinned host memory -> HBM on the copy stream (what a DataLoader with
+        pin_memory hands over; the copy of batch i + 1 runs under step i, as Lightning's prefetching does)."""
+        with torch.cuda.stream(copy_stream):
+            b = {k: v.to(dev, non_blocking=True) for k, v in host_batches[i % n_batches].items()}
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        staged[i] = (b, done)
+
+    def step(i, from_host=False):
+        if from_host:
+            if i not in staged:
+                upload(i)
+            batch, done = staged.pop(i)
+            torch.cuda.current_stream().wait_event(done)
+            for t in batch.values():
+                t.record_stream(torch.cuda.current_stream())
+            upload(i + 1)  # in flight while this step computes
+        else:
+            batch = batches[i % n_batches]
         opt = trainer.optimizer
         opt.zero_grad(set_to_none=True)
         # metrics stay on the device (no host sync per step)
@@ -224,55 +366,92 @@ def main():
         mod.sync_logging()
         return loss, out
 
+    lib = N.load()
+
+    def timed(n_steps, events=None, from_host=False):
+        """Exactly n_steps steps between barriers + device synchronisations; MAX over ranks."""
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            if events is not None:  # even steps time the gradient pass, odd steps the logging pass (one-shot hooks)
+                lib.xfmr_sampled_loss_profile_pass(events.pairs[i][0], events.pairs[i][1],
+                                                   N.PROFILE_LOGGING_PASS if (i & 1) else N.PROFILE_GRADIENT_PASS)
+            loss, out = step(i, from_host)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item()), loss, out
+
+    # cold rate: what a run WITHOUT the spin-up would report (--warmup steps, then --steps steps timed)
+    for i in range(args.warmup):
+        step(i)
+    cold_s, _, _ = timed(args.steps)
     for i in range(args.spinup_steps):  # device spin-up (clocks, caches, allocator pools): untimed, not the warmup
         step(i)
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     ev = HipEvents(args.steps)
-    lib = N.load()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        lib.xfmr_sampled_loss_profile_next(ev.pairs[i][0], ev.pairs[i][1])
-        loss, out = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, loss, out = timed(args.steps, ev)
+    h2d_s, _, _ = timed(args.steps, None, from_host=True)
+    staged.clear()
 
     stats = out["stats/device"].tolist()
     n_valid, n_query = stats[N.STAT["n_valid"]], stats[N.STAT["n_query"]]
-    kern_ms = ev.elapsed_ms()
-    kern_avg = sum(kern_ms) / max(len(kern_ms), 1)
-    # Executed = algorithmic flops of THIS kernel: columns are the distinct negative items (<= min(N, V): in-batch
+    n_cols = stats[N.STAT["neg_distinct"]]
+    grad_ms = ev.elapsed_ms({i for i in range(args.steps) if not (i & 1)})
+    log_ms = ev.elapsed_ms({i for i in range(args.steps) if (i & 1)}) if not args.lean else []
+    grad_avg = sum(grad_ms) / max(len(grad_ms), 1)
+    log_avg = sum(log_ms) / max(len(log_ms), 1)
+    peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+    # Executed = algorithmic flops of THESE kernels: their columns are the distinct negative items (<= min(N, V): in-batch
     # negatives repeat items and every per-column term is a function of the item; the north star's "batch x seq x
     # item-catalogue" GEMM). The reference's materialised form scores all N sampled columns: its count is reported
     # beside it, it is not a hardware rate.
-    n_cols = stats[N.STAT["neg_distinct"]]
-    flops = 4.0 * n_query * n_cols * H
-    flops_reference = 4.0 * n_query * n_valid * H
-    achieved = flops / (kern_avg * 1e-3) / 1e12 if kern_avg > 0 else 0.0
-    peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
-    traffic = mfma_busy = None
-    pmc = ROOT / "profiles" / "loss_main_traffic.json"
-    if pmc.exists():
-        try:
-            rec = json.loads(pmc.read_text())
-            if rec.get("batch") == B and rec.get("precision") == args.precision:
-                traffic = rec.get("hbm_bytes_per_launch")
-                mfma_busy = rec.get("mfma_busy_fraction")
-        except Exception:  # noqa: BLE001
-            traffic = mfma_busy = None
+    grad_flops = 4.0 * n_query * n_cols * H
+    log_flops = 2.0 * n_query * n_cols * H
+    ref_form_flops = 4.0 * n_query * n_valid * H
+
+    def kernel_entry(name, flops, avg_ms, n):
+        tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        return {"kernel": name, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(tf / peak, 5), "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops,
+                "launches_timed": n}
+
+    k_grad = kernel_entry("loss_main_dma_kernel, gradient pass (logit GEMM + fused epilogue + dQ GEMM)", grad_flops,
+                          grad_avg, len(grad_ms))
+    k_log = kernel_entry("loss_main_dma_kernel, logging pass (six logging heads + LogitsStatistics, values only; "
+                         "VALU-issue-bound: profiles/)", log_flops, log_avg, len(log_ms))
+    dominant = k_log if (log_avg > grad_avg and log_ms) else k_grad
+    # whole step: executed flops of the encoder (fwd + bwd, valid tokens) and of the two loss passes / step time
+    step_ms = elapsed / args.steps * 1e3
+    enc_flops = n_valid * encoder_flops_per_token(tokens_per_seq, H, args.inter, args.layers)
+    step_flops = enc_flops + grad_flops + (log_flops if log_ms else 0.0)
+    step_tf = step_flops / (step_ms * 1e-3) / 1e12
+    static = static_profile("r02_bench_static.json") or {}
 
     if rank == 0:
         seqs = B * world * args.steps
+        roofline = dict(dominant)
+        roofline |= {
+            "traffic": static.get("dominant_kernel_hbm_bytes_per_launch"),
+            "traffic_source": static.get("source") if static.get("dominant_kernel_hbm_bytes_per_launch") else None,
+            "columns": int(n_cols), "sampled_negative_columns": int(n_valid),
+            "reference_form_flops_per_launch": ref_form_flops,
+            "kernels": [k_grad] + ([k_log] if log_ms else []),
+            "step": {"executed_flops": step_flops, "achieved": round(step_tf, 1), "unit": "TFLOP/s", "peak": peak,
+                     "frac": round(step_tf / peak, 4),
+                     "note": "encoder fwd+bwd on valid tokens + both loss passes, / ms_per_step"},
+            "gemm_family_tbps": static.get("gemm_family_tbps"),
+            "gemm_family_tbps_source": static.get("source") if static.get("gemm_family_tbps") else None,
+            "hbm_peak_tbps": PEAK_HBM_TBPS,
+        }
         result = {
             "metric": METRIC,
             "value": round(seqs / elapsed, 2),
@@ -281,7 +460,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "spinup_steps": args.spinup_steps,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(step_ms, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -298,16 +477,12 @@ def main():
                 "dropout": 0.0 if args.no_dropout else 0.1, "parallelism": f"dp{world}",
                 "final_loss": round(float(loss.detach()), 4),
             },
-            "roofline": {
-                "kernel": "loss_main_dma_kernel (gradient pass of the fused sampled loss)", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
-                "hbm_gbps": None if traffic is None or kern_avg <= 0 else round(traffic / (kern_avg * 1e-3) / 1e9, 1),
-                "mfma_busy_fraction_pmc": mfma_busy,
-                "avg_launch_ms": round(kern_avg, 4), "algorithmic_flops_per_launch": flops,
-                "columns": int(n_cols), "sampled_negative_columns": int(n_valid),
-                "reference_form_flops_per_launch": flops_reference,
-                "launches_timed": len(kern_ms),
-            },
+            "h2d_inclusive": {"value": round(seqs / h2d_s, 2), "ms_per_step": round(h2d_s / args.steps * 1e3, 4),
+                              "note": "same timed region with every step's 3 x (B, L) int64 index tensors copied from "
+                                      "pinned host memory (copy stream, one batch ahead of the compute stream)"},
+            "cold_start": {"value": round(seqs / cold_s, 2), "ms_per_step": round(cold_s / args.steps * 1e3, 4),
+                           "note": f"the first {args.steps} steps after {args.warmup} warm-up steps only, before the spin-up"},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)

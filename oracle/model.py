@@ -127,6 +127,12 @@ class OracleTrainer:
         )
 
     def training_step(self, batch):
+        if not self.faithful and not self.kw.get("is_normalized"):
+            # 'reference-lean' (BASELINE.md section 3): only the train head, GEMM-form logits, no statistics
+            loss = lean_loss(self.params, self.table, batch, num_heads=self.kw["num_heads"],
+                             max_seq_length=self.kw["max_seq_length"], kind=self.train_loss, loss_cfg=self.loss_cfg,
+                             dropout_p=self.dropout_p)
+            return loss, {f"loss/{self.train_loss}": loss}
         kinds = L.LOSS_KINDS if self.faithful else (self.train_loss,)
         out = compute_losses(
             self.params, self.table, batch, loss_cfg=self.loss_cfg, kinds=kinds,

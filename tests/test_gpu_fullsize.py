@@ -218,8 +218,9 @@ def test_config2_encoder_with_layernorm_in_the_gemm_epilogues_equals_the_separat
     assert torch.isfinite(tok_f).all() and torch.isfinite(grad_f).all()
     assert rel_l2(tok_f, tok_u) <= 2e-3   # bf16 copies of LayerNorm outputs differ in the last bit now and then
     assert rel_l2(grad_f, grad_u) <= 5e-3
-    # run-to-run bit equality at the benchmark's size (6 400 workgroups of fused kernels per pass): an earlier build of
-    # the fused epilogues that kept row values in AGPRs across barriers got single rows wrong in ~40 % of the launches
+    # run-to-run bit equality at the benchmark's size (6 400 workgroups of fused kernels per pass): builds of the fused
+    # LayerNorm-backward epilogue that contained packed-fp32 op_sel broadcasts got single rows wrong in most launches
+    # (the build rejects that instruction form now: scripts/check_isa.py)
     for _ in range(reps):
         tok_f2, grad_f2 = run()
         assert torch.equal(tok_f, tok_f2) and torch.equal(grad_f, grad_f2)

@@ -145,6 +145,42 @@ def _encoder_shape_vs_oracle(X, prec, *, B, L, H, A, I, nL, V, lengths):
         assert_close(k, got[k], p.grad, prec, "grad")
 
 
+@pytest.mark.parametrize("mode,normalized", [("mean", False), ("max", True), ("cls", True), ("lasttoken", True)])
+def test_encode_drops_unknown_ids_and_pooling_normalize_through_forward(X, mode, normalized):
+    """`encode(item_ids)` (models.py:347-364): ids -> rows through id2idx, unknown ids dropped, the pooled embedding of
+    the remaining history; `forward` applies `pooling_mode` and, with `is_normalized`, the Normalize module
+    (models.py:143-147) -- against the oracle's encoder + pooling on the same rows. (max / cls / lasttoken follow the
+    oracle's restatement of sentence-transformers Pooling: parity unpinned for those modes)"""
+    import torch.nn.functional as F
+
+    from oracle import encoder as enc
+    from oracle import model as OM
+
+    H, A, I, nL, L, V = 64, 2, 96, 2, 16, 30
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn(V, H, generator=g)
+    ids = [f"item-{i}" for i in range(V)]
+    cfg = X.ModelConfig(hidden_size=H, num_attention_heads=A, intermediate_size=I, num_hidden_layers=nL, max_seq_length=L,
+                        pooling_mode=mode, is_normalized=normalized)
+    m = X.RecommenderModel(cfg, device=DEV, precision="fp32").eval()
+    m.configure_embeddings({"item_id": ids, "embedding": emb.numpy()})
+    assert m.embeddings.is_cuda and m.table_rnorm is not None and torch.all(m.embeddings[0] == 0)
+    history = ["item-3", "no-such-item", "item-17", "item-3", "???", "item-29"]
+    got = m.encode(history)
+    rows = torch.tensor([[4, 18, 4, 30]])  # item i of the dataset is row i + 1; the two unknown ids are gone
+    assert torch.equal(got, m(rows.to(DEV))["sentence_embedding"][0])
+    params = {k: v.detach().cpu() for k, v in m.encoder_state_dict().items()}
+    table = torch.cat([torch.zeros(1, H), emb])
+    ref = OM.forward(params, table, rows, num_heads=A, max_seq_length=L)
+    want = enc.pool(ref["token_embeddings"], ref["attention_mask"], mode)[0]
+    if normalized:
+        want = F.normalize(want, p=2, dim=0)
+    assert_close(f"encode[{mode}]", got, want, "fp32")
+    # a longer history than max_seq_length keeps its last L items (models.py:334-337)
+    long_hist = [f"item-{i % V}" for i in range(40)]
+    assert torch.equal(m.encode(long_hist), m.encode(long_hist[-L:]))
+
+
 def test_truncation_to_max_seq_length(X):
     """models.py:334-337: only the last max_seq_length items are encoded."""
     H, V = 64, 40
@@ -497,8 +533,10 @@ def test_reference_default_lightning_config_trains(X, prec, train_loss):
         opt.step()
         tr.opt.step()
     if prec == "fp32":
+        # three AdamW steps of lr 1e-3: early Adam moves every element by ~lr * sign(g), so an element whose gradient is
+        # rounding noise around 0 may differ by a fraction of a step; 1e-4 = 3 % of the total movement
         for k, v in mod.model.encoder_state_dict().items():
-            assert (v.cpu() - tr.params[k].detach()).abs().max().item() <= 3e-5, k
+            assert (v.cpu() - tr.params[k].detach()).abs().max().item() <= 1e-4, k
 
 
 @pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"])

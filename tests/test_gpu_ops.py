@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import assert_close
+from helpers import assert_close, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -321,6 +321,56 @@ def test_linear_with_layernorm_in_the_epilogue(ops, K, M, p_drop, bf16_storage):
     torch.testing.assert_close(rstd, rstd_ref, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(y, y_ref, rtol=1e-5, atol=2e-6)
     assert torch.equal(y16, y.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("Nn,p_drop", [(512, 0.1), (384, 0.0)])  # FFN1 dX (+ LayerNorm 1) / QKV dX (+ LayerNorm 2)
+def test_dx_gemm_with_layernorm_backward_epilogue_vs_separate_kernels_and_bit_reproducible(ops, Nn, p_drop):
+    """xf_linear_bwd_dx_lnbwd_ex (the dX GEMM whose epilogue applies the LayerNorm backward of the row it produces)
+    against the two-kernel form, at the benchmark's row count, and bit-for-bit equal over repeated launches. Builds of
+    this epilogue that contained packed-fp32 `op_sel` broadcasts returned 1-5 wrong rows of 102 400 in most launches
+    (scripts/probe/lnbwd_determinism.py is the long form of this test)."""
+    import ctypes as C
+
+    from xfmr_rec_amd import _native as N
+
+    lib = N.load()
+    M, K = 102400, 128
+    g = torch.Generator().manual_seed(Nn)
+    dy = torch.randn(M, Nn, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(Nn, K, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    rg = torch.randn(M, K, generator=g).to(DEV)
+    lnx = torch.randn(M, K, generator=g).to(DEV)
+    mean = lnx.mean(-1).contiguous()
+    rstd = (lnx.var(-1, unbiased=False) + 1e-12).rsqrt().contiguous()
+    gamma = (1 + 0.1 * torch.randn(K, generator=g)).to(DEV)
+    fn = lib.xf_linear_bwd_dx_lnbwd_ex
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [
+        C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int32,
+        C.c_uint32, C.c_void_p, C.c_float, C.c_uint32]
+
+    def run():
+        dx = torch.empty(M, K, device=DEV)
+        d16 = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+        parts = torch.zeros((M + 63) // 64, 3, K, device=DEV)
+        blocks = C.c_int(0)
+        rc = fn(N.ptr(dy), N.ptr(w), M, Nn, K, N.ptr(rg), N.ptr(lnx), N.ptr(mean), N.ptr(rstd), N.ptr(gamma), p_drop, 5,
+                9, N.ptr(dx), N.ptr(d16), N.ptr(parts), C.byref(blocks), N.precision_id("bf16"), 3, N.stream(), 0.0, 0)
+        assert rc == 0 and blocks.value == (M + 63) // 64
+        return dx, d16, parts
+
+    dx, d16, parts = run()
+    # the separate kernels: dX GEMM (+ residual gradient), then the LayerNorm backward kernel with the same dropout
+    dpre = ops.linear_bwd_dx(dy.float(), w.float(), residual_grad=rg, precision="bf16")
+    dx_ref, dlin_ref, dg_ref, db_ref, dbias_ref = ops.layernorm_bwd(dpre, lnx, mean, rstd, gamma, dropout_p=p_drop, seed=5, site=9)
+    assert rel_l2(dx, dx_ref) <= 1e-5
+    if p_drop > 0:
+        assert rel_l2(d16.float(), dlin_ref) <= 4e-3  # bf16 copy
+    assert rel_l2(parts[:, 0].sum(0), dg_ref) <= 1e-4 and rel_l2(parts[:, 1].sum(0), db_ref) <= 1e-4
+    assert rel_l2(parts[:, 2].sum(0), dbias_ref) <= 1e-4
+    for _ in range(8):
+        dx2, d162, parts2 = run()
+        assert torch.equal(dx, dx2) and torch.equal(d16, d162) and torch.equal(parts, parts2)
 
 
 def test_adamw_matches_torch(ops):

@@ -225,3 +225,105 @@ def test_bench_presets_name_the_baseline_configs(monkeypatch):
     a = bench.parse()
     assert (a.items, a.seq_len, a.hidden, a.loss) == (1_000_000, 512, 256, "AlignmentContrastiveLoss")
     assert bench.METRIC.startswith("user-sequences/sec")
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus N` started as ONE process must start N ranks itself (torch.distributed.run, one process
+    per GPU) and relay rank 0's line; a world size that disagrees with --gpus is an error, never a silent 1-GPU run
+    reported as N. XFMR_BENCH_DRY=1 runs the rank control flow (rendezvous, barrier, SUM all-reduce, MAX timing) over
+    gloo without a GPU."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, XFMR_BENCH_DRY="1", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE line, printed by rank 0
+    assert lines[0]["n_gpus"] == 2 and lines[0]["allreduce_ok"] is True and lines[0]["dry"] is True
+    # launched as a single rank of a 1-rank world but asked to report 2 GPUs: refused
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+# ----------------------------------------------------------------------------------------- drop-in surface (CPU)
+def _small_module(seed=0):
+    import xfmr_rec_amd as X
+
+    conf = X.LightningConfig(hidden_size=64, num_attention_heads=2, intermediate_size=96, num_hidden_layers=2,
+                             max_seq_length=12)
+    mod = X.RecommenderLightningModule(conf)
+    mod.model = X.RecommenderModel(conf, device="cpu", seed=seed)
+    return mod
+
+
+def test_lightning_state_dict_roundtrip_and_reference_keyed_checkpoint():
+    """state_dict() -> load_state_dict() must reproduce the flat parameter buffer bit for bit (resume / load of a
+    checkpoint), and a reference-keyed dict (trainer.py:352-362: every HF BERT tensor under model.model.0.auto_model.,
+    including word_embeddings and the pooler, without the table) must load too."""
+    from oracle import encoder as enc
+
+    a, b = _small_module(seed=1), _small_module(seed=2)
+    assert not torch.equal(a.model.flat, b.model.flat)
+    sd = a.state_dict()
+    assert "model.flat" not in sd and "model.embeddings.weight" not in sd
+    assert all(k.startswith("model.model.0.auto_model.") for k in sd)
+    res = b.load_state_dict(sd)  # strict
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(a.model.flat, b.model.flat)
+    # a checkpoint written by the reference: HF BertModel keys incl. the tensors this build does not keep
+    ref = {f"model.model.0.auto_model.{k}": v for k, v in enc.init_params(64, 2, 96, 12, seed=7).items()}
+    ref["model.model.0.auto_model.embeddings.word_embeddings.weight"] = torch.zeros(1, 64)
+    ref["model.model.0.auto_model.pooler.dense.weight"] = torch.zeros(64, 64)
+    ref["model.model.0.auto_model.pooler.dense.bias"] = torch.zeros(64)
+    c = _small_module(seed=3)
+    res = c.load_state_dict(ref, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in c.model.encoder_state_dict().items():
+        assert torch.equal(v, ref["model.model.0.auto_model." + k]), k
+    # genuinely missing / unknown tensors are reported, and raise when strict
+    part = dict(ref)
+    gone = "model.model.0.auto_model.encoder.layer.1.output.dense.weight"
+    del part[gone]
+    part["model.model.0.auto_model.encoder.layer.9.output.dense.weight"] = torch.zeros(64, 96)
+    with pytest.raises(RuntimeError, match="missing keys"):
+        c.load_state_dict(part, strict=True)
+    res = c.load_state_dict(part, strict=False)  # what Lightning does (strict_loading = False, trainer.py:129)
+    assert res.missing_keys == [gone] and len(res.unexpected_keys) == 1
+    bad = dict(ref)
+    bad[gone] = torch.zeros(3, 3)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        c.load_state_dict(bad)
+
+
+def test_configure_embeddings_builds_the_padded_table_and_id2idx():
+    """models.py:234-259: a zero padding row is inserted in front (item i of the dataset is row i + 1), the embedding
+    width must equal hidden_size (no projection: models.py:336-345), id2idx maps item_id -> row; both a
+    datasets.Dataset (the reference's type) and a plain mapping are accepted; a second call changes nothing."""
+    import datasets
+    import numpy as np
+
+    import xfmr_rec_amd as X
+
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn(7, 64, generator=g)
+    ids = [f"m{i}" for i in (5, 3, 11, 2, 8, 13, 1)]
+    cfg = X.ModelConfig(hidden_size=64, num_attention_heads=2, intermediate_size=64, num_hidden_layers=1, max_seq_length=8)
+    for ds in (datasets.Dataset.from_dict({"item_id": ids, "embedding": emb.tolist()}),
+               {"item_id": ids, "embedding": emb.numpy()}):
+        m = X.RecommenderModel(cfg, device="cpu")
+        m.configure_embeddings(ds)
+        assert m.embeddings.shape == (8, 64) and m.embeddings.dtype == torch.float32
+        assert torch.all(m.embeddings[0] == 0)
+        torch.testing.assert_close(m.embeddings[1:], emb, rtol=1e-6, atol=1e-7)
+        assert [int(m.id2idx[i]) for i in ids] == list(range(1, 8))
+        before = m.embeddings
+        m.configure_embeddings({"item_id": ["x"], "embedding": np.zeros((1, 64), np.float32)})  # already configured
+        assert m.embeddings is before and int(m.id2idx["m5"]) == 1
+    m = X.RecommenderModel(cfg, device="cpu")
+    with pytest.raises(ValueError, match="width 32 != hidden_size 64"):
+        m.configure_embeddings({"item_id": ids, "embedding": np.zeros((7, 32), np.float32)})

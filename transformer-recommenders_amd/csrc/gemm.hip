@@ -12,24 +12,6 @@
 
 #include "internal.h"
 
-// The LayerNorm-fused epilogues take the accumulator tile into VGPRs BEFORE they issue their operand loads (and before
-// the transposition stores): with the default launch bound hipcc keeps the accumulators in AGPRs and stores them to LDS
-// straight from there (ds_write_b32 v, aN) while the epilogue's 16 global loads are in flight -- single output rows then
-// came out wrong in ~1 of 500 workgroups (cause, the three diagnostic builds that isolate it, and
-// scripts/probe/lnbwd_determinism.py). XF_LN_DIAG & 1 (diagnostic builds only) drops the copy again.
-#if defined(XF_LN_DIAG) && (XF_LN_DIAG & 1)
-#define XF_ACC_TO_VGPRS(dst, src) const f32x16(&dst)[NI] = src
-#else
-#define XF_ACC_TO_VGPRS(dst, src)                       \
-  f32x16 dst[NI];                                       \
-  _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_) {   \
-    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) { \
-      float t_ = src[j_][r_];                           \
-      asm volatile("" : "+v"(t_));                      \
-      dst[j_][r_] = t_;                                 \
-    }                                                   \
-  }
-#endif
 // A per-row scalar that is broadcast into packed-fp32 arithmetic (v_pk_add/mul/fma_f32 on register pairs) is made
 // opaque right before its use: hipcc otherwise packs NEIGHBOURING rows' scalars (mean[ps], mean[ps + 1]) into one
 // 64-bit register and broadcasts the odd one with op_sel:[..] (the LOW result lane reads the HIGH dword). Every build
@@ -37,7 +19,7 @@
 // the passes that used them; every build without one was bit-reproducible (DESIGN.md section 4 has the table).
 #define XF_PIN_SCALAR(x) asm volatile("" : "+v"(x))
 #ifndef XF_LN_DIAG
-#define XF_LN_DIAG 0  // diagnostic variants of the LayerNorm-fused epilogues (scripts/probe/lnbwd_determinism.py); never set in the product build
+#define XF_LN_DIAG 0  // 32 (with -DXF_LN_EPI_MIN_WAVES=1): the unpinned build that reproduces the fault (scripts/probe/lnbwd_determinism.py)
 #endif
 #ifndef XF_LN_EPI_MIN_WAVES
 #define XF_LN_EPI_MIN_WAVES 3  // launch bound (waves per SIMD) of the two LayerNorm-fused epilogues: DESIGN.md section 4
@@ -280,9 +262,10 @@ __device__ __forceinline__ TileIdx tile_of(const int nt_n, const int nt_m, const
 // S = XF_S16_* storage mask (compile time: a runtime switch between the fp32 and bf16 load paths cost the
 // forward / dX GEMMs 15-80 %).
 template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S>
-// (The two LayerNorm-fused epilogues are held to <= 170 registers: with the default bound hipcc parked their row
-//  values in AGPRs across the workgroup barriers and single rows came out slightly wrong in ~40 % of the launches --
-//  not reproducible once no AGPR copies are involved; tests/test_gpu_fullsize.py checks run-to-run bit equality.)
+// (Launch bound of the two LayerNorm-fused epilogues: three waves per SIMD -- a speed choice, 129.4 k against 127.6 k
+//  sequences/s with the default bound. Round 1 believed this bound was what made them run-to-run deterministic; the
+//  cause was the packed-fp32 op_sel form described at XF_PIN_SCALAR above, which the default-bound schedule happened
+//  to contain and this one did not. With the scalars pinned, both bounds are bit-reproducible.)
 __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? XF_LN_EPI_MIN_WAVES : 1) void gemm_kernel(GemmArgs g) {
   using elem = typename P::elem;
   using TileA = OperandTile<P, BM, BK, TA>;
@@ -371,7 +354,6 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
       // The wave owns 32 rows x 64 columns; a row's other 64 columns are with the partner wave (wc ^ 1). Lane ->
       // (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3): 16 lanes per row, 8 rows per lane, all kept in registers.
       constexpr int LPRL = 16, RPPL = 4, NPL = 4;
-      XF_ACC_TO_VGPRS(accv, acc[0]);
       float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
       float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 wr][2 wc][32 rows] x 2 (sum, sumsq)
       const int prow = lane / LPRL, li = lane % LPRL, c0 = li * 4;
@@ -392,7 +374,7 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
         for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int r = 0; r < 8; ++r)
-            scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = accv[j][8 * hf + r];
+            scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[0][j][8 * hf + r];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -478,7 +460,6 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
       // Same lane map as EPI_DROP_RES_LN: lane -> (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3). A half strip
       // (16 rows) at a time: the two row sums of the LayerNorm backward are exchanged with the partner wave per half.
       constexpr int LPRL = 16, RPPL = 4, NPL = 4;
-      XF_ACC_TO_VGPRS(accv, acc[0]);
       float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
       float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 hf][2 wr][2 wc][16 rows][2]
       float* const colred = red + 2 * 2 * 2 * 16 * 2;                       // [2 wr][3][128]
@@ -507,14 +488,11 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
             rs[ps] = g.lnb_rstd[m];
           }
         }
-#if XF_LN_DIAG & 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic builds only: no load in flight beside the stores
-#endif
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int r = 0; r < 8; ++r)
-            scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = accv[j][8 * hf + r];
+            scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[0][j][8 * hf + r];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         float4 gv[NPL], xh[NPL];
@@ -545,18 +523,9 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
           gv[ps] = gg; xh[ps] = h;
           const float s1 = row_reduce((gg.x + gg.y) + (gg.z + gg.w));
           const float s2 = row_reduce((gg.x * h.x + gg.y * h.y) + (gg.z * h.z + gg.w * h.w));
-#if XF_LN_DIAG & 8
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // diagnostic: the shuffles land before EXEC narrows
-#endif
           if (li == 0) {
             float* rp = red + ((((hf * 2 + wr) * 2 + wc) * 16) + row) * 2;
             rp[0] = s1; rp[1] = s2;
-#if XF_LN_DIAG & 4
-            if (g.C2 && m < g.M) {  // diagnostic dump: this wave's half-row sums and the row's statistics as used
-              float* db = reinterpret_cast<float*>(g.C2) + (m * 2 + wc) * 8;
-              db[0] = s1; db[1] = s2; db[6] = mu[ps]; db[7] = rs[ps];
-            }
-#endif
           }
         }
         __syncthreads();  // (also: the scratch strip may be overwritten by the next half)
@@ -568,18 +537,6 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
           const float* r1 = red + ((((hf * 2 + wr) * 2 + 1) * 16) + row) * 2;
           const float mg = (r0[0] + r1[0]) * (1.f / 128.f), mgx = (r0[1] + r1[1]) * (1.f / 128.f);
           if (m >= g.M) continue;
-#if XF_LN_DIAG & 4
-          if (g.C2 && li == 0) {  // ... and the four exchanged values as this wave read them back
-            float* db = reinterpret_cast<float*>(g.C2) + (m * 2 + wc) * 8;
-            db[2] = r0[0]; db[3] = r0[1]; db[4] = r1[0]; db[5] = r1[1];
-          }
-#endif
-#if XF_LN_DIAG & 16
-          if (g.C2 && li == 0) {  // light dump (second loop only): the row's exchanged sums and statistics as used
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C2) + (m * 2 + wc) * 8) =
-                make_float4(mg * 128.f, mgx * 128.f, rs[ps], xh[ps].x);
-          }
-#endif
           const float4 gg = gv[ps], h = xh[ps];
           float4 d;
           d.x = rs[ps] * (gg.x - mg - h.x * mgx); d.y = rs[ps] * (gg.y - mg - h.y * mgx);
@@ -917,10 +874,6 @@ int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
 
 }  // namespace
 
-#if XF_LN_DIAG & (4 | 16)
-static void* g_xf_diag_buf = nullptr;  // diagnostic builds only: [M][2 column halves][8] floats (see EPI_DX_LNBWD)
-extern "C" void xf_diag_set_buffer(void* p) { g_xf_diag_buf = p; }
-#endif
 
 extern "C" {
 
@@ -1023,9 +976,6 @@ int xf_linear_bwd_dx_lnbwd_ex(const void* dy, const float* w, int64_t M, int32_t
   g.lnb_partials = partials;
   g.drop2 = xf_make_dropout(out_dropout_p, seed, out_site);
   *blocks_out = (int)((M + 63) / 64);
-#if XF_LN_DIAG & (4 | 16)
-  g.C2 = g_xf_diag_buf;
-#endif
   return dispatch_gemm<false, true, EPI_DX_LNBWD, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, 1, precision, st);
 }
 

@@ -21,6 +21,7 @@ PREC_F32, PREC_BF16 = 0, 1
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES = 0, 1, 2
 NEG_SHARED, NEG_CATALOG = 0, 1
+PROFILE_GRADIENT_PASS, PROFILE_LOGGING_PASS = 0, 1  # xfmr_sampled_loss_profile_pass
 NUM_LOSSES, NUM_STATS = 7, 16
 LOSS_IDS = {
     "AlignmentLoss": 0,

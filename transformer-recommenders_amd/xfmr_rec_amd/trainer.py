@@ -332,6 +332,45 @@ class RecommenderLightningModule(_Base):
                 sd[f"model.model.0.auto_model.{k}"] = v
         return sd
 
+    _ENC_PREFIX = "model.model.0.auto_model."
+    # tensors a reference checkpoint carries that this build has no use for (never trained on this path: SURVEY F12)
+    _IGNORED_ENC_KEYS = ("embeddings.word_embeddings.weight", "embeddings.position_ids", "embeddings.token_type_ids",
+                         "pooler.dense.weight", "pooler.dense.bias")
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Inverse of :meth:`state_dict`: HF-keyed encoder tensors under ``model.model.0.auto_model.`` -- this build's
+        checkpoints and the reference's (``trainer.py:352-362`` only pops the table) -- go back into the flat buffer.
+        Returns torch's ``(missing_keys, unexpected_keys)``; ``strict=True`` raises on either, as ``nn.Module`` does.
+        Lightning resumes with ``strict_loading=False`` (``trainer.py:129``), i.e. ``strict=False``."""
+        from torch.nn.modules.module import _IncompatibleKeys
+
+        if self.model is None:
+            self.configure_model()
+        pre = self._ENC_PREFIX
+        enc = {k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre)}
+        views = self.model.encoder_state_dict()
+        if "model.flat" in state_dict and not enc:  # a raw dump of the flat buffer
+            flat = torch.as_tensor(state_dict["model.flat"])
+            if flat.shape != self.model.flat.shape:
+                raise RuntimeError(f"model.flat: shape {tuple(flat.shape)} != {tuple(self.model.flat.shape)}")
+            with torch.no_grad():
+                self.model.flat.copy_(flat.to(self.model.flat.device, torch.float32))
+            enc = {k: None for k in views}
+        missing = [pre + k for k in views if k not in enc]
+        unexpected = [pre + k for k in enc if k not in views and k not in self._IGNORED_ENC_KEYS]
+        unexpected += [k for k in state_dict if not k.startswith(pre) and k not in ("model.flat", "model.embeddings.weight")]
+        bad_shape = [pre + k for k, v in enc.items() if k in views and v is not None
+                     and tuple(torch.as_tensor(v).shape) != tuple(views[k].shape)]
+        if bad_shape:
+            raise RuntimeError(f"size mismatch for {bad_shape[:4]}")
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing keys {missing[:4]}{'...' if len(missing) > 4 else ''}, "
+                               f"unexpected keys {unexpected[:4]}{'...' if len(unexpected) > 4 else ''}")
+        self.model.load_encoder_state_dict({k: v for k, v in enc.items() if v is not None and k in views}, strict=False)
+        if "model.embeddings.weight" in state_dict:  # a checkpoint that kept the table (not the reference's): install it
+            self.model.set_table(torch.as_tensor(state_dict["model.embeddings.weight"]).to(self.model.device, torch.float32))
+        return _IncompatibleKeys(missing, unexpected)
+
     def save(self, path) -> None:
         assert self.model is not None
         self.model.save(str(path))
