@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Isolated timing of the two passes of the fused sampled loss at the bench shape (nothing else on the GPU):
+    python scripts/bench_logging.py [--batch 512] [--hidden 128] [--items 3883] [--reps 20]
+HIP events around the kernel through xfmr_sampled_loss_profile_pass. XFMR_HIP_LIB selects another build for A/B runs."""
+import argparse
+import ctypes
+import pathlib
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+for p in (ROOT, ROOT / "transformer-recommenders_amd"):
+    sys.path.insert(0, str(p))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--seq-len", type=int, default=200)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--items", type=int, default=3883)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--head", default="InfoNCELoss")
+    args = ap.parse_args()
+    from xfmr_rec_amd import _native as N
+    from xfmr_rec_amd import ops
+
+    dev = "cuda"
+    B, L, H, V = args.batch, args.seq_len, args.hidden, args.items
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(V + 1, H, generator=g)
+    table = table / table.norm(dim=-1, keepdim=True)
+    table[0] = 0
+    table = table.to(dev)
+    rn, tb = ops.table_prepare(table)
+    tok = torch.randn(B * L, H, generator=g).to(dev)
+    mask = torch.ones(B * L, dtype=torch.uint8, device=dev)
+    pos = torch.randint(1, V + 1, (B * L,), generator=g).to(dev)
+    neg = torch.randint(1, V + 1, (B * L,), generator=g).to(dev)
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    lib = N.load()
+    print("library:", N.LIB_PATH)
+    has_pass = hasattr(lib, "xfmr_sampled_loss_profile_pass")
+    n_cols = int(torch.unique(neg).numel())
+    for name, kw, which, flops in (
+        ("gradient pass", dict(all_heads=False, need_grad=True), 0, 4.0 * B * L * n_cols * H),
+        ("logging pass, all 7 heads (-1)", dict(all_heads=True, need_grad=False), 1, 2.0 * B * L * n_cols * H),
+        ("logging pass without the InfoNCE lse (-2)", dict(all_heads=2, need_grad=False), 1, 2.0 * B * L * n_cols * H),
+    ):
+        ms = []
+        for _ in range(args.reps + 3):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            hip.hipEventCreate(ctypes.byref(a)); hip.hipEventCreate(ctypes.byref(b))
+            if has_pass:
+                lib.xfmr_sampled_loss_profile_pass(a, b, which)
+            else:
+                lib.xfmr_sampled_loss_profile_next(a, b)
+            ops.sampled_loss(tok, mask, pos, neg, table, rn, train_head=args.head, precision="bf16", table_bf16=tb, **kw)
+            torch.cuda.synchronize()
+            t = ctypes.c_float()
+            if hip.hipEventElapsedTime(ctypes.byref(t), a, b) == 0:
+                ms.append(t.value)
+        ms = sorted(ms[3:])
+        med = ms[len(ms) // 2]
+        print(f"{name}: median {med * 1e3:.1f} us (min {ms[0] * 1e3:.1f}) -> {flops / (med * 1e-3) / 1e12:.0f} TFLOP/s executed")
+
+
+if __name__ == "__main__":
+    main()

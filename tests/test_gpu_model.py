@@ -536,6 +536,8 @@ def test_reference_default_lightning_config_trains(X, prec, train_loss):
         # three AdamW steps of lr 1e-3: early Adam moves every element by ~lr * sign(g), so an element whose gradient is
         # rounding noise around 0 may differ by a fraction of a step; 1e-4 = 3 % of the total movement
         for k, v in mod.model.encoder_state_dict().items():
+            if k.endswith("key.bias"):  # gradient exactly 0 in exact arithmetic: Adam follows the sign of rounding noise
+                continue
             assert (v.cpu() - tr.params[k].detach()).abs().max().item() <= 1e-4, k
 
 

@@ -233,6 +233,71 @@ __device__ __forceinline__ void loss_epilogue_infonce_pinned(f32x16& s, float& l
   }
 }
 
+// The logging pass in its common case -- false-negative masking on, in-batch (shared) negatives, no top-k -- with the
+// per-logit work cut from ~47 to ~36 issue slots (VALU issue bounds this pass: DESIGN.md section 4):
+//   * an exact tie (the negative IS the positive item) is simply not counted: no logit substitution (with masking on the
+//     substituted value s = pos is never < pos anyway);
+//   * softplus(x) / ln 2 = log2(1 + 2^y), y = x log2(e) clamped at 100 (fp32 cannot tell 1 + 2^y from 2^y beyond y = 24,
+//     and a masked-out logit must stay finite for the multiply by its zero weight): no max / |.| pair, the ln 2 is applied
+//     once per row (st.nce, st.logi hold the log2 sums until loss_logging_masked_finish);
+//   * cosine heads in the query-norm-free form: with sc = s / |e|, c < c_pos <=> sc < pos / |e_pos| and
+//     max(c - 1 + margin, 0) = (1 / |q|) max(sc - (1 - margin) |q|, 0): one multiply per logit, 1 / |q| once per row;
+//   * min / max through NaN (fminf / fmaxf = minNum / maxNum return the other operand): one select for both.
+// HEAD code -3: without the InfoNCE log-sum-exp (its value comes from the gradient pass), -4: with it.
+constexpr int HEAD_LOG_MASKED = -3, HEAD_LOG_MASKED_LSE = -4;
+struct LogConst {
+  float pos_dot, sc2, m, chinge, clog2e /* chinge * log2e */, kpos_c /* pos / |e_pos| */, kappa_c /* (1 - margin) |q| */;
+  int pos_item;
+};
+template <bool CHECK_VALID, bool LSE>
+__device__ __forceinline__ void loss_epilogue_logging_masked(const f32x16& s, RowState& st, const LogConst& k,
+                                                             const int* nid_sb, const float* rc_sb, const float* mu_sb,
+                                                             int hh) {
+  const float qnan = __builtin_nanf("");
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl0 = 8 * g + 4 * hh;
+    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[jl0]);
+    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+    const float4 c4 = *reinterpret_cast<const float4*>(&rc_sb[jl0]);
+    const float rc[4] = {c4.x, c4.y, c4.z, c4.w};
+    const float4 m4 = *reinterpret_cast<const float4*>(&mu_sb[jl0]);
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float sv = s[4 * g + u];
+      bool other = nn[u] != k.pos_item;              // not the positive's own item (past-the-end columns carry -1)
+      if (CHECK_VALID) other &= nn[u] >= 0;
+      const bool cd = (sv < k.pos_dot) & other;
+      const float md = cd ? mu[u] : 0.f;
+      st.cnt_d += md;
+      if (LSE) st.l = fmaf(xf_exp2(fminf(fmaf(sv, k.sc2, -k.m), 0.f)), md, st.l);
+      const float y = sv * kLog2e;
+      st.nce = fmaf(xf_log2(1.f + xf_exp2(fminf(y, 100.f))), md, st.nce);
+      const float d = sv - k.chinge;
+      st.hinge = fmaf(fmaxf(d, 0.f), md, st.hinge);
+      st.logi = fmaf(xf_log2(1.f + xf_exp2(fminf(y - k.clog2e, 100.f))), md, st.logi);
+      const float sc = sv * rc[u];
+      const float mc = ((sc < k.kpos_c) & other) ? mu[u] : 0.f;
+      st.cnt_c += mc;
+      st.contr = fmaf(fmaxf(sc - k.kappa_c, 0.f), mc, st.contr);
+      const float t1 = sv * md;
+      st.ssum += t1;
+      st.ssq = fmaf(t1, sv, st.ssq);
+      const float svm = cd ? sv : qnan;
+      st.smin = fminf(st.smin, svm);
+      st.smax = fmaxf(st.smax, svm);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (as in loss_epilogue_t: one run of four elements at a time)
+  }
+}
+// per row, once: back to natural-log sums and the 1 / |q| of the contrastive term
+__device__ __forceinline__ void loss_logging_masked_finish(RowState& st, float rq) {
+  st.nce *= kLn2;
+  st.logi *= kLn2;
+  st.contr *= rq;
+}
+
 // runtime head -> compile-time head (one wave-uniform switch per sub-block instead of ~6 per element)
 template <bool ALL, bool GRAD, int NO, bool HARD = false>
 __device__ __forceinline__ void loss_epilogue_h(f32x16& s, RowState& st, f32x16 (&o)[NO], const RowConst& k,
