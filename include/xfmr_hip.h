@@ -293,14 +293,18 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
  * H <= 1024, H % 4 == 0): dot / cosine logits (:179-208), target from target_position "first" / "diagonal" or an
  * explicit `target` (N) of column indices (:211-261), false-negative mask (:263-293), top-k hard negatives
  * (:295-330, ties at the k-th logit share the remaining weight), the seven heads + LogitsStatistics, and
- * d_query (N,H) = dL(train_head)/dquery (may be NULL). Candidates are treated as constants (the reference's
- * candidates are rows of the frozen table). cfg->mode and cfg->precision are ignored (fp32 vector arithmetic).
+ * d_query (N,H) = dL(train_head)/dquery (may be NULL). cfg->mode and cfg->precision are ignored (fp32 vector arithmetic).
  * losses[14] / stats[16] as for xfmr_sampled_loss, with N_VALID = C and N_QUERY = N. */
 enum { XFMR_TARGET_FIRST = 0, XFMR_TARGET_DIAGONAL = 1, XFMR_TARGET_EXPLICIT = 2 };
 size_t xfmr_dense_loss_workspace(int64_t N, int32_t C, int32_t H);
 int xfmr_dense_loss(const xfmr_loss_cfg* cfg, const float* query, const float* cand, const int64_t* target,
                     int32_t target_mode, int64_t N, int32_t C, int32_t H, float* losses, float* stats, float* d_query,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* ... and with d_cand (N,C,H) = dL(train_head)/dcandidate_embed (may be NULL): EmbedLoss.forward is differentiable in
+ * both arguments (losses.py:128-155; cosine heads through F.normalize of the candidates, losses.py:196-208). */
+int xfmr_dense_loss_grads(const xfmr_loss_cfg* cfg, const float* query, const float* cand, const int64_t* target,
+                          int32_t target_mode, int64_t N, int32_t C, int32_t H, float* losses, float* stats,
+                          float* d_query, float* d_cand, void* workspace, size_t workspace_bytes, void* stream);
 /* Measurement hook (bench.py) -- the ONE piece of per-host-thread state in the library: the next
  * xfmr_sampled_loss[_lists] call made by THIS host thread records the two hipEvent_t (passed as void*) on its stream
  * immediately before and after one main-kernel launch, then forgets them. Pass NULL, NULL to cancel. No effect on

@@ -5,7 +5,7 @@
 # bench command, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) over scripts/bench_loss.py for the HBM
 # traffic of the dominant kernel. Copy the summaries into profiles/ with scripts/summarize_profiles.py.
 set -eo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -16,11 +16,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
   python3 "$ROOT/bench.py" --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline --overlap off > "$OUT/trace.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_overlap" -o bench -- \
   python3 "$ROOT/bench.py" --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline --overlap on > "$OUT/trace_overlap.log" 2>&1
+# HBM traffic of the two loss passes in isolation (scripts/bench_logging.py): separate --pmc passes, as the guide prescribes
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o loss -- \
-    python3 "$ROOT/scripts/bench_loss.py" --reps 4 > "$OUT/pmc_$c.log" 2>&1
+    python3 "$ROOT/scripts/bench_logging.py" --reps 4 > "$OUT/pmc_$c.log" 2>&1
 done
-# matrix-core busy cycles of the same kernel (its own pass; GRBM_GUI_ACTIVE = cycles the GPU was active)
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
-  -d "$OUT/pmc_MFMA" -o loss -- python3 "$ROOT/scripts/bench_loss.py" --reps 4 > "$OUT/pmc_MFMA.log" 2>&1
+# SQ counters of the same kernels (instruction mix, wait / stall shares, matrix-core busy cycles): two more passes
+"$ROOT/scripts/pmc_loss_passes.sh" "$TAG"
 echo done > "$OUT/DONE"

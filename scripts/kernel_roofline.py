@@ -35,16 +35,27 @@ K = [
     ("ln_bwd_v4_kernel", "LayerNorm bwd (top layer / embedding)", TH * f32 * 3 + TH * b16 / 2, 0),
     ("ln_fwd_v4_kernel<32, true>", "embedding gather + LayerNorm", TH * f32 * 3 + TH * b16, 0),
     ("loss_main_dma_kernel<128, 7>", "loss gradient pass", 0, 4.0 * T * ND * H),
+    ("loss_main_dma_kernel<128, -3>", "loss logging pass (6 heads + statistics; masked fast path)", 0, 2.0 * T * ND * H),
     ("loss_main_dma_kernel<128, -2>", "loss logging pass (6 heads + statistics)", 0, 2.0 * T * ND * H),
     ("loss_combine_kernel", "loss combine", 2 * TH * f32 + TH * f32 + TH * f32, 0),
     ("multi_rowsum_kernel", "split-K slab / partial-record reduction", 0, 0),
     ("scale_kernel", "d_tok *= upstream gradient", 2 * TH * f32, 0),
 ]
 
-rows = list(csv.DictReader(open(sys.argv[1])))
-print("| kernel | launches/step | avg µs | algorithmic MB | TB/s (of 8 nominal; 5–6.6 measured stream) | TFLOP/s (of 2500) |")
-print("|---|---|---|---|---|---|")
-steps = 13
+import argparse
+import json
+
+ap = argparse.ArgumentParser()
+ap.add_argument("csv")
+ap.add_argument("--steps", type=int, default=13)
+ap.add_argument("--json", action="store_true", help="print the GEMM-family summary as JSON instead of the table")
+args = ap.parse_args()
+rows = list(csv.DictReader(open(args.csv)))
+steps = args.steps
+lines = [f"# Achieved rates per kernel of the default bench line (config 2, batch 512): python scripts/kernel_roofline.py {args.csv}", "",
+         "| kernel | launches/step | avg µs | algorithmic MB | TB/s (of 8 nominal; 5–6.6 measured stream) | TFLOP/s (of 2500) |",
+         "|---|---|---|---|---|---|"]
+gemm_bytes = gemm_ns = 0.0
 for frag, desc, nbytes, flops in K:
     hit = [r for r in rows if frag in r["Name"]]
     if not hit:
@@ -54,4 +65,16 @@ for frag, desc, nbytes, flops in K:
     avg = tot / calls / 1e3
     tb = f"{nbytes / (avg * 1e-6) / 1e12:.2f}" if nbytes else "—"
     tf = f"{flops / (avg * 1e-6) / 1e12:.0f}" if flops else "—"
-    print(f"| {desc} (`{frag.strip(', ')}`) | {calls / steps:.1f} | {avg:.1f} | {nbytes / MB:.0f} | {tb} | {tf} |")
+    lines.append(f"| {desc} (`{frag.strip(', ')}`) | {calls / steps:.1f} | {avg:.1f} | {nbytes / MB:.0f} | {tb} | {tf} |")
+    if frag.startswith("gemm_kernel"):
+        gemm_bytes += nbytes * calls / steps
+        gemm_ns += tot / steps
+if args.json:
+    print(json.dumps({"gemm_family_tbps": round(gemm_bytes / (gemm_ns * 1e-9) / 1e12, 3),
+                      "gemm_family_ms_per_step": round(gemm_ns / 1e6, 4),
+                      "gemm_family_compulsory_gb_per_step": round(gemm_bytes / 1e9, 3)}))
+else:
+    lines.append("")
+    lines.append(f"GEMM family: {gemm_bytes / 1e9:.2f} GB of compulsory bytes in {gemm_ns / 1e6:.3f} ms per step = "
+                 f"{gemm_bytes / (gemm_ns * 1e-9) / 1e12:.2f} TB/s")
+    print("\n".join(lines))

@@ -39,8 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
     ap.add_argument("--steps", type=int, default=13)
-    ap.add_argument("--kernel", default="loss_main_dma_kernel<128, 7>")
-    a = ap.parse_args()
+        a = ap.parse_args()
     src = ROOT / "gpurun_out" / a.tag
     prof = ROOT / "profiles"
     line = [l for l in open(src / "bench.json") if l.startswith("{")][-1]
@@ -58,32 +57,37 @@ def main():
         (prof / f"{a.tag}_kernel_stats{suffix}.md").write_text(head + md)
     f = find(src / "pmc_FETCH_SIZE" / "**" / "*counter_collection.csv")
     w = find(src / "pmc_WRITE_SIZE" / "**" / "*counter_collection.csv")
+    static = {"source": f"profiles/{a.tag}_* (rocprofv3 runs of scripts/collect_profiles.sh {a.tag}; static, not measured in the bench run)",
+              "round": a.tag}
+    traffic = {}
     if f and w:
-        fk = pmc_mean(f, "FETCH_SIZE", a.kernel)
-        wk = pmc_mean(w, "WRITE_SIZE", a.kernel)
-        if fk is not None and wk is not None:
-            rec = {
-                "kernel": a.kernel + " (gradient pass of the fused sampled loss)", "batch": 512, "precision": "bf16",
-                "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
-                "correction": "gfx950: FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads -> doubled; "
-                              "WRITE_SIZE exact (MI355X_MICROARCH.md, HBM); separate --pmc passes",
-                "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 scripts/bench_loss.py --reps 4",
-                "round": a.tag,
-            }
-            mf = find(src / "pmc_MFMA" / "**" / "*counter_collection.csv")
-            if mf:
-                busy = pmc_mean(mf, "SQ_VALU_MFMA_BUSY_CYCLES", a.kernel)
-                active = pmc_mean(mf, "GRBM_GUI_ACTIVE", a.kernel)
-                if busy and active:
-                    # SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md), summed
-                    # over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs (8 x the launch's cycles)
-                    rec |= {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": active,
-                            "mfma_instructions_per_launch": busy / 32.0,
-                            "mfma_busy_fraction": busy / (1024.0 * active / 8.0),
-                            "mfma_note": "matrix-core busy cycles summed over 1024 SIMDs / (1024 x active cycles of "
-                                         "the launch, GRBM_GUI_ACTIVE / 8 XCDs); its own --pmc pass"}
-            (prof / "loss_main_traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
-            print(rec)
+        for label, needle in (("gradient_pass", "loss_main_dma_kernel<128, 7>"), ("logging_pass", "loss_main_dma_kernel<128, -3>")):
+            fk, wk = pmc_mean(f, "FETCH_SIZE", needle), pmc_mean(w, "WRITE_SIZE", needle)
+            if fk is not None and wk is not None:
+                traffic[label] = {"kernel": needle, "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
+                                  "hbm_bytes_per_launch": (2 * fk + wk) * 1024}
+        rec = {"batch": 512, "precision": "bf16", "kernels": traffic,
+               "correction": "gfx950: FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads -> doubled; "
+                             "WRITE_SIZE exact (MI355X_MICROARCH.md, HBM); separate --pmc passes",
+               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 scripts/bench_logging.py --reps 4",
+               "round": a.tag}
+        (prof / f"{a.tag}_loss_traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
+        if "logging_pass" in traffic:
+            static["dominant_kernel_hbm_bytes_per_launch"] = traffic["logging_pass"]["hbm_bytes_per_launch"]
+    # GEMM family: compulsory bytes / GPU time of every gemm_kernel launch of one step (scripts/kernel_roofline.py table)
+    stats = prof / f"{a.tag}_kernel_stats.csv"
+    if stats.exists():
+        out = subprocess.run([sys.executable, str(ROOT / "scripts" / "kernel_roofline.py"), str(stats), "--steps", str(a.steps),
+                              "--json"], capture_output=True, text=True, check=True).stdout
+        fam = json.loads(out)
+        static |= fam
+        md = subprocess.run([sys.executable, str(ROOT / "scripts" / "kernel_roofline.py"), str(stats), "--steps", str(a.steps)],
+                            capture_output=True, text=True, check=True).stdout
+        (prof / f"{a.tag}_kernel_roofline.md").write_text(md)
+    (prof / f"{a.tag}_bench_static.json").write_text(json.dumps(static, indent=1) + "\n")
+    pm = subprocess.run([sys.executable, str(ROOT / "scripts" / "summarize_pmc.py"), a.tag, "--out",
+                         str(prof / f"{a.tag}_loss_passes_pmc.md")], capture_output=True, text=True)
+    print(pm.stdout[-400:])
     print("profiles/ updated from", src)
 
 

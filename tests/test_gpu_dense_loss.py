@@ -110,3 +110,26 @@ def test_dense_loss_rejects_what_the_reference_rejects(L):
         L.InfoNCELoss(L.LossConfig(target_position="first"))(q, cand, torch.zeros(4, dtype=torch.long, device=DEV))
     with pytest.raises(AssertionError):  # losses.py:166-177
         L.InfoNCELoss(L.LossConfig())(q, cand[:3])
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(mask_false_negatives=False, scale=4.0, margin=0.2),
+                                 dict(target_position="diagonal"), dict(num_hard_negatives=5)])
+@pytest.mark.parametrize("kind", OL.LOSS_KINDS)
+def test_dense_loss_gradient_wrt_candidates_vs_oracle(L, kind, cfg):
+    """EmbedLoss.forward is differentiable in candidate_embed too (losses.py:128-155; the cosine heads through the
+    normalisation of the candidates, losses.py:196-208): d_candidates against the oracle's autograd, every head, dot and
+    cosine logits, diagonal target, top-k restriction."""
+    g = torch.Generator().manual_seed(21)
+    N, C, H = 9, 23, 48
+    q = torch.randn(N, H, generator=g)
+    cand = torch.randn(N, C, H, generator=g) * torch.rand(N, C, 1, generator=g).add(0.3)  # assorted candidate norms
+    full = dict(target_position="first", mask_false_negatives=True, num_hard_negatives=0, scale=1.0, margin=0.5) | cfg
+    qo, co = q.clone().requires_grad_(True), cand.clone().requires_grad_(True)
+    want = OL.embed_loss(kind, qo, co, None, **full)
+    want.backward()
+    qd, cd = q.to(DEV).requires_grad_(True), cand.to(DEV).requires_grad_(True)
+    got = getattr(L, kind)(L.LossConfig(**full))(qd, cd)
+    assert got.item() == pytest.approx(want.item(), rel=2e-5, abs=1e-5)
+    (2.5 * got).backward()  # an upstream factor reaches both gradients
+    _grad_close(qd.grad.cpu().numpy() / 2.5, qo.grad.numpy(), f"{kind} d_query")
+    _grad_close(cd.grad.cpu().numpy().reshape(N * C, H) / 2.5, co.grad.numpy().reshape(N * C, H), f"{kind} d_candidates")

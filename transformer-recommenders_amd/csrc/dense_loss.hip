@@ -28,6 +28,7 @@ struct DenseArgs {
   int train_head, all_heads, mask_fn, k_hard;
   float scale, margin;
   float* d_query; double* blockpart;
+  float* d_cand;  // (N, C, H) or null: dL(train_head)/dcandidates (losses.py:128-155 is differentiable in them too)
 };
 
 __device__ __forceinline__ unsigned sort_key(float f) {  // monotone: a < b  <=>  key(a) < key(b)
@@ -237,6 +238,42 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(DenseArgs a) {
     for (int k = 0; k < BP; ++k) a.blockpart[(int64_t)k * gridDim.x + blockIdx.x] = acc[k];
   }
 
+  // ---- 4a. gradient of the train head w.r.t. the candidates --------------------------------------------------
+  // dot heads: dL/de_c = a_c q with a_c = dL/ds_c; cosine heads (logits on e_c / max(|e_c|, 1e-8)):
+  // dL/de_c = b_c / |e_c| (q_hat - cos_c e_hat_c), b_c = dL/dcos_c. The masks and the top-k selection are piecewise
+  // constant: no gradient flows through them (the reference's boolean masks / topk indices carry none either).
+  if (a.d_cand) {
+    const bool cosh_c = head <= XFMR_LOSS_CONTRASTIVE;
+    float* dc = a.d_cand + row * (int64_t)C * H;
+    const bool qclamped = sqrtf(qq) < 1e-8f;
+    for (int64_t idx = tid; idx < (int64_t)C * H; idx += 256) {
+      const int c = (int)(idx / H), h = (int)(idx - (int64_t)c * H);
+      float coef;  // dL/d(logit of candidate c), in the head's own logit space
+      const bool is_t = c == tgt;
+      switch (head) {
+        case XFMR_LOSS_INFONCE: coef = is_t ? -a.scale * (1.f - epos / ltot) : a.scale * sW[c] / ltot; break;
+        case XFMR_LOSS_NCE: coef = is_t ? -xf_sigmoid(-pos_dot) : sW[c] * inv_d; break;
+        case XFMR_LOSS_PAIRWISE_HINGE:
+        case XFMR_LOSS_PAIRWISE_LOGISTIC: coef = is_t ? -(1.f - a.margin) * sw * inv_d : sW[c] * inv_d; break;
+        case XFMR_LOSS_ALIGNMENT: coef = is_t ? -1.f : 0.f; break;
+        // sW of the cosine heads carries the candidate's 1/|e| (for the query gradient): take it out again
+        case XFMR_LOSS_CONTRASTIVE: coef = is_t ? 0.f : sW[c] * inv_c * fmaxf(1.f / sRc[c], 1e-8f); break;
+        default: coef = is_t ? -1.f : sW[c] * inv_c * fmaxf(1.f / sRc[c], 1e-8f); break;  // ALIGNMENT_CONTRASTIVE
+      }
+      float g;
+      if (!cosh_c) {
+        g = coef * sQ[h];
+      } else {
+        const float rc = sRc[c], e = cand[idx];
+        const float qh = sQ[h] * rq;  // q_hat (q / max(|q|, 1e-8))
+        const bool cclamped = rc >= 1e8f;  // |e_c| < 1e-8: the norm was clamped, e_hat = e / 1e-8 is linear in e
+        g = cclamped ? coef * rc * qh : coef * rc * (qh - (e * rc) * sCos[c]);
+        (void)qclamped;
+      }
+      dc[idx] = g;
+    }
+  }
+
   // ---- 4. gradient of the train head w.r.t. the query ---------------------------------------------------------
   if (!a.d_query) return;
   const bool cosh = head <= XFMR_LOSS_CONTRASTIVE;
@@ -299,6 +336,13 @@ size_t xfmr_dense_loss_workspace(int64_t N, int32_t C, int32_t H) {
 int xfmr_dense_loss(const xfmr_loss_cfg* cfg, const float* query, const float* cand, const int64_t* target,
                     int32_t target_mode, int64_t N, int32_t C, int32_t H, float* losses, float* stats, float* d_query,
                     void* workspace, size_t workspace_bytes, void* stream) {
+  return xfmr_dense_loss_grads(cfg, query, cand, target, target_mode, N, C, H, losses, stats, d_query, nullptr, workspace,
+                               workspace_bytes, stream);
+}
+
+int xfmr_dense_loss_grads(const xfmr_loss_cfg* cfg, const float* query, const float* cand, const int64_t* target,
+                          int32_t target_mode, int64_t N, int32_t C, int32_t H, float* losses, float* stats,
+                          float* d_query, float* d_cand, void* workspace, size_t workspace_bytes, void* stream) {
   if (!cfg || !query || !cand || !losses || !stats || !workspace || N <= 0 || C <= 0 || H <= 0) return XFMR_EINVAL;
   if (target_mode < XFMR_TARGET_FIRST || target_mode > XFMR_TARGET_EXPLICIT) return XFMR_EINVAL;
   if ((target_mode == XFMR_TARGET_EXPLICIT) != (target != nullptr)) return XFMR_EINVAL;  // losses.py:233-238
@@ -316,7 +360,7 @@ int xfmr_dense_loss(const xfmr_loss_cfg* cfg, const float* query, const float* c
   a.q = query; a.cand = cand; a.target = target; a.target_mode = target_mode; a.N = N; a.C = C; a.H = H;
   a.train_head = cfg->train_head; a.all_heads = cfg->all_heads; a.mask_fn = cfg->mask_false_negatives;
   a.k_hard = cfg->num_hard_negatives; a.scale = cfg->scale; a.margin = cfg->margin;
-  a.d_query = d_query; a.blockpart = blockpart;
+  a.d_query = d_query; a.blockpart = blockpart; a.d_cand = d_cand;
   const size_t smem = ((size_t)H + 4 * (size_t)C + 8) * sizeof(float);
   if (hipFuncSetAttribute((const void*)dense_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
       hipSuccess)

@@ -101,6 +101,8 @@ _SIGNATURES = {
     "xfmr_dense_loss_workspace": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "xfmr_dense_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P,
                                   _P, _P, C.c_size_t, _P]),
+    "xfmr_dense_loss_grads": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P,
+                                        _P, _P, _P, _P, C.c_size_t, _P]),
     "xfmr_sampled_loss_profile_next": (C.c_int, [_P, _P]),
     "xfmr_sampled_loss_profile_pass": (C.c_int, [_P, _P, C.c_int32]),
     "xfmr_table_rnorm": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),

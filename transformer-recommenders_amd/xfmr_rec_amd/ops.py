@@ -262,9 +262,10 @@ def _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, 
 
 
 def dense_loss(query, cand, target=None, *, target_position="first", train_head, all_heads=False,
-               mask_false_negatives=True, num_hard_negatives=0, scale=1.0, margin=0.5, need_grad=True):
+               mask_false_negatives=True, num_hard_negatives=0, scale=1.0, margin=0.5, need_grad=True,
+               need_cand_grad=False):
     """``EmbedLoss.forward`` on a dense (N,C,H) candidate tensor (``losses.py:128-155``):
-    returns (losses[14], stats[16], d_query or None)."""
+    returns (losses[14], stats[16], d_query or None[, d_cand when ``need_cand_grad``])."""
     Nq, H = query.shape
     Cn = cand.shape[1]
     mode = {"first": N.TARGET_FIRST, "diagonal": N.TARGET_DIAGONAL, None: N.TARGET_EXPLICIT}[target_position]
@@ -275,12 +276,13 @@ def dense_loss(query, cand, target=None, *, target_position="first", train_head,
     d_q = torch.empty_like(query) if need_grad else None
     nbytes = lib.xfmr_dense_loss_workspace(Nq, Cn, H)
     ws = _bytes(nbytes, query)
+    d_c = torch.empty_like(cand) if need_cand_grad else None
     N.check(
-        lib.xfmr_dense_loss(C.byref(cfg), N.ptr(query), N.ptr(cand), N.ptr(target), mode, Nq, Cn, H, N.ptr(losses),
-                            N.ptr(stats), N.ptr(d_q), N.ptr(ws), nbytes, N.stream()),
-        "xfmr_dense_loss",
+        lib.xfmr_dense_loss_grads(C.byref(cfg), N.ptr(query), N.ptr(cand), N.ptr(target), mode, Nq, Cn, H, N.ptr(losses),
+                                  N.ptr(stats), N.ptr(d_q), N.ptr(d_c), N.ptr(ws), nbytes, N.stream()),
+        "xfmr_dense_loss_grads",
     )
-    return losses, stats, d_q
+    return (losses, stats, d_q, d_c) if need_cand_grad else (losses, stats, d_q)
 
 
 def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head, all_heads=False,
@@ -425,23 +427,31 @@ class SampledLossListsFunction(torch.autograd.Function):
 
 
 class DenseLossFunction(torch.autograd.Function):
-    """``EmbedLoss.forward`` on dense candidates; gradient w.r.t. the query only (candidates are constants)."""
+    """``EmbedLoss.forward`` on dense candidates, differentiable in the query and -- when they require a gradient -- in
+    the candidates (``losses.py:128-155``)."""
 
     @staticmethod
     def forward(ctx, query, cand, target, opts):
-        need = query.requires_grad
-        losses, stats, d_q = dense_loss(query, cand, target, need_grad=need, **opts)
+        need, need_c = query.requires_grad, cand.requires_grad
+        out = dense_loss(query, cand, target, need_grad=need or need_c, need_cand_grad=need_c, **opts)
+        losses, stats, d_q = out[:3]
         head = opts["train_head"]
         head = N.LOSS_IDS[head] if isinstance(head, str) else head
-        if need:
-            ctx.save_for_backward(d_q)
+        ctx.flags = (need, need_c)
+        ctx.save_for_backward(*([d_q] if need else []), *([out[3]] if need_c else []))
         ctx.mark_non_differentiable(losses, stats)
         return losses[head].clone(), losses, stats
 
     @staticmethod
     def backward(ctx, g, _gl, _gs):
-        (d_q,) = ctx.saved_tensors
+        need, need_c = ctx.flags
+        saved = list(ctx.saved_tensors)
         g = g.contiguous().to(f32)
-        N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(d_q), d_q.numel(), N.ptr(g), N.stream()),
-                "xfmr_scale_by_device_scalar")
-        return d_q, None, None, None
+        outs = []
+        for t in saved:
+            N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(t), t.numel(), N.ptr(g), N.stream()),
+                    "xfmr_scale_by_device_scalar")
+            outs.append(t)
+        d_q = outs.pop(0) if need else None
+        d_c = outs.pop(0) if need_c else None
+        return d_q, d_c, None, None
