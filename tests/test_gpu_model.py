@@ -341,8 +341,11 @@ def test_loss_api_errors_mirror_reference(X):
         fn(torch.zeros(5, 64, device=DEV), cand)  # batch mismatch (losses.py:172)
     with pytest.raises(AssertionError):
         fn(torch.zeros(4, 64, device=DEV), cand, torch.zeros(4, dtype=torch.int64, device=DEV))  # both target and position
-    with pytest.raises(NotImplementedError):  # gradients w.r.t. dense candidates are not produced
-        fn(torch.zeros(4, 64, device=DEV), torch.zeros(4, 7, 64, device=DEV, requires_grad=True))
+    # dense candidates that require a gradient get one (losses.py:128-155 is differentiable in both arguments;
+    # values are checked in tests/test_gpu_dense_loss.py)
+    dc = torch.randn(4, 7, 64, device=DEV, requires_grad=True)
+    fn(torch.randn(4, 64, device=DEV), dc).backward()
+    assert dc.grad is not None and dc.grad.shape == dc.shape and torch.isfinite(dc.grad).all()
 
 
 # ------------------------------------------------------------------------------------------ fused loss, positions form

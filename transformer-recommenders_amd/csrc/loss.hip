@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
 
   if (dump) return;
   // ---- write the (split, query) partial -----------------------------------------------------------
-  write_partial(st, a.part + ((int64_t)split * a.T + qi) * REC, lane < 32 && qvalid && hpart == 0, pos_dot, rq, qq);
+  write_partial(merge_halves(st), a.part + ((int64_t)split * a.T + qi) * REC, lane < 32 && qvalid && hpart == 0, pos_dot,
+                rq, qq);
   if (do_grad) {
     __syncthreads();  // sScratch aliases the tile images other waves may still be reading
     float* base = a.partO + (int64_t)split * a.T * H;
@@ -460,7 +461,7 @@ struct CombineArgs {
   const float* part_loss;  // records the loss values / statistics are read from (== part in single-pass modes)
   const float* partO;
   float* d_tok; double* blockpart;
-  int T, H, nsplit, train_head, need_grad, mode; int64_t n_rows;
+  int T, H, nsplit, nsplit_loss, train_head, need_grad, mode; int64_t n_rows;  // nsplit: of `part` / partO; nsplit_loss: of part_loss
   float scale, margin;
   int k_hard, skip_train_head, lse_from_grad;
 };
@@ -490,10 +491,10 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
     const float sc2 = a.scale * kLog2e;
     const float z2pos = pos_dot * sc2;
     struct Merged { float M, l, cnt_d, cnt_c, sw, nce, hinge, logi, contr, ssum, ssq, smin, smax; };
-    auto merge = [&](const float* base) {
+    auto merge = [&](const float* base, const int ns) {
       Merged g{-INFINITY, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, INFINITY, -INFINITY};
-      for (int s = 0; s < a.nsplit; ++s) g.M = fmaxf(g.M, base[((int64_t)s * a.T + qi) * REC + R_M]);
-      for (int s = 0; s < a.nsplit; ++s) {
+      for (int s = 0; s < ns; ++s) g.M = fmaxf(g.M, base[((int64_t)s * a.T + qi) * REC + R_M]);
+      for (int s = 0; s < ns; ++s) {
         const float* r = base + ((int64_t)s * a.T + qi) * REC;
         const float f = exp2f(r[R_M] - g.M);
         g.cnt_d += r[R_CNTD]; g.l += r[R_L] * f; g.nce += r[R_NCE]; g.hinge += r[R_HINGE]; g.logi += r[R_LOGI];
@@ -503,8 +504,8 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       }
       return g;
     };
-    const Merged G = merge(a.part);
-    const Merged V = (a.part_loss == a.part) ? G : merge(a.part_loss);
+    const Merged G = merge(a.part, a.nsplit);
+    const Merged V = (a.part_loss == a.part) ? G : merge(a.part_loss, a.nsplit_loss);
     {
       const float Mv = a.lse_from_grad ? G.M : V.M, lv = a.lse_from_grad ? G.l : V.l;
       const float ltot_v = lv + exp2f(z2pos - Mv);
@@ -822,6 +823,17 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   a.T = T; a.nsplit = p.nsplit; a.train_head = cfg->train_head; a.mask_fn = cfg->mask_false_negatives;
   a.mode = cfg->mode; a.need_grad = d_tok != nullptr; a.scale = cfg->scale; a.margin = cfg->margin;
   dim3 grid((unsigned)((T + QB - 1) / QB), p.nsplit);
+  // Gradient pass of the bf16 production path with ONE column split when the query blocks alone fill the chip (>= two
+  // workgroups per CU): the kernel then finishes its rows itself (LossArgs::d_tok) -- no (split, T, H) partial dQ written
+  // and re-read (105 + 105 MB at the benchmark shape), no gradient work in the combine kernel. Measured at 800 query
+  // blocks: the pass itself takes the same time with 1, 2 or 3 splits (387 us). XFMR_LOSS_NSPLIT_GRAD overrides (experiments).
+  int ns_grad = p.nsplit;
+  if (grid.x >= 512) ns_grad = 1;
+  if (const char* e = getenv("XFMR_LOSS_NSPLIT_GRAD")) ns_grad = atoi(e);
+  if (ns_grad < 1) ns_grad = 1;
+  if (ns_grad > p.nsplit) ns_grad = p.nsplit;  // (the workspace is carved for p.nsplit)
+  int ns_part = p.nsplit;  // split count the records in a.part (and partO) are written with
+  bool fused_finish = false;
   int rc;
   // one-shot measurement hook. XFMR_PROFILE_GRADIENT_PASS: events around the main kernel of THIS call (its gradient
   // pass, or its only pass). XFMR_PROFILE_LOGGING_PASS: events around the values-only logging pass of a call that runs
@@ -870,8 +882,17 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
     // maximum pinned from the logging records (lean epilogue, see HEAD_INFONCE_PINNED)
     const bool pinned = grad_pass && cfg->all_heads == 1 && cfg->train_head == XFMR_LOSS_INFONCE &&
                         !cfg->mask_false_negatives;
+    // the online-maximum InfoNCE at H > 128 runs as dQ column parts (loss_dma.inc): it keeps the split form
+    const bool col_parts = H > 128 && cfg->train_head == XFMR_LOSS_INFONCE && !cfg->mask_false_negatives && !pinned;
+    if (!grad_pass || col_parts) ns_grad = p.nsplit;
+    dim3 ggrid(grid.x, (unsigned)ns_grad);
+    if (grad_pass) {
+      a.nsplit = ns_part = ns_grad;
+      if (ns_grad == 1) { a.d_tok = d_tok; fused_finish = true; }
+    }
     if (pinned) {
       LossArgs b = a;
+      b.nsplit = p.nsplit; b.d_tok = nullptr;
       b.part = (float*)(ws + p.off_part2);
       b.need_grad = 0;
       if (lev0 && hipEventRecord(lev0, st) != hipSuccess) return XFMR_EHIP;
@@ -881,19 +902,21 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       part_loss = b.part;
       lse_from_grad = true;
       a.pin_part = b.part;
+      a.pin_nsplit = p.nsplit;
       if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
-      rc = launch_dma_h(a, table_bf16, H, cfg->train_head, grid, st);
+      rc = launch_dma_h(a, table_bf16, H, cfg->train_head, ggrid, st);
       if (rc) return rc;
       if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
     } else {
     if (grad_pass) {
       if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
-      rc = launch_dma_h(a, table_bf16, H, cfg->train_head, grid, st);
+      rc = launch_dma_h(a, table_bf16, H, cfg->train_head, ggrid, st);
       if (rc) return rc;
       if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
     }
     if (all || !grad_pass) {
       LossArgs b = a;
+      b.nsplit = p.nsplit; b.d_tok = nullptr;
       if (grad_pass) b.part = (float*)(ws + p.off_part2);
       b.need_grad = 0;
       if (!grad_pass && ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
@@ -924,7 +947,11 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   CombineArgs c{};
   c.tok = tok; c.table = table; c.rnorm = table_rnorm; c.counts = counts; c.qrow = qrow; c.qpos = qpos;
   c.part = a.part; c.part_loss = part_loss ? part_loss : a.part; c.partO = a.partO; c.d_tok = d_tok; c.blockpart = (double*)(ws + p.off_block);
-  c.T = T; c.H = H; c.nsplit = p.nsplit; c.train_head = cfg->train_head; c.need_grad = d_tok != nullptr;
+  c.T = T; c.H = H; c.train_head = cfg->train_head;
+  // split counts of the two record sets: `part` (and partO) were written by the launch that used a.nsplit; part_loss,
+  // when it is another buffer, by a logging pass with p.nsplit
+  c.nsplit = ns_part; c.nsplit_loss = part_loss ? p.nsplit : ns_part;
+  c.need_grad = (d_tok != nullptr && !fused_finish) ? 1 : 0;  // fused_finish: the gradient pass wrote d_tok itself
   c.mode = cfg->mode; c.n_rows = n_rows; c.scale = cfg->scale; c.margin = cfg->margin;
   c.k_hard = cfg->num_hard_negatives;
   c.skip_train_head = (cfg->all_heads == 2 && d_tok == nullptr) ? 1 : 0;

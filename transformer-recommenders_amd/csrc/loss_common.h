@@ -39,6 +39,11 @@ struct LossArgs {
   // row qi to those at / above its thresholds tau[qi] = {tau_dot, rho_dot, tau_cos, rho_cos}
   float* dump; int64_t dump_ld; float2* qinfo; const float4* tau;
   const float* pin_part;  // HEAD_INFONCE_PINNED: the logging pass's split records (row maxima)
+  int pin_nsplit;         // ... and how many splits that pass ran with
+  // Gradient pass with ONE column split (this workgroup sees every column of its 128 queries): finish the rows here --
+  // dL/dquery written straight to d_tok rows (qrow), no (split, query, H) partials, no gradient work left for the
+  // combine kernel. Null: write the partials to partO as before.
+  float* d_tok;
   int T; int nsplit;
   int train_head, mask_fn, mode, need_grad;
   float scale, margin;
@@ -327,13 +332,18 @@ __device__ __forceinline__ void loss_epilogue(f32x16& s, RowState& st, f32x16 (&
   else loss_epilogue_h<ALL, GRAD, NO, false>(s, st, o, k, nid_sb, rc_sb, mu_sb, hh);
 }
 
-// halves of a lane pair (l, l^32) hold disjoint negatives of the same query: combine, then one lane writes
-__device__ __forceinline__ void write_partial(RowState st, float* rec, bool writer, float pos_dot, float rq, float qq) {
+// halves of a lane pair (l, l^32) hold disjoint negatives of the same query: combine
+__device__ __forceinline__ RowState merge_halves(RowState st) {
   st.cnt_d += xf_half_swap(st.cnt_d); st.l += xf_half_swap(st.l); st.nce += xf_half_swap(st.nce);
   st.hinge += xf_half_swap(st.hinge); st.logi += xf_half_swap(st.logi); st.cnt_c += xf_half_swap(st.cnt_c);
   st.contr += xf_half_swap(st.contr); st.ssum += xf_half_swap(st.ssum); st.ssq += xf_half_swap(st.ssq);
   st.sw += xf_half_swap(st.sw);
   st.smin = fminf(st.smin, xf_half_swap(st.smin)); st.smax = fmaxf(st.smax, xf_half_swap(st.smax));
+  return st;
+}
+// ... then one lane writes the (split, query) record; st = the merged state
+__device__ __forceinline__ void write_partial(const RowState& st, float* rec, bool writer, float pos_dot, float rq,
+                                              float qq) {
   if (writer) {
     rec[R_CNTD] = st.cnt_d; rec[R_M] = st.m; rec[R_L] = st.l; rec[R_NCE] = st.nce; rec[R_HINGE] = st.hinge;
     rec[R_LOGI] = st.logi; rec[R_CNTC] = st.cnt_c; rec[R_CONTR] = st.contr; rec[R_SSUM] = st.ssum;
