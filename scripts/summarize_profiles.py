@@ -39,7 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
     ap.add_argument("--steps", type=int, default=13)
-        a = ap.parse_args()
+    a = ap.parse_args()
     src = ROOT / "gpurun_out" / a.tag
     prof = ROOT / "profiles"
     line = [l for l in open(src / "bench.json") if l.startswith("{")][-1]

@@ -466,7 +466,12 @@ struct CombineArgs {
   int k_hard, skip_train_head, lse_from_grad;
 };
 
+__device__ __forceinline__ double shfl_xor_f64(double v, int o);
 constexpr int kCombineRows = 8;  // query rows per workgroup of loss_combine_kernel (two per wave)
+constexpr int kValueRows = 256;  // ... of its values-only form (one lane per row)
+// VALUES_ONLY: the gradient has been written by the gradient pass itself (LossArgs::d_tok): one LANE per query row merges
+// the records and evaluates the row's seven losses + statistics (the half-wave-per-row form spent 38 us on 6.5 + 13 MB).
+template <bool VALUES_ONLY>
 __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
   // a HALF wave per query row: 32 lanes x 16 bytes cover 128 columns per access (4-byte accesses, one row per wave,
   // ran at 113 us for 260 MB: the kernel is bound by the number of vector-memory instructions)
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
   const int Nq = a.counts[1];
   const int N = (a.mode == XFMR_NEG_CATALOG) ? (int)a.n_rows : a.counts[0];
-  const int qi = blockIdx.x * kCombineRows + wid * 2 + half;
+  const int qi = VALUES_ONLY ? blockIdx.x * kValueRows + (int)threadIdx.x : blockIdx.x * kCombineRows + wid * 2 + half;
   const int H = a.H;
   double acc[BP];
 #pragma unroll
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
     const float ltot = G.l + epos;
     const float inv_d = 1.f / (G.cnt_d + 1e-9f), inv_c = 1.f / (G.cnt_c + 1e-9f);
 
-    if (a.need_grad) {
+    if (!VALUES_ONLY && a.need_grad) {
       const int head = a.train_head;
       const int64_t row = a.qrow[qi];
       const float* ep = a.table + (int64_t)pit * H;
@@ -607,6 +612,31 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       }
     }
   }
+  if (VALUES_ONLY) {  // every lane carries a row: wave reduction (fixed tree), then the four waves through sAcc
+#pragma unroll
+    for (int k = 0; k < BP; ++k) {
+      double v = acc[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double w = shfl_xor_f64(v, o);
+        v = (k == 20 || k == 22) ? fmin(v, w) : (k == 21 || k == 23) ? fmax(v, w) : v + w;
+      }
+      if (lane == 0) sAcc[wid][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < BP) {
+      const int k = threadIdx.x;
+      double v = sAcc[0][k];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        if (k == 20 || k == 22) v = fmin(v, sAcc[w][k]);
+        else if (k == 21 || k == 23) v = fmax(v, sAcc[w][k]);
+        else v += sAcc[w][k];
+      }
+      a.blockpart[(int64_t)k * gridDim.x + blockIdx.x] = v;
+    }
+    return;
+  }
   if (hl == 0) {
 #pragma unroll
     for (int k = 0; k < BP; ++k) sAcc[wid * 2 + half][k] = acc[k];
@@ -628,7 +658,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
 // ---- final: deterministic reduction of the block partials ------------------------------------------------
 // 16 waves; wave w reduces quantities k = w, w+16 over the blocks that carried queries (lanes stride the
 // blocks, fixed shuffle tree), then one thread finishes the statistics.
-__device__ __forceinline__ double shfl_xor_f64(double v, int o) {
+__device__ __forceinline__ double shfl_xor_f64(double v, int o) {  // (declared above loss_combine_kernel)
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __shfl_xor(lo, o, 64);
   hi = __shfl_xor(hi, o, 64);
@@ -956,7 +986,14 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   c.k_hard = cfg->num_hard_negatives;
   c.skip_train_head = (cfg->all_heads == 2 && d_tok == nullptr) ? 1 : 0;
   c.lse_from_grad = lse_from_grad ? 1 : 0;
-  hipLaunchKernelGGL(loss_combine_kernel, dim3(p.nblocks), dim3(256), 0, st, c);
+  if (!c.need_grad) {  // values only: one lane per row
+    const int nb = (T + kValueRows - 1) / kValueRows;
+    hipLaunchKernelGGL(loss_combine_kernel<true>, dim3(nb), dim3(256), 0, st, c);
+    XF_LAUNCH_CHECK();
+    return xf_loss_finalize(c.blockpart, nb, kValueRows, counts, cfg->mode, n_rows, losses, stats,
+                            (double*)(ws + p.off_tot), st);
+  }
+  hipLaunchKernelGGL(loss_combine_kernel<false>, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
   return xf_loss_finalize(c.blockpart, p.nblocks, kCombineRows, counts, cfg->mode, n_rows, losses, stats,
                           (double*)(ws + p.off_tot), st);

@@ -445,9 +445,18 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64
   }
 }
 
-__global__ void scale_kernel(float* x, int64_t n, const float* s) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] *= s[0];
+// x *= *s (the upstream gradient of a loss, a device scalar: no host sync). `loss.backward()` passes exactly 1: the
+// workgroup then leaves without touching x (22 us and 105 MB per step at the benchmark shape otherwise).
+__global__ __launch_bounds__(256) void scale_kernel(float* x, int64_t n4, int64_t n, const float* s) {
+  const float f = s[0];
+  if (f == 1.f) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+  if (i < n - 4 * n4) x[4 * n4 + i] *= f;  // tail (n not a multiple of 4)
 }
 
 __global__ void table_rnorm_kernel(const float* table, float* out, int64_t rows, int H) {
@@ -655,7 +664,9 @@ int xfmr_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg
 
 int xfmr_scale_by_device_scalar(float* x, int64_t n, const float* scalar, void* stream) {
   if (!x || !scalar || n <= 0) return XFMR_EINVAL;
-  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+  const int64_t n4 = xf_aligned16(x) ? n / 4 : 0;
+  const int64_t work = n4 > 0 ? (n4 > n - 4 * n4 ? n4 : n - 4 * n4) : n;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n4, n,
                      scalar);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
