@@ -8,18 +8,10 @@ int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, 
   dim3 block(256);
   if (head == XFMR_LOSS_INFONCE && !a.mask_fn && !a.pin_part) grid.z = 2;  // two dQ column halves (loss_dma.inc)
   switch (head) {
-    // logging pass: masking on + in-batch negatives (the reference's default and only training form) take the fast
-    // epilogue (loss_epilogue_logging_masked); everything else the general one
-    case -1:
-      if (a.mask_fn && a.mode == XFMR_NEG_SHARED)
-        hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_LOG_MASKED_LSE>), grid, block, 0, st, a, tbf);
-      else hipLaunchKernelGGL((loss_main_dma_kernel<256, -1>), grid, block, 0, st, a, tbf);
-      break;
-    case -2:
-      if (a.mask_fn && a.mode == XFMR_NEG_SHARED)
-        hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_LOG_MASKED>), grid, block, 0, st, a, tbf);
-      else hipLaunchKernelGGL((loss_main_dma_kernel<256, -2>), grid, block, 0, st, a, tbf);
-      break;
+    // (the masked fast-path epilogue of the logging pass is for H <= 128 only: at one wave per SIMD it measured 26 %
+    //  SLOWER than the general epilogue -- 2.21 against 1.75 ms at BASELINE config 5)
+    case -1: hipLaunchKernelGGL((loss_main_dma_kernel<256, -1>), grid, block, 0, st, a, tbf); break;
+    case -2: hipLaunchKernelGGL((loss_main_dma_kernel<256, -2>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:
       hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_CONTRASTIVE:
