@@ -55,6 +55,11 @@ enum {
 };
 
 enum { XFMR_PREC_F32 = 0, XFMR_PREC_BF16 = 1 };
+/* Self-attention mask. CAUSAL is what the reference builds (BertConfig(is_decoder=True), xfmr_rec/models.py:355);
+ * BIDIRECTIONAL is BertConfig.is_decoder=False: the key-padding mask alone (TF:masking_utils.py bidirectional mask). */
+enum { XFMR_ATTN_CAUSAL = 0, XFMR_ATTN_BIDIRECTIONAL = 1 };
+/* xfmr_encoder_cfg.flags */
+enum { XFMR_ENC_BIDIRECTIONAL = 1u };
 
 /* Loss heads, in the order of the reference's LOSS_CLASSES (xfmr_rec/losses.py:546-554). */
 enum {
@@ -98,7 +103,7 @@ typedef struct xfmr_encoder_cfg {
   float ln_eps;       /* 1e-12 (TF:models/bert/configuration_bert.py:44-63)          */
   float hidden_dropout;  /* 0.1 in training (same file), 0 for eval / parity         */
   float attn_dropout;    /* 0.1 in training, 0 for eval / parity                     */
-  uint32_t reserved;
+  uint32_t flags;     /* XFMR_ENC_* bits; 0 = the reference's setting (causal decoder-style mask) */
   uint64_t seed;      /* dropout stream of this step; fwd and bwd must pass the same */
 } xfmr_encoder_cfg;
 
@@ -179,6 +184,14 @@ int xfmr_attn_fwd(const float* qkv, const uint8_t* key_mask, float* ctx, float* 
 int xfmr_attn_bwd(const float* qkv, const uint8_t* key_mask, const float* ctx, const float* lse,
                   const float* d_ctx, float* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p,
                   uint64_t seed, uint32_t site, int32_t precision, void* stream);
+/* The same pair with the mask selectable: attn_mode = XFMR_ATTN_CAUSAL is exactly the pair above;
+ * XFMR_ATTN_BIDIRECTIONAL drops the `k <= q` condition (key k is visible to every query iff key_mask[b,k]). */
+int xfmr_attn_fwd_mode(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,
+                       int32_t A, int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision,
+                       int32_t attn_mode, void* stream);
+int xfmr_attn_bwd_mode(const float* qkv, const uint8_t* key_mask, const float* ctx, const float* lse,
+                       const float* d_ctx, float* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p,
+                       uint64_t seed, uint32_t site, int32_t precision, int32_t attn_mode, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole encoder (BertEmbeddings + `layers` x BertLayer), forward and backward, as one call each.

@@ -89,11 +89,16 @@ def embeddings_forward(p, inputs_embeds, *, dropout_p=0.0, training=False):
     return _dropout(x, dropout_p, training)
 
 
-def causal_padding_bias(key_mask: torch.Tensor, dtype) -> torch.Tensor:
-    """(B,L) key mask -> additive (B,1,L,L) bias. TF:masking_utils.py:76-80,168-179."""
+def causal_padding_bias(key_mask: torch.Tensor, dtype, causal: bool = True) -> torch.Tensor:
+    """(B,L) key mask -> additive (B,1,L,L) bias. TF:masking_utils.py:76-80,168-179.
+
+    ``causal=False`` is ``BertConfig(is_decoder=False)`` (``ModelConfig.is_decoder``, models.py:50,355): HF then
+    builds the bidirectional mask, i.e. the key-padding condition alone."""
     B, L = key_mask.shape
-    causal = torch.ones(L, L, dtype=torch.bool, device=key_mask.device).tril()
-    allowed = causal[None, :, :] & key_mask.bool()[:, None, :]
+    tri = torch.ones(L, L, dtype=torch.bool, device=key_mask.device)
+    if causal:
+        tri = tri.tril()
+    allowed = tri[None, :, :] & key_mask.bool()[:, None, :]
     bias = torch.zeros(B, L, L, dtype=dtype, device=key_mask.device)
     bias.masked_fill_(~allowed, torch.finfo(dtype).min)
     return bias[:, None]
@@ -138,14 +143,14 @@ def num_layers_of(p) -> int:
     return 1 + max(int(k.split(".")[2]) for k in p if k.startswith("encoder.layer."))
 
 
-def encoder_forward(p, inputs_embeds, key_mask, num_heads, *, dropout_p=0.0, training=False):
+def encoder_forward(p, inputs_embeds, key_mask, num_heads, *, dropout_p=0.0, training=False, causal=True):
     """``BertModel(inputs_embeds=, attention_mask=).last_hidden_state``.
 
     TF:models/bert/modeling_bert.py:623-686. The pooler and the KV cache the
     reference also computes are unused by the training path and omitted.
     """
     x = embeddings_forward(p, inputs_embeds, dropout_p=dropout_p, training=training)
-    bias = causal_padding_bias(key_mask, x.dtype)
+    bias = causal_padding_bias(key_mask, x.dtype, causal)
     for i in range(num_layers_of(p)):
         x = layer_forward(p, i, x, bias, num_heads, dropout_p=dropout_p, training=training)
     return x

@@ -13,7 +13,9 @@ What is executed from the reference:
     ``BertModel(BertConfig(vocab_size, hidden_size, num_hidden_layers,
     num_attention_heads, intermediate_size, max_position_embeddings,
     is_decoder=True))`` from the ``transformers`` package in this container
-    (version recorded in every fixture) -> G2, and the encoder stage of G3.
+    (version recorded in every fixture) -> G2, and the encoder stage of G3;
+    the same with ``is_decoder=False`` (``ModelConfig.is_decoder``,
+    models.py:50) -> G5.
   * ``xfmr_rec/models.py`` / ``trainer.py`` are NOT importable here (they need
     loguru / sentence_transformers / lightning, absent offline). Their glue
     (``models.py:333-345, 366-419``, ``trainer.py:213-264``) is restated in
@@ -110,11 +112,11 @@ def gen_losses():
 
 
 # --------------------------------------------------------------------------- G2
-def _make_bert(H, nL, A, I, Lmax, attn_impl, seed=0):
+def _make_bert(H, nL, A, I, Lmax, attn_impl, seed=0, is_decoder=True):
     torch.manual_seed(seed)
     cfg = BertConfig(
         vocab_size=1, hidden_size=H, num_hidden_layers=nL, num_attention_heads=A,
-        intermediate_size=I, max_position_embeddings=Lmax, is_decoder=True,
+        intermediate_size=I, max_position_embeddings=Lmax, is_decoder=is_decoder,
     )
     cfg._attn_implementation = attn_impl
     m = BertModel(cfg)
@@ -136,7 +138,7 @@ def _ragged_inputs(B, L, H, seed, lengths):
     return x
 
 
-def gen_encoder():
+def gen_encoder(is_decoder=True, out_name="g2_encoder.npz"):
     store: dict[str, np.ndarray] = {"versions": np.array(VERSIONS)}
     cases = {
         # head size 32 throughout (the reference's 384/12; the HIP attention kernels are built for it)
@@ -144,12 +146,14 @@ def gen_encoder():
         "b": dict(B=2, L=20, H=64, nL=1, A=2, I=64, lengths=[20, 13]),
         "c": dict(B=2, L=40, H=32, nL=2, A=1, I=32, lengths=[33, 40]),
     }
+    if not is_decoder:  # G5: ModelConfig.is_decoder=False (models.py:50,355) -- bidirectional attention
+        cases["d"] = dict(B=2, L=150, H=64, nL=1, A=2, I=64, lengths=[150, 41])  # two 128-row blocks
     for name, c in cases.items():
         x = _ragged_inputs(c["B"], c["L"], c["H"], 7, c["lengths"])
         mask = (x != 0).any(-1).long()
         state = None
         for impl in ("eager", "sdpa"):
-            m = _make_bert(c["H"], c["nL"], c["A"], c["I"], c["L"], impl)
+            m = _make_bert(c["H"], c["nL"], c["A"], c["I"], c["L"], impl, is_decoder=is_decoder)
             if state is None:
                 state = {k: v.clone() for k, v in m.state_dict().items()}
             m.zero_grad()
@@ -173,8 +177,9 @@ def gen_encoder():
         store[f"{name}/x"] = _np(x)
         store[f"{name}/mask"] = _np(mask)
         store[f"{name}/cfg"] = np.array(json.dumps({k: v for k, v in c.items()}))
-    np.savez_compressed(OUT / "g2_encoder.npz", **store)
-    print("g2_encoder:", list(cases))
+    store["is_decoder"] = np.array(is_decoder)
+    np.savez_compressed(OUT / out_name, **store)
+    print(out_name, list(cases))
 
 
 # --------------------------------------------------------------------------- G3
@@ -334,9 +339,20 @@ def gen_shared_negatives():
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(4)
-    gen_losses()
-    gen_encoder()
-    gen_step()
-    gen_shared_negatives()
+    only = sys.argv[1:]  # e.g. `python oracle/make_golden.py g5` regenerates one file
+
+    def want(tag):
+        return not only or tag in only
+
+    if want("g1"):
+        gen_losses()
+    if want("g2"):
+        gen_encoder()
+    if want("g3"):
+        gen_step()
+    if want("g4"):
+        gen_shared_negatives()
+    if want("g5"):
+        gen_encoder(is_decoder=False, out_name="g5_encoder_bidirectional.npz")
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")

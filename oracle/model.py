@@ -25,12 +25,12 @@ def build_table(item_embeddings: torch.Tensor) -> torch.Tensor:
     return torch.cat([torch.zeros_like(item_embeddings[:1]), item_embeddings])
 
 
-def forward(params, table, item_idx, *, num_heads, max_seq_length, dropout_p=0.0, training=False):
+def forward(params, table, item_idx, *, num_heads, max_seq_length, dropout_p=0.0, training=False, causal=True):
     """models.py:306-345: truncate, gather, mask from embedding VALUES, encode, pool."""
     idx = item_idx[:, -max_seq_length:]
     x = F.embedding(idx, table)
     key_mask = (x != 0).any(-1).long()
-    tok = enc.encoder_forward(params, x, key_mask, num_heads, dropout_p=dropout_p, training=training)
+    tok = enc.encoder_forward(params, x, key_mask, num_heads, dropout_p=dropout_p, training=training, causal=causal)
     return {
         "token_embeddings": tok,
         "sentence_embedding": enc.mean_pool(tok, key_mask),

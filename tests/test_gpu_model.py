@@ -25,9 +25,9 @@ def X():
     return x
 
 
-def _model(X, *, H, A, I, nL, Lmax, prec, state=None, table=None):
+def _model(X, *, H, A, I, nL, Lmax, prec, state=None, table=None, is_decoder=True):
     cfg = X.ModelConfig(hidden_size=H, num_attention_heads=A, intermediate_size=I, num_hidden_layers=nL,
-                        max_seq_length=Lmax)
+                        max_seq_length=Lmax, is_decoder=is_decoder)
     m = X.RecommenderModel(cfg, device=DEV, precision=prec)
     if state is not None:
         m.load_encoder_state_dict(state)
@@ -40,12 +40,23 @@ def _model(X, *, H, A, I, nL, Lmax, prec, state=None, table=None):
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", ["a", "b", "c"])
 def test_encoder_matches_hf_bert_golden(X, golden_dir, case, prec):
-    g2 = np.load(golden_dir / "g2_encoder.npz")
+    _encoder_vs_golden(X, np.load(golden_dir / "g2_encoder.npz"), case, prec, is_decoder=True)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_bidirectional_encoder_matches_hf_bert_golden(X, golden_dir, case, prec):
+    """ModelConfig(is_decoder=False) (models.py:50,355): HF BertModel then attends in both directions; outputs and every
+    parameter gradient against G5 (generated from transformers' BertModel(is_decoder=False), oracle/make_golden.py)."""
+    _encoder_vs_golden(X, np.load(golden_dir / "g5_encoder_bidirectional.npz"), case, prec, is_decoder=False)
+
+
+def _encoder_vs_golden(X, g2, case, prec, is_decoder):
     cfg = json.loads(str(g2[f"{case}/cfg"]))
     pre = f"{case}/param/"
     state = {k[len(pre):]: _t(g2[k]) for k in g2.files if k.startswith(pre)}
     m = _model(X, H=cfg["H"], A=cfg["A"], I=cfg["I"], nL=cfg["nL"], Lmax=cfg["L"], prec=prec, state=state,
-               table=torch.zeros(2, cfg["H"]))
+               table=torch.zeros(2, cfg["H"]), is_decoder=is_decoder)
     x = _t(g2[f"{case}/x"]).to(DEV)
     mask = _t(g2[f"{case}/mask"]).bool()
     out = m(item_embeds=x)
@@ -122,14 +133,22 @@ def test_encoder_reference_default_shape_vs_oracle(X, prec):
     _encoder_shape_vs_oracle(X, prec, B=5, L=32, H=384, A=12, I=48, nL=1, V=200, lengths=[32, 31, 17, 2, 1])
 
 
-def _encoder_shape_vs_oracle(X, prec, *, B, L, H, A, I, nL, V, lengths):
+@pytest.mark.parametrize("prec,L,lengths", [("fp32", 200, [200, 131, 17]), ("bf16", 200, [200, 131, 17]),
+                                            ("bf16", 300, [300, 129, 2])])
+def test_bidirectional_encoder_config2_shape_vs_oracle(X, prec, L, lengths):
+    """is_decoder=False at the bench's layer shape (H=128, 4 heads, I=512; 2 layers): two and three 128-row blocks per
+    sequence, every block reading ALL keys (the causal kernels stop at the diagonal), ragged rows."""
+    _encoder_shape_vs_oracle(X, prec, B=3, L=L, H=128, A=4, I=512, nL=2, V=300, lengths=lengths, is_decoder=False)
+
+
+def _encoder_shape_vs_oracle(X, prec, *, B, L, H, A, I, nL, V, lengths, is_decoder=True):
     from oracle import model as OM
 
     table = unit_table(V, H)
     batch, lengths = ragged_batch(B, L, V, lengths=lengths, seed=2)
-    m = _model(X, H=H, A=A, I=I, nL=nL, Lmax=L, prec=prec, table=table)
+    m = _model(X, H=H, A=A, I=I, nL=nL, Lmax=L, prec=prec, table=table, is_decoder=is_decoder)
     params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.encoder_state_dict().items()}
-    ref = OM.forward(params, table, batch["history_item_idx"], num_heads=A, max_seq_length=L)
+    ref = OM.forward(params, table, batch["history_item_idx"], num_heads=A, max_seq_length=L, causal=is_decoder)
     out = m(batch["history_item_idx"].to(DEV))
     valid = ref["attention_mask"].bool()
     assert torch.equal(out["attention_mask"].cpu().bool(), valid)

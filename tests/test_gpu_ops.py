@@ -146,26 +146,29 @@ def test_embed_gather_layernorm_and_param_grads(ops):
     assert torch.count_nonzero(d_type[1]) == 0
 
 
-def _attention_reference(qkv, key_mask, A):
-    """fp64 restatement of eager attention (TF:modeling_bert.py:111-136) with the causal+padding mask."""
+def _attention_reference(qkv, key_mask, A, causal=True):
+    """fp64 restatement of eager attention (TF:modeling_bert.py:111-136) with the causal+padding mask (causal=False:
+    the padding mask alone, BertConfig.is_decoder=False)."""
     B, L, H3 = qkv.shape
     H = H3 // 3
     dh = H // A
     q, k, v = (t.view(B, L, A, dh).transpose(1, 2) for t in qkv.split(H, dim=-1))
     scores = q @ k.transpose(2, 3) * dh**-0.5
-    allowed = torch.ones(L, L, dtype=torch.bool).tril()[None] & key_mask.bool()[:, None, :]
+    tri = torch.ones(L, L, dtype=torch.bool)
+    allowed = (tri.tril() if causal else tri)[None] & key_mask.bool()[:, None, :]
     scores = scores.masked_fill(~allowed[:, None], float("-inf"))
     probs = torch.softmax(scores, dim=-1)
     probs = torch.nan_to_num(probs, nan=0.0)  # rows without any visible key -> zeros (documented)
     return (probs @ v).transpose(1, 2).reshape(B, L, H)
 
 
+@pytest.mark.parametrize("causal", [True, False], ids=["causal", "bidirectional"])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,L,A,lengths", [(3, 12, 1, [12, 7, 1]), (2, 40, 2, [33, 40]), (2, 130, 2, [130, 77]),
                                            (2, 200, 4, [200, 150]), (1, 256, 1, [250]),
                                            # L > 256: the two-block forward and the two-kernel backward
                                            (2, 320, 2, [320, 301]), (1, 512, 1, [512])])
-def test_attention_fwd_bwd(ops, prec, B, L, A, lengths):
+def test_attention_fwd_bwd(ops, prec, B, L, A, lengths, causal):
     if prec == "fp32" and L > 256:
         pytest.skip("fp32 parity policy: its kernels keep whole fp32 panels in LDS (L <= 256); see DESIGN.md section 2")
     H = 32 * A
@@ -177,12 +180,12 @@ def test_attention_fwd_bwd(ops, prec, B, L, A, lengths):
         mask[1, 2] = 0  # a hole in the middle: the kernels take an arbitrary key mask
     w = _rand(B, L, H, seed=4) * mask[..., None]  # the training path only back-propagates valid rows
     ref_in = qkv.clone().double().requires_grad_(True)
-    ref = _attention_reference(ref_in, mask, A)
+    ref = _attention_reference(ref_in, mask, A, causal)
     (ref * w.double()).sum().backward()
-    ctx, lse = ops.attn_fwd(qkv.to(DEV), mask.to(DEV), A, precision=prec)
+    ctx, lse = ops.attn_fwd(qkv.to(DEV), mask.to(DEV), A, precision=prec, causal=causal)
     valid = mask.bool()
     assert_close("attn.ctx", ctx.cpu()[valid], ref.detach()[valid], prec)
-    d_qkv = ops.attn_bwd(qkv.to(DEV), mask.to(DEV), ctx, lse, w.to(DEV), A, precision=prec)
+    d_qkv = ops.attn_bwd(qkv.to(DEV), mask.to(DEV), ctx, lse, w.to(DEV), A, precision=prec, causal=causal)
     assert_close("attn.d_qkv", d_qkv, ref_in.grad, prec, "grad")
 
 
@@ -205,14 +208,51 @@ def test_attention_causality_and_padding_invariance(ops):
     assert torch.equal(base[0, keep], out3[0, keep])
 
 
-def test_attention_dropout_forward_backward_agree(ops):
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_bidirectional_attention_sees_later_keys_but_never_masked_ones(ops, prec):
+    """XFMR_ATTN_BIDIRECTIONAL (BertConfig.is_decoder=False): a later key changes EVERY query's output (first and
+    second 128-row block alike), a masked key changes none; the causal entry point and mode 0 are the same kernels."""
+    B, L, A = 1, 160, 2
+    H = 32 * A
+    qkv = _rand(B, L, 3 * H, seed=1).to(DEV)
+    mask = torch.ones(B, L, dtype=torch.uint8, device=DEV)
+    mask[0, 50] = 0
+    base, lse = ops.attn_fwd(qkv, mask, A, precision=prec, causal=False)
+    q2 = qkv.clone()
+    q2[0, 150, H:] += 1.0
+    out2, _ = ops.attn_fwd(q2, mask, A, precision=prec, causal=False)
+    changed = (base[0] != out2[0]).any(-1)
+    assert bool(changed.all())
+    q3 = qkv.clone()
+    q3[0, 50, H:] += 5.0
+    out3, _ = ops.attn_fwd(q3, mask, A, precision=prec, causal=False)
+    assert torch.equal(base, out3)
+    causal_out, _ = ops.attn_fwd(qkv, mask, A, precision=prec)
+    # the last query sees the same key set either way
+    assert_close("last row", base[0, -1].cpu(), causal_out[0, -1].cpu(), prec)
+    assert not torch.allclose(base[0, :100], causal_out[0, :100])
+    import ctypes as C
+
+    from xfmr_rec_amd import _native as N
+
+    ctx, lse2 = torch.empty_like(base), torch.empty_like(lse)
+    rc = N.load().xfmr_attn_fwd_mode(N.ptr(qkv), N.ptr(mask), N.ptr(ctx), N.ptr(lse2), B, L, A, H, 0.0, 0, 0,
+                                     N.precision_id(prec), N.ATTN_CAUSAL, N.stream())
+    assert rc == 0 and torch.equal(ctx, causal_out)
+    rc = N.load().xfmr_attn_fwd_mode(N.ptr(qkv), N.ptr(mask), N.ptr(ctx), N.ptr(lse2), B, L, A, H, 0.0, 0, 0,
+                                     N.precision_id(prec), 7, N.stream())
+    assert rc == -1  # XFMR_EINVAL: unknown attn_mode
+
+
+@pytest.mark.parametrize("causal", [True, False], ids=["causal", "bidirectional"])
+def test_attention_dropout_forward_backward_agree(ops, causal):
     """With dropout on, backward must differentiate the SAME masked forward: check by finite differences."""
     B, L, A = 1, 40, 1
     H = 32
     qkv = _rand(B, L, 3 * H, seed=1).to(DEV)
     mask = torch.ones(B, L, dtype=torch.uint8, device=DEV)
     w = _rand(B, L, H, seed=2).to(DEV)
-    kw = dict(dropout_p=0.3, seed=11, site=5, precision="fp32")
+    kw = dict(dropout_p=0.3, seed=11, site=5, precision="fp32", causal=causal)
     ctx, lse = ops.attn_fwd(qkv, mask, A, **kw)
     d = ops.attn_bwd(qkv, mask, ctx, lse, w, A, **kw)
     direction = _rand(B, L, 3 * H, seed=3).to(DEV)
@@ -222,12 +262,13 @@ def test_attention_dropout_forward_backward_agree(ops):
     fd = (fp - fm) / (2 * eps)
     an = (d * direction).sum().item()
     assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (fd, an)
-    ctx0, _ = ops.attn_fwd(qkv, mask, A, precision="fp32")
+    ctx0, _ = ops.attn_fwd(qkv, mask, A, precision="fp32", causal=causal)
     assert not torch.allclose(ctx, ctx0)  # dropout really changed the output
 
 
+@pytest.mark.parametrize("causal", [True, False], ids=["causal", "bidirectional"])
 @pytest.mark.parametrize("B,L,A", [(2, 200, 2), (1, 96, 1)])
-def test_attention_dropout_mask_is_shared_by_all_kernels(ops, B, L, A):
+def test_attention_dropout_mask_is_shared_by_all_kernels(ops, B, L, A, causal):
     """The dropout decision is a function of (seed, site, query row, key column) only: the bf16 kernels (forward,
     dQ, dK/dV -- interior and diagonal tiles, row keys staged in LDS) must apply the mask the fp32 kernels apply,
     whose forward / backward agreement the finite-difference test above checks."""
@@ -236,7 +277,7 @@ def test_attention_dropout_mask_is_shared_by_all_kernels(ops, B, L, A):
     mask = torch.ones(B, L, dtype=torch.uint8, device=DEV)
     mask[0, L - 9:] = 0
     w = (_rand(B, L, H, seed=6).to(DEV)) * mask[..., None]
-    kw = dict(dropout_p=0.25, seed=3, site=2)
+    kw = dict(dropout_p=0.25, seed=3, site=2, causal=causal)
     ctx32, lse32 = ops.attn_fwd(qkv, mask, A, precision="fp32", **kw)
     d32 = ops.attn_bwd(qkv, mask, ctx32, lse32, w, A, precision="fp32", **kw)
     ctx16, lse16 = ops.attn_fwd(qkv, mask, A, precision="bf16", **kw)

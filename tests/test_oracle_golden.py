@@ -70,14 +70,25 @@ def g2(golden_dir):
     return np.load(golden_dir / "g2_encoder.npz")
 
 
-@pytest.mark.parametrize("case", ["a", "b", "c"])
-def test_g2_encoder_matches_hf_bert(g2, case):
+@pytest.fixture(scope="module")
+def g5(golden_dir):
+    return np.load(golden_dir / "g5_encoder_bidirectional.npz")
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "g5:a", "g5:b", "g5:c", "g5:d"])
+def test_g2_encoder_matches_hf_bert(g2, g5, case):
+    """G2: BertModel(is_decoder=True), the reference's setting; G5: is_decoder=False (ModelConfig.is_decoder,
+    models.py:50) -- the same oracle with the causal term of the mask dropped."""
+    causal = not case.startswith("g5:")
+    if not causal:
+        g2, case = g5, case[3:]
+        assert not bool(g2["is_decoder"])
     cfg = json.loads(str(g2[f"{case}/cfg"]))
     prefix = f"{case}/param/"
     params = {k[len(prefix):]: _t(g2[k]).clone().requires_grad_(True) for k in g2.files if k.startswith(prefix)}
     x = _t(g2[f"{case}/x"]).clone().requires_grad_(True)
     mask = _t(g2[f"{case}/mask"])
-    out = enc.encoder_forward(params, x, mask, cfg["A"])
+    out = enc.encoder_forward(params, x, mask, cfg["A"], causal=causal)
     valid = mask.bool().numpy()
     for impl, tol in (("eager", 2e-6), ("sdpa", 2e-5)):
         want = g2[f"{case}/{impl}/last_hidden_state"]

@@ -21,6 +21,8 @@ struct AttnArgs {
   const float* qkv; const uint8_t* key_mask; float* ctx; float* lse;  // qkv / ctx / d_ctx / d_qkv: fp32, or bf16
   const float* d_ctx; float* d_qkv;                                   // behind the same pointers (S16 kernels)
   int B, L, A, H;
+  int causal;  // 1: key j is visible to query i only when j <= i (BertConfig.is_decoder=True, the reference's
+               // setting, models.py:355); 0: every unpadded key is visible (is_decoder=False)
   XfDropout drop;
 };
 
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int L = a.L, H = a.H;
   const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
   const int qblk0 = blockIdx.x * 128;
-  const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);  // keys the causal mask can reach, padded to 32
+  // keys the mask can reach, padded to 32: the causal triangle stops at the block's last query
+  const int nkeys = a.causal ? min(((L + 31) / 32) * 32, qblk0 + 128) : ((L + 31) / 32) * 32;
   elem* sK = reinterpret_cast<elem*>(smem_raw);
   elem* sVT = reinterpret_cast<elem*>(smem_raw + SM::align(SM::row_img(nkeys)));
   const int ldt = SM::ldt(nkeys);
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blockIdx.y * L + q));
 
-  const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
+  const int kb_end = a.causal ? min((q0 + 31) / 32, nkeys / 32 - 1) : nkeys / 32 - 1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s;
 #pragma unroll
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kb * 32 + xf_acc_row(r, lane);
-      const bool vis = (key <= q) && sMask[key];
+      const bool vis = (key <= q || !a.causal) && sMask[key];
       s[r] = vis ? s[r] * sc : -INFINITY;
       bmax = fmaxf(bmax, s[r]);
     }
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   const int L = a.L, H = a.H;
   const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
   const int qblk0 = blockIdx.x * 128;
-  const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
+  const int nkeys = a.causal ? min(((L + 31) / 32) * 32, qblk0 + 128) : ((L + 31) / 32) * 32;
   elem* sK = reinterpret_cast<elem*>(smem_raw);
   elem* sV = reinterpret_cast<elem*>(smem_raw + SM::align(SM::row_img(nkeys)));
   elem* sKT = reinterpret_cast<elem*>(smem_raw + 2 * SM::align(SM::row_img(nkeys)));
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   f32x16 dq;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-  const int kb_end = min((q0 + 31) / 32, nkeys / 32 - 1);
+  const int kb_end = a.causal ? min((q0 + 31) / 32, nkeys / 32 - 1) : nkeys / 32 - 1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s, dp;
 #pragma unroll
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kb * 32 + xf_acc_row(r, lane);
-      const bool vis = (key <= q) && sMask[key];
+      const bool vis = (key <= q || !a.causal) && sMask[key];
       const float p = vis ? exp2f(s[r] * sc - lse2) : 0.f;
       float dpv = dp[r];
       if (a.drop.on) dpv *= xf_keep_scale_rc(a.drop, rowkey, (uint32_t)key * kDropColMul);
@@ -222,9 +225,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
-  const int kblk0 = blockIdx.x * 128;          // first key of this workgroup == first query it needs
+  const int kblk0 = blockIdx.x * 128;          // first key of this workgroup
+  const int qs = a.causal ? kblk0 : 0;         // first query its keys are visible to
   const int Lp = ((L + 31) / 32) * 32;
-  const int nq = Lp - kblk0;                    // queries [kblk0, Lp) staged, image row = q - kblk0
+  const int nq = Lp - qs;                       // queries [qs, Lp) staged, image row = q - qs
   elem* sQ = reinterpret_cast<elem*>(smem_raw);
   elem* sDO = reinterpret_cast<elem*>(smem_raw + SM::align(SM::row_img(nq)));
   elem* sQT = reinterpret_cast<elem*>(smem_raw + 2 * SM::align(SM::row_img(nq)));
@@ -238,16 +242,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float* qbase = a.qkv + tok0 * 3 * H + h * DH;
   const float* dobase = a.d_ctx + tok0 * H + h * DH;
   const float* obase = a.ctx + tok0 * H + h * DH;
-  stage_rows<P>(sQ, SM::LDR, qbase, 3 * H, kblk0, nq, L);
-  stage_rows<P>(sDO, SM::LDR, dobase, H, kblk0, nq, L);
-  stage_rows_T<P>(sQT, ldt, qbase, 3 * H, kblk0, nq, L);
-  stage_rows_T<P>(sDOT, ldt, dobase, H, kblk0, nq, L);
+  stage_rows<P>(sQ, SM::LDR, qbase, 3 * H, qs, nq, L);
+  stage_rows<P>(sDO, SM::LDR, dobase, H, qs, nq, L);
+  stage_rows_T<P>(sQT, ldt, qbase, 3 * H, qs, nq, L);
+  stage_rows_T<P>(sDOT, ldt, dobase, H, qs, nq, L);
   for (int c = threadIdx.x; c < nq * 8; c += blockDim.x) {  // delta: 8 consecutive lanes share a row
     const int r = c >> 3, dd = (c & 7) * 4;
     float part = 0.f;
-    if (kblk0 + r < L) {
-      const float4 x = *reinterpret_cast<const float4*>(obase + (int64_t)(kblk0 + r) * H + dd);
-      const float4 y = *reinterpret_cast<const float4*>(dobase + (int64_t)(kblk0 + r) * H + dd);
+    if (qs + r < L) {
+      const float4 x = *reinterpret_cast<const float4*>(obase + (int64_t)(qs + r) * H + dd);
+      const float4 y = *reinterpret_cast<const float4*>(dobase + (int64_t)(qs + r) * H + dd);
       part = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
     }
     part += __shfl_xor(part, 1, 64);
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     part += __shfl_xor(part, 4, 64);
     if ((c & 7) == 0) {
       sDelta[r] = part;
-      sLse[r] = (kblk0 + r < L) ? a.lse[(int64_t)blockIdx.y * L + kblk0 + r] * kLog2e : INFINITY;
+      sLse[r] = (qs + r < L) ? a.lse[(int64_t)blockIdx.y * L + qs + r] * kLog2e : INFINITY;
     }
   }
   __syncthreads();
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   f32x16 dk, dv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
-  for (int qb = k0 / 32; qb < Lp / 32; ++qb) {
-    const int row0 = qb * 32 - kblk0;
+  for (int qb = a.causal ? k0 / 32 : 0; qb < Lp / 32; ++qb) {
+    const int row0 = qb * 32 - qs;
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -283,8 +287,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = row0 + xf_acc_row(r, lane);
-      const int q = qi + kblk0;
-      const bool vis = kvis && (key <= q);
+      const int q = qi + qs;
+      const bool vis = kvis && (key <= q || !a.causal);
       const float p = vis ? exp2f(s[r] * sc - sLse[qi]) : 0.f;  // q >= L: lse = +inf -> 0
       float keep = 1.f;
       if (a.drop.on) keep = xf_keep_scale_rc(a.drop, xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blockIdx.y * L + q)), (uint32_t)key * kDropColMul);
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kernel(AttnArgs a) {
   if (!blk.valid) return;  // (whole workgroup: the grid is padded to a multiple of 8 sequences)
   const int b = blk.by / a.A, h = blk.by % a.A;
   const int qblk0 = blk.bx * 128;
-  const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
+  const int nkeys = a.causal ? min(((L + 31) / 32) * 32, qblk0 + 128) : ((L + 31) / 32) * 32;
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sV = sK + nkeys * DH;
   // the output-transposition scratch ALIASES the K / V images (used after a barrier, once every wave is done with
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kernel(AttnArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + q));
-  const int kb_end = active ? min((q0 + 31) / 32, nkeys / 32 - 1) : -1;
+  const int kb_end = !active ? -1 : a.causal ? min((q0 + 31) / 32, nkeys / 32 - 1) : nkeys / 32 - 1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s;
 #pragma unroll
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kernel(AttnArgs a) {
     float bmax = -INFINITY;
     const uint32_t kword = sBits[kb];
     // interior tile: every key is at or before the wave's first query and none is padding -- no per-score masking
-    const bool interior = kb * 32 + 31 <= q0 && __builtin_amdgcn_readfirstlane(kword) == 0xFFFFFFFFu;
+    const bool interior = (kb * 32 + 31 <= q0 || !a.causal) && __builtin_amdgcn_readfirstlane(kword) == 0xFFFFFFFFu;
     if (interior) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) bmax = fmaxf(bmax, s[r]);
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kb * 32 + xf_acc_row(r, lane);
-        const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
+        const bool vis = (key <= q || !a.causal) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
         s[r] = vis ? s[r] : -INFINITY;
         bmax = fmaxf(bmax, s[r]);
       }
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   if (!blk.valid) return;  // (whole workgroup: the grid is padded to a multiple of 8 sequences)
   const int b = blk.by / a.A, h = blk.by % a.A;
   const int qblk0 = blk.bx * 128;
-  const int nkeys = min(((L + 31) / 32) * 32, qblk0 + 128);
+  const int nkeys = a.causal ? min(((L + 31) / 32) * 32, qblk0 + 128) : ((L + 31) / 32) * 32;
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sV = sK + nkeys * DH;
   // the output-transposition scratch ALIASES the K / V images (used after a barrier, once every wave is done with
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   f32x16 dq;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-  const int kb_end = active ? min((q0 + 31) / 32, nkeys / 32 - 1) : -1;
+  const int kb_end = !active ? -1 : a.causal ? min((q0 + 31) / 32, nkeys / 32 - 1) : nkeys / 32 - 1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s, dp;
 #pragma unroll
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     AI::tile_nreg(s, sK, kb * 32, qreg.regs());
     AI::tile_nreg(dp, sV, kb * 32, doreg.regs());
     const uint32_t kword = sBits[kb];
-    const bool interior = kb * 32 + 31 <= q0 && __builtin_amdgcn_readfirstlane(kword) == 0xFFFFFFFFu;
+    const bool interior = (kb * 32 + 31 <= q0 || !a.causal) && __builtin_amdgcn_readfirstlane(kword) == 0xFFFFFFFFu;
     if (interior) {  // (see attn_fwd_bf16_kernel)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kb * 32 + xf_acc_row(r, lane);
-        const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
+        const bool vis = (key <= q || !a.causal) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
         const float p = vis ? xf_exp2(fmaf(s[r], sc, -lse2)) : 0.f;
         float dpv = dp[r];
         if (a.drop.on) dpv *= xf_keep_scale_rc(a.drop, rowkey, (uint32_t)key * kDropColMul);
@@ -582,7 +586,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   const int b = blk.by / a.A, h = blk.by % a.A;
   const int kblk0 = blk.bx * 128;
   const int Lp = ((L + 31) / 32) * 32;
-  const int nq = Lp - kblk0;
+  const int qs = a.causal ? kblk0 : 0;  // first query this block's keys are visible to; image row = q - qs
+  const int nq = Lp - qs;
   __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sDO = sQ + nq * DH;
   float* scratch = reinterpret_cast<float*>(smem_raw);  // aliases the Q / dO images: see attn_fwd_bf16_kernel
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
 
   const int64_t tok0 = (int64_t)b * L;
   const int64_t hoff = tok0 * H + h * DH;
-  stage2_rows_swz<S16>(sQ, a.qkv, tok0 * 3 * H + h * DH, 3 * H, sDO, a.d_ctx, hoff, H, kblk0, nq, L);
+  stage2_rows_swz<S16>(sQ, a.qkv, tok0 * 3 * H + h * DH, 3 * H, sDO, a.d_ctx, hoff, H, qs, nq, L);
   // delta[r] = rowsum(dO * O), lse[r]: loads of a batch of 4 pieces issued together (see stage2_rows_swz)
   for (int c0 = threadIdx.x; c0 < nq * 8; c0 += (int)blockDim.x * 4) {
     float4 x[4], y[4];
@@ -602,10 +607,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
       const int c = c0 + u * (int)blockDim.x, r = c >> 3, dd = (c & 7) * 4;
       x[u] = y[u] = make_float4(0, 0, 0, 0);
       ls[u] = INFINITY;
-      if (c < nq * 8 && kblk0 + r < L) {
-        x[u] = xf_ld4<S16>(a.ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
-        y[u] = xf_ld4<S16>(a.d_ctx, hoff + (int64_t)(kblk0 + r) * H + dd);
-        if ((c & 7) == 0) ls[u] = a.lse[(int64_t)blk.by * L + kblk0 + r] * kLog2e;
+      if (c < nq * 8 && qs + r < L) {
+        x[u] = xf_ld4<S16>(a.ctx, hoff + (int64_t)(qs + r) * H + dd);
+        y[u] = xf_ld4<S16>(a.d_ctx, hoff + (int64_t)(qs + r) * H + dd);
+        if ((c & 7) == 0) ls[u] = a.lse[(int64_t)blk.by * L + qs + r] * kLog2e;
       }
     }
 #pragma unroll
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
       if (c < nq * 8 && (c & 7) == 0) {
         sDelta[r] = part;
         sLse[r] = ls[u];
-        sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + kblk0 + r));
+        sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + qs + r));
       }
     }
   }
@@ -638,14 +643,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
   const bool all_kvis = __all(kvis);
   const uint32_t colmix = (uint32_t)key * kDropColMul;
-  for (int qb = active ? k0 / 32 : Lp / 32; qb < Lp / 32; ++qb) {
-    const int row0 = qb * 32 - kblk0;
+  for (int qb = !active ? Lp / 32 : a.causal ? k0 / 32 : 0; qb < Lp / 32; ++qb) {
+    const int row0 = qb * 32 - qs;
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     AI::tile_nreg(s, sQ, row0, kreg.regs());
     AI::tile_nreg(dp, sDO, row0, vreg.regs());
-    const bool interior = all_kvis && qb * 32 > k0;  // every query row is after the wave's keys, every key valid
+    const bool interior = all_kvis && (qb * 32 > k0 || !a.causal);  // every query row is after the wave's keys, every key valid
     // the lane's 16 query rows are four runs of 4 consecutive rows: lse / delta come as 16-byte LDS reads
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
       } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          pr[u] = (kvis && key <= qi0 + u + kblk0) ? xf_exp2(fmaf(s[4 * g + u], sc, -ls[u])) : 0.f;
+          pr[u] = (kvis && (key <= qi0 + u + qs || !a.causal)) ? xf_exp2(fmaf(s[4 * g + u], sc, -ls[u])) : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -781,7 +786,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kb * 32 + xf_acc_row(r, lane);
-          const bool vis = (key <= q) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
+          const bool vis = (key <= q || !a.causal) && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
           s[r] = vis ? s[r] : -INFINITY;
           bmax = fmaxf(bmax, s[r]);
         }
@@ -1096,7 +1101,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 template <bool S16>
 int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
   static const int two_blocks = [] { const char* e = getenv("XFMR_ATTN_FWD_SPLIT"); return e ? atoi(e) : 0; }();
-  if (!two_blocks && a.L <= kFusedMaxL) {
+  if (!two_blocks && a.causal && a.L <= kFusedMaxL) {  // the one-workgroup forms walk the causal triangle only
     const size_t sf = bf16_smem_fwd_seq(a.L);
     if (hipFuncSetAttribute((const void*)attn_fwd_seq_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sf) != hipSuccess)
@@ -1120,7 +1125,7 @@ template <bool S16>
 int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
   static const int two_kernels = [] { const char* e = getenv("XFMR_ATTN_BWD_SPLIT"); return e ? atoi(e) : 0; }();
   const size_t sf = bf16_smem_fused(a.L);
-  if (!two_kernels && a.L <= kFusedMaxL && sf <= kLdsLimit) {
+  if (!two_kernels && a.causal && a.L <= kFusedMaxL && sf <= kLdsLimit) {
     if (hipFuncSetAttribute((const void*)attn_bwd_fused_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sf) != hipSuccess)
       return XFMR_EHIP;
@@ -1193,13 +1198,13 @@ extern "C" {
 
 int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t A,
                    int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision, bool s16,
-                   hipStream_t st) {
+                   bool causal, hipStream_t st) {
   if (!qkv || !key_mask || !ctx || !lse) return XFMR_EINVAL;
   if (int rc = check_shape(B, L, A, H)) return rc;
   if (!xf_aligned16(qkv) || !xf_aligned16(ctx)) return XFMR_EALIGN;
   AttnArgs a{};
   a.qkv = (const float*)qkv; a.key_mask = key_mask; a.ctx = (float*)ctx; a.lse = lse; a.B = B; a.L = L; a.A = A;
-  a.H = H;
+  a.H = H; a.causal = causal;
   a.drop = xf_make_dropout(dropout_p, seed, site);
   if (precision == XFMR_PREC_BF16) return s16 ? launch_fwd_bf16<true>(a, st) : launch_fwd<PrecBF16>(a, st);
   if (precision == XFMR_PREC_F32 && !s16) return launch_fwd<PrecF32>(a, st);
@@ -1209,20 +1214,27 @@ int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* l
 int xfmr_attn_fwd(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,
                   int32_t A, int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision,
                   void* stream) {
-  return xf_attn_fwd_ex(qkv, key_mask, ctx, lse, B, L, A, H, dropout_p, seed, site, precision, false,
+  return xf_attn_fwd_ex(qkv, key_mask, ctx, lse, B, L, A, H, dropout_p, seed, site, precision, false, true,
                         (hipStream_t)stream);
+}
+int xfmr_attn_fwd_mode(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,
+                       int32_t A, int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision,
+                       int32_t attn_mode, void* stream) {
+  if (attn_mode != XFMR_ATTN_CAUSAL && attn_mode != XFMR_ATTN_BIDIRECTIONAL) return XFMR_EINVAL;
+  return xf_attn_fwd_ex(qkv, key_mask, ctx, lse, B, L, A, H, dropout_p, seed, site, precision, false,
+                        attn_mode == XFMR_ATTN_CAUSAL, (hipStream_t)stream);
 }
 
 int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* d_ctx,
                    void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, uint64_t seed,
-                   uint32_t site, int32_t precision, bool s16, hipStream_t st) {
+                   uint32_t site, int32_t precision, bool s16, bool causal, hipStream_t st) {
   if (!qkv || !key_mask || !ctx || !lse || !d_ctx || !d_qkv) return XFMR_EINVAL;
   if (int rc = check_shape(B, L, A, H)) return rc;
   if (!xf_aligned16(qkv) || !xf_aligned16(ctx) || !xf_aligned16(d_ctx) || !xf_aligned16(d_qkv)) return XFMR_EALIGN;
   AttnArgs a{};
   a.qkv = (const float*)qkv; a.key_mask = key_mask; a.ctx = (float*)const_cast<void*>(ctx);
   a.lse = const_cast<float*>(lse); a.d_ctx = (const float*)d_ctx; a.d_qkv = (float*)d_qkv;
-  a.B = B; a.L = L; a.A = A; a.H = H;
+  a.B = B; a.L = L; a.A = A; a.H = H; a.causal = causal;
   a.drop = xf_make_dropout(dropout_p, seed, site);
   if (precision == XFMR_PREC_BF16) return s16 ? launch_bwd_bf16<true>(a, st) : launch_bwd<PrecBF16>(a, st);
   if (precision == XFMR_PREC_F32 && !s16) return launch_bwd<PrecF32>(a, st);
@@ -1233,7 +1245,14 @@ int xfmr_attn_bwd(const float* qkv, const uint8_t* key_mask, const float* ctx, c
                   const float* d_ctx, float* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p,
                   uint64_t seed, uint32_t site, int32_t precision, void* stream) {
   return xf_attn_bwd_ex(qkv, key_mask, ctx, lse, d_ctx, d_qkv, B, L, A, H, dropout_p, seed, site, precision, false,
-                        (hipStream_t)stream);
+                        true, (hipStream_t)stream);
+}
+int xfmr_attn_bwd_mode(const float* qkv, const uint8_t* key_mask, const float* ctx, const float* lse,
+                       const float* d_ctx, float* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p,
+                       uint64_t seed, uint32_t site, int32_t precision, int32_t attn_mode, void* stream) {
+  if (attn_mode != XFMR_ATTN_CAUSAL && attn_mode != XFMR_ATTN_BIDIRECTIONAL) return XFMR_EINVAL;
+  return xf_attn_bwd_ex(qkv, key_mask, ctx, lse, d_ctx, d_qkv, B, L, A, H, dropout_p, seed, site, precision, false,
+                        attn_mode == XFMR_ATTN_CAUSAL, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -169,6 +169,7 @@ int check_cfg(const xfmr_encoder_cfg* c) {
   if (c->seq_len > c->max_pos) return XFMR_EINVAL;
   if (c->hidden != c->heads * 32 || (c->inter & 3)) return XFMR_EUNSUPPORTED;
   if (c->precision != XFMR_PREC_F32 && c->precision != XFMR_PREC_BF16) return XFMR_EINVAL;
+  if (c->flags & ~(uint32_t)XFMR_ENC_BIDIRECTIONAL) return XFMR_EINVAL;  // unknown flag bits
   return XFMR_OK;
 }
 
@@ -247,6 +248,7 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
   const int64_t T = (int64_t)B * L;
   const int prec = cfg->precision;
   const bool mix = mixed_storage(cfg);
+  const bool causal = !(cfg->flags & XFMR_ENC_BIDIRECTIONAL);
   hipStream_t st = (hipStream_t)stream;
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
@@ -278,7 +280,7 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     XF_TRY(xf_linear_fwd_ex(xg, W(p.wqkv), params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
                             0.f, 0, 0, prec, (mix ? XF_S16_C : 0) | sA | sB, st));
     XF_TRY(xf_attn_fwd_ex(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, cfg->seed, site_attn(i), prec,
-                          mix, st));
+                          mix, causal, st));
     if (fuse_ln) {  // LayerNorm in the GEMM epilogue (the tile spans whole rows)
       XF_TRY(xf_linear_ln_fwd_ex(l.ctx, W(p.wo), params + p.bo, l.pre1, T, H, H, x, cfg->hidden_dropout, cfg->seed,
                                  site_out(i), params + p.ln1g, params + p.ln1b, cfg->ln_eps, l.x1, l.x1b, l.mean1,
@@ -323,6 +325,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   const int prec = cfg->precision;
   const bool hdrop = cfg->hidden_dropout > 0.f;
   const bool mix = mixed_storage(cfg);
+  const bool causal = !(cfg->flags & XFMR_ENC_BIDIRECTIONAL);
   const uint32_t sA = mix ? XF_S16_A : 0, sC = mix ? XF_S16_C : 0, sP = mix ? XF_S16_P : 0,
                  sAB = mix ? (XF_S16_A | XF_S16_B) : 0, sB = mix ? XF_S16_B : 0;
   auto W = [&](int64_t off) -> const float* {  // weight operand: the bf16 copy the forward pass made
@@ -391,7 +394,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
     XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, a.dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
-                          site_attn(i), prec, mix, st));
+                          site_attn(i), prec, mix, causal, st));
     XF_TRY(xf_linear_bwd_dw_deferred(a.dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, st));
     seg(r.wqkv, grads + p.wqkv, splits, (int64_t)3 * H * H, (int64_t)3 * H * H);
     seg(r.bqkv, grads + p.bqkv, splits, 3 * H, 3 * H);

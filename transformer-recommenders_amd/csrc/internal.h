@@ -38,10 +38,10 @@ int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st);
 int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st);
 int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t A,
                    int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision, bool s16,
-                   hipStream_t st);
+                   bool causal, hipStream_t st);
 int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* d_ctx,
                    void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, uint64_t seed,
-                   uint32_t site, int32_t precision, bool s16, hipStream_t st);
+                   uint32_t site, int32_t precision, bool s16, bool causal, hipStream_t st);
 // loss.hip: deterministic totals of per-block fp64 records [24][nblocks] (each block = rows_per_block queries) ->
 // losses[14], stats[16]; counts = device {n_valid, n_query}; tot = 24 doubles of scratch
 int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, const int* counts, int mode,

@@ -22,6 +22,8 @@ PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES = 0, 1, 2
 NEG_SHARED, NEG_CATALOG = 0, 1
 PROFILE_GRADIENT_PASS, PROFILE_LOGGING_PASS = 0, 1  # xfmr_sampled_loss_profile_pass
+ATTN_CAUSAL, ATTN_BIDIRECTIONAL = 0, 1  # xfmr_attn_{fwd,bwd}_mode
+ENC_BIDIRECTIONAL = 1  # xfmr_encoder_cfg.flags
 NUM_LOSSES, NUM_STATS = 7, 16
 LOSS_IDS = {
     "AlignmentLoss": 0,
@@ -43,7 +45,7 @@ class EncoderCfg(C.Structure):
         ("batch", C.c_int32), ("seq_len", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
         ("inter", C.c_int32), ("layers", C.c_int32), ("max_pos", C.c_int32), ("precision", C.c_int32),
         ("ln_eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float),
-        ("reserved", C.c_uint32), ("seed", C.c_uint64),
+        ("flags", C.c_uint32), ("seed", C.c_uint64),
     ]
 
 
@@ -82,6 +84,10 @@ _SIGNATURES = {
                                 C.c_uint32, C.c_int32, _P]),
     "xfmr_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                 C.c_uint64, C.c_uint32, C.c_int32, _P]),
+    "xfmr_attn_fwd_mode": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
+                                     C.c_uint32, C.c_int32, C.c_int32, _P]),
+    "xfmr_attn_bwd_mode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                     C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _P]),
     "xfmr_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderCfg)]),
     "xfmr_encoder_fwd": (C.c_int, [C.POINTER(EncoderCfg), _P, _P, _P, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "xfmr_encoder_bwd": (C.c_int, [C.POINTER(EncoderCfg), _P, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -132,8 +132,6 @@ class RecommenderModel(torch.nn.Module):
                 f"ModelConfig fields {missing} are None: the reference resolves them by downloading "
                 f"{c.pretrained_model_name!r} (models.py:69-91); this build is offline -- set them explicitly"
             )
-        if not c.is_decoder:
-            raise NotImplementedError("only the causal encoder (is_decoder=True, the reference default) is built")
         if c.hidden_size != 32 * c.num_attention_heads:
             raise ValueError(
                 f"hidden_size / num_attention_heads must be 32 (got {c.hidden_size}/{c.num_attention_heads}): "
@@ -234,6 +232,7 @@ class RecommenderModel(torch.nn.Module):
             hidden_dropout=HIDDEN_DROPOUT_PROB if train else 0.0,
             attn_dropout=ATTENTION_PROBS_DROPOUT_PROB if train else 0.0,
             seed=(self._seed * 0x9E3779B97F4A7C15 + self._step) & 0xFFFFFFFFFFFFFFFF,
+            causal=bool(c.is_decoder),  # BertConfig(is_decoder=...) (models.py:355): False = key-padding mask only
         )
 
     def _encode_tokens(self, item_idx=None, item_embeds=None):

@@ -134,26 +134,30 @@ def colsum(a):
     return out
 
 
-def attn_fwd(qkv, key_mask, heads, *, dropout_p=0.0, seed=0, site=0, precision="bf16"):
+def attn_fwd(qkv, key_mask, heads, *, dropout_p=0.0, seed=0, site=0, precision="bf16", causal=True):
     B, L, H3 = qkv.shape
     H = H3 // 3
     ctx, lse = _empty((B, L, H), qkv), _empty((B, heads, L), qkv)
-    N.check(
-        N.load().xfmr_attn_fwd(N.ptr(qkv), N.ptr(key_mask), N.ptr(ctx), N.ptr(lse), B, L, heads, H, dropout_p, seed,
-                               site, N.precision_id(precision), N.stream()),
-        "xfmr_attn_fwd",
-    )
+    lib = N.load()
+    head = (N.ptr(qkv), N.ptr(key_mask), N.ptr(ctx), N.ptr(lse), B, L, heads, H, dropout_p, seed, site,
+            N.precision_id(precision))
+    if causal:
+        N.check(lib.xfmr_attn_fwd(*head, N.stream()), "xfmr_attn_fwd")
+    else:
+        N.check(lib.xfmr_attn_fwd_mode(*head, N.ATTN_BIDIRECTIONAL, N.stream()), "xfmr_attn_fwd_mode")
     return ctx, lse
 
 
-def attn_bwd(qkv, key_mask, ctx, lse, d_ctx, heads, *, dropout_p=0.0, seed=0, site=0, precision="bf16"):
+def attn_bwd(qkv, key_mask, ctx, lse, d_ctx, heads, *, dropout_p=0.0, seed=0, site=0, precision="bf16", causal=True):
     B, L, H3 = qkv.shape
     d_qkv = torch.empty_like(qkv)
-    N.check(
-        N.load().xfmr_attn_bwd(N.ptr(qkv), N.ptr(key_mask), N.ptr(ctx), N.ptr(lse), N.ptr(d_ctx), N.ptr(d_qkv), B, L,
-                               heads, H3 // 3, dropout_p, seed, site, N.precision_id(precision), N.stream()),
-        "xfmr_attn_bwd",
-    )
+    lib = N.load()
+    head = (N.ptr(qkv), N.ptr(key_mask), N.ptr(ctx), N.ptr(lse), N.ptr(d_ctx), N.ptr(d_qkv), B, L, heads, H3 // 3,
+            dropout_p, seed, site, N.precision_id(precision))
+    if causal:
+        N.check(lib.xfmr_attn_bwd(*head, N.stream()), "xfmr_attn_bwd")
+    else:
+        N.check(lib.xfmr_attn_bwd_mode(*head, N.ATTN_BIDIRECTIONAL, N.stream()), "xfmr_attn_bwd_mode")
     return d_qkv
 
 
@@ -310,11 +314,11 @@ def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head,
 
 # ------------------------------------------------------------------------------------------------ encoder
 def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, precision, ln_eps=1e-12,
-                     hidden_dropout=0.0, attn_dropout=0.0, seed=0) -> N.EncoderCfg:
+                     hidden_dropout=0.0, attn_dropout=0.0, seed=0, causal=True) -> N.EncoderCfg:
     return N.EncoderCfg(
         batch=batch, seq_len=seq_len, hidden=hidden, heads=heads, inter=inter, layers=layers, max_pos=max_pos,
         precision=N.precision_id(precision), ln_eps=ln_eps, hidden_dropout=hidden_dropout,
-        attn_dropout=attn_dropout, reserved=0, seed=seed,
+        attn_dropout=attn_dropout, flags=0 if causal else N.ENC_BIDIRECTIONAL, seed=seed,
     )
 
 
