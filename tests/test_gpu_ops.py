@@ -364,6 +364,99 @@ def test_linear_with_layernorm_in_the_epilogue(ops, K, M, p_drop, bf16_storage):
     assert torch.equal(y16, y.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("chunk", ["64", "128"])
+@pytest.mark.parametrize("M,I,p_drop", [(300, 512, 0.0), (4096 + 17, 512, 0.2), (1000, 128, 0.1), (102400, 512, 0.1)])
+def test_ffn_forward_in_one_kernel_vs_the_two_gemm_form(ops, M, I, p_drop, chunk, monkeypatch):
+    """xf_ffn_fwd_fused_ex (FFN1 -> GELU -> FFN2 -> dropout + residual + LayerNorm, TF:modeling_bert.py:325-351, in one
+    kernel; the encoder forward's path at T >= 16 384, H = 128) against the two launches it replaces
+    (xf_linear_fwd_ex with the GELU epilogue, xf_linear_ln_fwd_ex). The only arithmetic difference: the fused kernel
+    rounds the pre-activation to bf16 before the GELU (as bf16 autocast holds it), the two-kernel form rounds after --
+    so g / gelu' agree to a bf16 ulp and everything downstream to bf16 rounding noise; against an fp64 restatement of
+    the fused kernel's own rounding points the pre-LayerNorm sum agrees to fp32 accumulation error. Partial last tile,
+    dropout, the benchmark's row count, and both chunk widths (XFMR_FFN_CHUNK, read per call)."""
+    import ctypes as C
+
+    from xfmr_rec_amd import _native as N
+
+    lib = N.load()
+    H = 128
+    g = torch.Generator().manual_seed(M + I)
+    x16 = torch.randn(M, H, generator=g).to(DEV).to(torch.bfloat16)
+    w1 = (torch.randn(I, H, generator=g) * 0.08).to(DEV).to(torch.bfloat16)
+    b1 = (0.1 * torch.randn(I, generator=g)).to(DEV)
+    w2 = (torch.randn(H, I, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    b2 = (0.1 * torch.randn(H, generator=g)).to(DEV)
+    res = torch.randn(M, H, generator=g).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(H, generator=g)).to(DEV)
+
+    def outs():
+        return dict(g=torch.empty(M, I, device=DEV, dtype=torch.bfloat16), d=torch.empty(M, I, device=DEV, dtype=torch.bfloat16),
+                    pre=torch.empty(M, H, device=DEV), y=torch.empty(M, H, device=DEV),
+                    y16=torch.empty(M, H, device=DEV, dtype=torch.bfloat16), mean=torch.empty(M, device=DEV),
+                    rstd=torch.empty(M, device=DEV))
+
+    # the two-kernel form, with the encoder's storage masks (bf16 A, B, C; gelu' as the auxiliary output)
+    ref = outs()
+    f1 = lib.xf_linear_fwd_ex
+    f1.restype = C.c_int
+    f1.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
+                                      C.c_uint64, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p]
+    rc = f1(N.ptr(x16), N.ptr(w1), N.ptr(b1), N.ptr(ref["g"]), M, I, H, N.EPI_BIAS_GELU, None, N.ptr(ref["d"]), 0.0, 0, 0,
+            N.precision_id("bf16"), 1 | 2 | 4 | 0x100, N.stream())
+    assert rc == 0, rc
+    f2 = lib.xf_linear_ln_fwd_ex
+    f2.restype = C.c_int
+    f2.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32,
+                                      C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 4 + [C.c_int32, C.c_uint32,
+                                                                                               C.c_void_p]
+    rc = f2(N.ptr(ref["g"]), N.ptr(w2), N.ptr(b2), N.ptr(ref["pre"]), M, H, I, N.ptr(res), p_drop, 5, 9, N.ptr(gamma),
+            N.ptr(beta), 1e-12, N.ptr(ref["y"]), N.ptr(ref["y16"]), N.ptr(ref["mean"]), N.ptr(ref["rstd"]),
+            N.precision_id("bf16"), 3, N.stream())
+    assert rc == 0, rc
+
+    monkeypatch.setenv("XFMR_FFN_CHUNK", chunk)  # read per call
+    fn = lib.xf_ffn_fwd_fused_ex
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32,
+                                      C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 5
+
+    def run():
+        o = outs()
+        rc = fn(N.ptr(x16), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), N.ptr(o["g"]), N.ptr(o["d"]), N.ptr(o["pre"]), M, H,
+                I, N.ptr(res), p_drop, 5, 9, N.ptr(gamma), N.ptr(beta), 1e-12, N.ptr(o["y"]), N.ptr(o["y16"]),
+                N.ptr(o["mean"]), N.ptr(o["rstd"]), N.stream())
+        assert rc == 0, rc
+        return o
+
+    got = run()
+    # g and gelu': one bf16 ulp of each other (rounding u first moves the result by at most the rounding of u)
+    for k in ("g", "d"):
+        a, b = got[k].float(), ref[k].float()
+        # two roundings (u, then the value) against one: a bf16 ulp of the value plus gelu's slope times a bf16 ulp of u
+        assert bool(((a - b).abs() <= 2.0 ** -6 * b.abs() + 4e-3).all()), k
+        assert rel_l2(a, b) <= 5e-3, k
+    assert rel_l2(got["pre"], ref["pre"]) <= 2e-3 and rel_l2(got["y"], ref["y"]) <= 2e-3
+    assert torch.equal(got["y16"], got["y"].to(torch.bfloat16))
+    # the fused kernel's own rounding points, restated in fp64 (without dropout: the mask is the shared hash)
+    if p_drop == 0.0:
+        u = (x16.double() @ w1.double().T + b1.double()).to(torch.bfloat16)
+        gg = torch.nn.functional.gelu(u.double()).to(torch.bfloat16)
+        n_off = int((gg != got["g"]).sum())  # fp32-vs-fp64 accumulation flips a bf16 rounding now and then
+        assert n_off <= 2e-3 * gg.numel(), n_off
+        pre = got["g"].double() @ w2.double().T + b2.double() + res.double()
+        torch.testing.assert_close(got["pre"].double(), pre, rtol=2e-5, atol=2e-5)
+        ln = torch.nn.functional.layer_norm(pre, (H,), gamma.double(), beta.double(), 1e-12)
+        torch.testing.assert_close(got["y"].double(), ln, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(got["mean"].double(), pre.mean(-1), rtol=1e-5, atol=1e-5)
+    again = run()  # no atomics, fixed reduction orders: bit-reproducible
+    assert all(torch.equal(got[k], again[k]) for k in got)
+    # arguments the kernel is not built for fail loudly
+    bad = fn(N.ptr(x16), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), None, None, N.ptr(got["pre"]), M, H, 96, N.ptr(res), 0.0,
+             0, 0, N.ptr(gamma), N.ptr(beta), 1e-12, N.ptr(got["y"]), None, N.ptr(got["mean"]), N.ptr(got["rstd"]), N.stream())
+    assert bad == -2  # XFMR_EUNSUPPORTED
+
+
 @pytest.mark.parametrize("Nn,p_drop", [(512, 0.1), (384, 0.0)])  # FFN1 dX (+ LayerNorm 1) / QKV dX (+ LayerNorm 2)
 def test_dx_gemm_with_layernorm_backward_epilogue_vs_separate_kernels_and_bit_reproducible(ops, Nn, p_drop):
     """xf_linear_bwd_dx_lnbwd_ex (the dX GEMM whose epilogue applies the LayerNorm backward of the row it produces)

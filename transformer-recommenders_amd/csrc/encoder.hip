@@ -94,6 +94,13 @@ bool mixed_storage(const xfmr_encoder_cfg* c) {
   }();
   return c->precision == XFMR_PREC_BF16 && !force_fp32;
 }
+// FFN1 -> GELU -> FFN2 -> LayerNorm as one forward kernel (gemm.hip: ffn_fwd_fused_kernel): same conditions as the
+// LayerNorm-fused GEMM epilogues plus I a multiple of its chunk widths. It saves the tensors the two-kernel form saves.
+bool ffn_fused(const xfmr_encoder_cfg* c, int64_t T) {
+  auto on = [](const char* name) { const char* e = getenv(name); return e && *e && *e != '0'; };
+  return mixed_storage(c) && c->hidden == 128 && T >= 16384 && (c->inter % 128) == 0 && !on("XFMR_LN_UNFUSED") &&
+         !on("XFMR_FFN_UNFUSED");
+}
 
 // Carves `base` (may be null: size query). Layer i's activations are returned in *la when i >= 0.
 Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs* la, RedBufs* rb = nullptr) {
@@ -269,6 +276,7 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
   // out-proj / FFN2 GEMM + LayerNorm as one kernel: its 64 x 128 tiles are T / 64 workgroups -- below one per CU
   // (T < 16 384) the two-kernel form with 64 x 64 tiles is faster (batch 32: -1.5 % fused; batch 128: +0.9 %; 512: +1.8 %)
   const bool fuse_ln = mix && H == 128 && T >= 16384 && !no_fuse;
+  const bool fuse_ffn = ffn_fused(cfg, T);
   auto W = [&](int64_t off) -> const float* {  // weight operand: the bf16 copy under mixed storage
     return mix ? reinterpret_cast<const float*>((const __bf16*)a.wbf + off) : params + off;
   };
@@ -291,10 +299,18 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
       XF_TRY(xf_layernorm_fwd_ex(l.pre1, params + p.ln1g, params + p.ln1b, l.x1, mix ? l.x1b : nullptr, l.mean1,
                                  l.rstd1, T, H, cfg->ln_eps, st));
     }
+    const bool last = i == cfg->layers - 1;
+    if (fuse_ffn) {  // FFN1 -> GELU -> FFN2 -> dropout + residual + LayerNorm in one kernel; g, f1 <- gelu, gelu'
+      XF_TRY(xf_ffn_fwd_fused_ex(l.x1b, W(p.w1), params + p.b1, W(p.w2), params + p.b2, l.g, l.f1, l.pre2, T, H, I, l.x1,
+                                 cfg->hidden_dropout, cfg->seed, site_ffn(i), params + p.ln2g, params + p.ln2b,
+                                 cfg->ln_eps, out, last ? nullptr : l.x2b, l.mean2, l.rstd2, st));
+      x = out;
+      xg = mix ? (const void*)l.x2b : (const void*)out;
+      continue;
+    }
     XF_TRY(xf_linear_fwd_ex(mix ? (const void*)l.x1b : (const void*)l.x1, W(p.w1), params + p.b1, l.g, T, I, H,
                             XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f, 0, 0, prec,
                             (mix ? XF_S16_C : 0) | sA | sB | XF_AUX_GELU_GRAD, st));  // f1 <- gelu'(pre)
-    const bool last = i == cfg->layers - 1;
     if (fuse_ln) {
       XF_TRY(xf_linear_ln_fwd_ex(l.g, W(p.w2), params + p.b2, l.pre2, T, H, I, l.x1, cfg->hidden_dropout, cfg->seed,
                                  site_ffn(i), params + p.ln2g, params + p.ln2b, cfg->ln_eps, out,

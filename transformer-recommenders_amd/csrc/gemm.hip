@@ -10,6 +10,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "internal.h"
 
 // A per-row scalar that is broadcast into packed-fp32 arithmetic (v_pk_add/mul/fma_f32 on register pairs) is made
@@ -20,6 +22,12 @@
 #define XF_PIN_SCALAR(x) asm volatile("" : "+v"(x))
 #ifndef XF_LN_DIAG
 #define XF_LN_DIAG 0  // 32 (with -DXF_LN_EPI_MIN_WAVES=1): the unpinned build that reproduces the fault (scripts/probe/lnbwd_determinism.py)
+#endif
+#ifndef XF_GEMM_PF
+#define XF_GEMM_PF 1  // operand K slices in flight per workgroup (gemm_kernel)
+#endif
+#ifndef XF_FFN_MIN_WAVES
+#define XF_FFN_MIN_WAVES 2
 #endif
 #ifndef XF_LN_EPI_MIN_WAVES
 #define XF_LN_EPI_MIN_WAVES 3  // launch bound (waves per SIMD) of the two LayerNorm-fused epilogues: DESIGN.md section 4
@@ -58,6 +66,19 @@ struct GemmArgs {
   void* D16; float* lnb_partials;
   XfDropout drop2;  // EPI_DX_LNBWD: dropout that was applied to the LayerNorm OUTPUT (embedding site); off otherwise
 };
+
+// gelu and gelu' of eight bf16 values (one erf / exp each), both rounded back to bf16
+__device__ __forceinline__ float4 xf_gelu_both_bf16x8(float4 raw4, float4& grad8) {
+  const uint4 raw = *reinterpret_cast<const uint4*>(&raw4);
+  float4 lo = xf_bf16x4_to_f32(make_uint2(raw.x, raw.y)), hi = xf_bf16x4_to_f32(make_uint2(raw.z, raw.w));
+  float4 dl, dh;
+  lo.x = xf_gelu_both(lo.x, dl.x); lo.y = xf_gelu_both(lo.y, dl.y); lo.z = xf_gelu_both(lo.z, dl.z); lo.w = xf_gelu_both(lo.w, dl.w);
+  hi.x = xf_gelu_both(hi.x, dh.x); hi.y = xf_gelu_both(hi.y, dh.y); hi.z = xf_gelu_both(hi.z, dh.z); hi.w = xf_gelu_both(hi.w, dh.w);
+  const uint2 a = xf_f32x4_to_bf16(lo), b = xf_f32x4_to_bf16(hi), c = xf_f32x4_to_bf16(dl), d = xf_f32x4_to_bf16(dh);
+  const uint4 o = make_uint4(a.x, a.y, b.x, b.y), od = make_uint4(c.x, c.y, d.x, d.y);
+  grad8 = *reinterpret_cast<const float4*>(&od);
+  return *reinterpret_cast<const float4*>(&o);
+}
 
 // One operand tile (ROWS x BK, fp32 in memory) in flight in registers, then committed to an LDS image of the
 // MFMA element type.
@@ -259,6 +280,116 @@ __device__ __forceinline__ TileIdx tile_of(const int nt_n, const int nt_m, const
   return t;
 }
 
+// Epilogue of a 64 x 128 tile that spans whole output rows (N == 128), computed by 2 x 2 waves (wave = 32 rows x 64
+// columns, acc[j] = its 32 x 32 block j): bias + dropout + residual -> C (the pre-LayerNorm sum, kept for the backward),
+// LayerNorm -> Y (fp32) / Y16 (bf16 GEMM operand), mean / rstd per row. `smem`: >= 4 strips of 16 x 68 floats + 128
+// floats, free of live data (the callers alias their operand images after a barrier).
+__device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], unsigned char* smem, const GemmArgs& g,
+                                                       const int64_t m0, const int wid, const int lane) {
+  // The wave owns 32 rows x 64 columns; a row's other 64 columns are with the partner wave (wc ^ 1). Lane ->
+  // (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3): 16 lanes per row, 8 rows per lane, all kept in registers.
+  constexpr int LPRL = 16, RPPL = 4, NPL = 4, WM = 32, WN = 64, NI = 2, SCR_LD = WN + 4;
+  const int wr = wid >> 1, wc = wid & 1;
+  float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
+  float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 wr][2 wc][32 rows] x 2 (sum, sumsq)
+  const int prow = lane / LPRL, li = lane % LPRL, c0 = li * 4;
+  const int n = wc * WN + c0;  // (n0 == 0: one N tile)
+  const float4 bias = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0, 0, 0, 0);
+  float4 vv[2][NPL];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int64_t mb = m0 + wr * WM + 16 * hf;
+    float4 aux[NPL];
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      aux[ps] = make_float4(0, 0, 0, 0);
+      const int64_t m = mb + prow + RPPL * ps;
+      if (m < g.M) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * g.ldc + n);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[j][8 * hf + r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      const int row = prow + RPPL * ps;
+      const int64_t m = mb + row;
+      float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
+      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+      if (g.drop.on) {
+        const uint32_t e = (uint32_t)(m * g.N + n);
+        v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
+        v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
+      }
+      v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
+      if (m >= g.M) v = make_float4(0, 0, 0, 0);
+      else *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = v;
+      vv[hf][ps] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();  // every wave is done with its scratch strip before `red` (behind the strips) is written
+  auto row_reduce = [&](float x) {  // over the 16 lanes that hold a row's 64 columns of this wave
+    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+    return x;
+  };
+  float mean[2][NPL];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      const float4 v = vv[hf][ps];
+      const float s = row_reduce((v.x + v.y) + (v.z + v.w));
+      if (li == 0) red[(wr * 2 + wc) * 32 + 16 * hf + prow + RPPL * ps] = s;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      const int rr = 16 * hf + prow + RPPL * ps;
+      mean[hf][ps] = (red[(wr * 2) * 32 + rr] + red[(wr * 2 + 1) * 32 + rr]) * (1.f / 128.f);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      float4& v = vv[hf][ps];
+      const float mu = mean[hf][ps];
+      v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+      const float s = row_reduce((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+      if (li == 0) red[(wr * 2 + wc) * 32 + 16 * hf + prow + RPPL * ps] = s;
+    }
+  __syncthreads();
+  const float4 gm = *reinterpret_cast<const float4*>(g.ln_gamma + n);
+  const float4 bt = *reinterpret_cast<const float4*>(g.ln_beta + n);
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      const int rr = 16 * hf + prow + RPPL * ps;
+      const int64_t m = m0 + wr * WM + rr;
+      const float var = (red[(wr * 2) * 32 + rr] + red[(wr * 2 + 1) * 32 + rr]) * (1.f / 128.f);
+      const float rs = rsqrtf(var + g.ln_eps);
+      if (m >= g.M) continue;
+      const float4 d = vv[hf][ps];
+      float4 o;
+      o.x = d.x * rs * gm.x + bt.x; o.y = d.y * rs * gm.y + bt.y;
+      o.z = d.z * rs * gm.z + bt.z; o.w = d.w * rs * gm.w + bt.w;
+      *reinterpret_cast<float4*>(g.Y + m * g.ldc + n) = o;
+      if (g.Y16) xf_st4<true>(g.Y16, m * g.ldc + n, o);
+      if (wc == 0 && li == 0) {
+        g.ln_mean[m] = mean[hf][ps];
+        g.ln_rstd[m] = rs;
+      }
+    }
+}
+
 // S = XF_S16_* storage mask (compile time: a runtime switch between the fp32 and bf16 load paths cost the
 // forward / dX GEMMs 15-80 %).
 template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S>
@@ -309,24 +440,31 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  TileA ta;
-  TileB tb;
+  // XF_GEMM_PF operand slices in flight in registers. Measured with two (both slices of a K = 128 GEMM issued up front):
+  // 58 more VGPRs, one workgroup fewer per CU, 3.77 against 3.67 ms/step -- co-resident workgroups hide the round
+  // trips better than a deeper prefetch inside one; a launch bound of 5 waves for the forward GEMMs (96 VGPRs) changed
+  // nothing (3.758 / 3.759). One slice it stays.
+  constexpr int PF = EPI == EPI_SPLITK ? 1 : XF_GEMM_PF;  // (split-K dW: a dozen 128-deep slices; one workgroup more per CU wins)
+  TileA ta[PF];
+  TileB tb[PF];
   const bool do_bias = (EPI == EPI_SPLITK) && TA && g.bias_part != nullptr && tix.n == 0;
   float4 bsum[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
   const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk > 0) {
-    ta.template load<a16>(g.A, g.lda, m0, g.M, kbeg, kend);
-    tb.template load<b16>(g.B, g.ldb, n0, g.N, kbeg, kend);
-  }
-  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < nk) {
+      ta[p].template load<a16>(g.A, g.lda, m0, g.M, kbeg + p * BK, kend);
+      tb[p].template load<b16>(g.B, g.ldb, n0, g.N, kbeg + p * BK, kend);
+    }
+  auto k_slice = [&](TileA& tac, TileB& tbc, const int kt) {
     __syncthreads();
-    if (do_bias) ta.template add_rowsum<a16>(bsum);
-    ta.template commit<a16>(sA);
-    tb.template commit<b16>(sB);
+    if (do_bias) tac.template add_rowsum<a16>(bsum);
+    tac.template commit<a16>(sA);
+    tbc.template commit<b16>(sB);
     __syncthreads();
-    if (kt + 1 < nk) {  // next slice in flight while this one is multiplied
-      ta.template load<a16>(g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend);
-      tb.template load<b16>(g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend);
+    if (kt + PF < nk) {  // the slice PF steps ahead goes into the registers just committed
+      tac.template load<a16>(g.A, g.lda, m0, g.M, kbeg + (kt + PF) * BK, kend);
+      tbc.template load<b16>(g.B, g.ldb, n0, g.N, kbeg + (kt + PF) * BK, kend);
     }
 #pragma unroll
     for (int k0 = 0; k0 < BK; k0 += FA::KS) {
@@ -341,6 +479,13 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = xf_mma(fa[i], fb[j], acc[i][j]);
     }
+  };
+#pragma unroll 1
+  for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+    k_slice(ta[0], tb[0], kt0);
+    if constexpr (PF > 1) {
+      if (kt0 + 1 < nk) k_slice(ta[PF - 1], tb[PF - 1], kt0 + 1);
+    }
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------
@@ -350,109 +495,7 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
   // (one wave instruction = 4-8 rows x 128-256 B instead of 2 rows x 32 scattered 4- or 2-byte elements).
   __syncthreads();  // everyone is done with the operand images the scratch aliases
   if constexpr (EPI == EPI_DROP_RES_LN) {
-    if constexpr (BM == 64 && BN == 128) {
-      // The wave owns 32 rows x 64 columns; a row's other 64 columns are with the partner wave (wc ^ 1). Lane ->
-      // (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3): 16 lanes per row, 8 rows per lane, all kept in registers.
-      constexpr int LPRL = 16, RPPL = 4, NPL = 4;
-      float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
-      float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 wr][2 wc][32 rows] x 2 (sum, sumsq)
-      const int prow = lane / LPRL, li = lane % LPRL, c0 = li * 4;
-      const int n = wc * WN + c0;  // (n0 == 0: one N tile)
-      const float4 bias = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0, 0, 0, 0);
-      float4 vv[2][NPL];
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int64_t mb = m0 + wr * WM + 16 * hf;
-        float4 aux[NPL];
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          aux[ps] = make_float4(0, 0, 0, 0);
-          const int64_t m = mb + prow + RPPL * ps;
-          if (m < g.M) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * g.ldc + n);
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[0][j][8 * hf + r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          const int row = prow + RPPL * ps;
-          const int64_t m = mb + row;
-          float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
-          v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-          if (g.drop.on) {
-            const uint32_t e = (uint32_t)(m * g.N + n);
-            v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
-            v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
-          }
-          v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
-          if (m >= g.M) v = make_float4(0, 0, 0, 0);
-          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = v;
-          vv[hf][ps] = v;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-      }
-      __syncthreads();  // every wave is done with its scratch strip before `red` (behind the strips) is written
-      auto row_reduce = [&](float x) {  // over the 16 lanes that hold a row's 64 columns of this wave
-        x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
-        return x;
-      };
-      float mean[2][NPL];
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          const float4 v = vv[hf][ps];
-          const float s = row_reduce((v.x + v.y) + (v.z + v.w));
-          if (li == 0) red[(wr * 2 + wc) * 32 + 16 * hf + prow + RPPL * ps] = s;
-        }
-      __syncthreads();
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          const int rr = 16 * hf + prow + RPPL * ps;
-          mean[hf][ps] = (red[(wr * 2) * 32 + rr] + red[(wr * 2 + 1) * 32 + rr]) * (1.f / 128.f);
-        }
-      __syncthreads();
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          float4& v = vv[hf][ps];
-          const float mu = mean[hf][ps];
-          v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
-          const float s = row_reduce((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
-          if (li == 0) red[(wr * 2 + wc) * 32 + 16 * hf + prow + RPPL * ps] = s;
-        }
-      __syncthreads();
-      const float4 gm = *reinterpret_cast<const float4*>(g.ln_gamma + n);
-      const float4 bt = *reinterpret_cast<const float4*>(g.ln_beta + n);
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          const int rr = 16 * hf + prow + RPPL * ps;
-          const int64_t m = m0 + wr * WM + rr;
-          const float var = (red[(wr * 2) * 32 + rr] + red[(wr * 2 + 1) * 32 + rr]) * (1.f / 128.f);
-          const float rs = rsqrtf(var + g.ln_eps);
-          if (m >= g.M) continue;
-          const float4 d = vv[hf][ps];
-          float4 o;
-          o.x = d.x * rs * gm.x + bt.x; o.y = d.y * rs * gm.y + bt.y;
-          o.z = d.z * rs * gm.z + bt.z; o.w = d.w * rs * gm.w + bt.w;
-          *reinterpret_cast<float4*>(g.Y + m * g.ldc + n) = o;
-          if (g.Y16) xf_st4<true>(g.Y16, m * g.ldc + n, o);
-          if (wc == 0 && li == 0) {
-            g.ln_mean[m] = mean[hf][ps];
-            g.ln_rstd[m] = rs;
-          }
-        }
-    }
+    if constexpr (BM == 64 && BN == 128) epi_drop_res_ln_64x128(acc[0], smem, g, m0, wid, lane);
     return;
   }
   if constexpr (EPI == EPI_DX_LNBWD) {
@@ -707,6 +750,185 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
   }
 }
 
+// ---- fused FFN forward (bf16 storage, H = 128) -----------------------------------------------------------------------
+//   u = x W1^T + b1 (T x I)  ->  g = gelu(u)  ->  y = g W2^T + b2  ->  dropout, + residual, LayerNorm
+// (TF:modeling_bert.py:325-351) in ONE kernel: a workgroup owns 64 token rows and walks I in chunks of CH columns; the
+// second GEMM reads g from LDS, never from HBM. g and gelu'(u) are still WRITTEN (bf16): the backward's dW2 GEMM and
+// FFN2 dX epilogue read them, exactly as after the two-kernel form -- the saved tensors are the same, so either
+// forward pairs with the one backward. (Storing only u and applying gelu on the dW2 GEMM's way into LDS was measured:
+// the dW2 GEMM went from 27 to 53 us, more than the 105 MB of writes it saved.) u is rounded to bf16 BEFORE the GELU, as
+// the reference's bf16 autocast holds the Linear's output. Per layer at T = 102 400, I = 512: 418 MB instead of 524 MB.
+//   LDS (CH = 64): sG [64][72] bf16 (u, then g in place: the A operand of the second GEMM) + sW 18 KB (the W1 chunk
+//   [64][136], then the W2 chunk [128][72]; the x tile before the first chunk, the epilogue's scratch after the last):
+//   27.6 KB. The x tile's MFMA fragments stay in registers for the whole tile (32 VGPRs); 168 VGPRs = 3 waves per SIMD.
+//   Weights stream from L2 (256 KB per layer, shared by every workgroup) through two register sets, a chunk ahead.
+//   Measured at T = 102 400 (rocprofv3): 110 us against 59 + 65 us for the two launches it replaces; the step gains
+//   0 ... 0.7 % (the pair was not bound by the re-read of g). Tried and not kept: 128-column chunks (two workgroups
+//   per CU: 118 us); barriers that leave global operations in flight (s_waitcnt lgkmcnt(0) + s_barrier: 127 us).
+struct FfnFwdArgs {
+  const __bf16* X;    // [M][128]
+  const __bf16* W1;   // [I][128]
+  const float* b1;    // [I]
+  const __bf16* W2;   // [128][I]
+  __bf16* G;          // [M][I] gelu(u) out: the dW2 operand (null: not stored -- inference)
+  __bf16* D;          // [M][I] gelu'(u) out: the FFN2 dX epilogue's factor (null: not stored)
+  int I;
+  GemmArgs e;         // the LayerNorm epilogue's arguments: M, N = 128, ldc = 128, bias = b2, R, C, drop, ln_*, Y, Y16
+};
+
+// One weight chunk of the fused FFN forward in flight in registers: W1 rows [c CH, +CH) x 128 (image [CH][136]) or
+// W2 columns [c CH, +CH) of all 128 rows (image [128][CH + 8]); 16-byte pieces, CH / 16 per thread.
+template <int N, class F>
+__device__ __forceinline__ void xf_static_for(F&& fn) {  // fn(integral_constant<int, 0>) ... fn(<N - 1>): indices are
+  if constexpr (N > 0) {                                  // constants at the source level (register arrays stay in registers)
+    xf_static_for<N - 1>(fn);
+    fn(std::integral_constant<int, N - 1>{});
+  }
+}
+template <int CH>
+struct WeightChunk {
+  static constexpr int NW = CH / 16, PC = CH / 8, H = 128, LDH = H + 8, LDC = CH + 8;
+  bf16x8 reg[NW];  // (a native vector type: HIP's uint4 / float4 structs are copied with memcpy between address
+                   //  spaces, which kept this array in scratch memory)
+  __device__ __forceinline__ void load_w1(const __bf16* W1, int c, int tid) {
+    xf_static_for<NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, row = p >> 4, ch = p & 15;
+      reg[i] = *reinterpret_cast<const bf16x8*>(W1 + (int64_t)(c * CH + row) * H + ch * 8);
+    });
+  }
+  __device__ __forceinline__ void commit_w1(__bf16* sW, int tid) const {
+    xf_static_for<NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, row = p >> 4, ch = p & 15;
+      *reinterpret_cast<bf16x8*>(sW + row * LDH + ch * 8) = reg[i];
+    });
+  }
+  __device__ __forceinline__ void load_w2(const __bf16* W2, int I, int c, int tid) {
+    xf_static_for<NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, row = p / PC, ch = p % PC;
+      reg[i] = *reinterpret_cast<const bf16x8*>(W2 + (int64_t)row * I + c * CH + ch * 8);
+    });
+  }
+  __device__ __forceinline__ void commit_w2(__bf16* sW, int tid) const {
+    xf_static_for<NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, row = p / PC, ch = p % PC;
+      *reinterpret_cast<bf16x8*>(sW + row * LDC + ch * 8) = reg[i];
+    });
+  }
+};
+
+template <int CH>  // columns of I per chunk: 128 (two workgroups' worth of registers) or 64
+__global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd_fused_kernel(FfnFwdArgs f) {
+  constexpr int H = 128, LDH = H + 8, LDC = CH + 8, BM = 64;
+  constexpr int NJ = CH / 64;           // 32-column blocks of the u chunk per wave (2 x 2 waves over 64 x CH)
+  constexpr int W_ELEMS = CH * LDH > H * LDC ? CH * LDH : H * LDC;
+  __shared__ __attribute__((aligned(16))) __bf16 sG[BM * LDC];
+  __shared__ __attribute__((aligned(16))) __bf16 sW[W_ELEMS];
+  static_assert(W_ELEMS >= BM * LDH, "the x tile is staged through sW");
+  static_assert(W_ELEMS * 2 >= 4 * 16 * 68 * 4 + 128 * 4, "the LayerNorm epilogue's scratch aliases sW");
+  using FR = Frag<PrecBF16, false>;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tid = threadIdx.x;
+  const int wr = wid >> 1, wc = wid & 1;
+  const TileIdx tix = tile_of(1, f.e.nt_m, 1);
+  if (!tix.valid) return;
+  const int64_t m0 = (int64_t)tix.m * BM;
+  const int64_t M = f.e.M;
+  const int I = f.I, nchunk = I / CH;
+
+  // two weight chunks in flight, each for a whole chunk period: W1(c + 1) from the first GEMM of chunk c on, W2(c + 1)
+  // from its second GEMM on (with ONE set, issued a GEMM ahead, the L2 round trip was exposed twice per chunk)
+  WeightChunk<CH> wa, wb;
+  constexpr int PC = CH / 8;  // 16-byte pieces per row of a [rows][CH] image
+
+  // x tile -> sW (as a [64][136] image) -> this wave's A fragments of all 8 k-steps
+  {
+    uint4 xr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + i * 256, row = p >> 4, ch = p & 15;
+      xr[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (m0 + row < M) xr[i] = *reinterpret_cast<const uint4*>(f.X + (m0 + row) * H + ch * 8);
+    }
+    wa.load_w1(f.W1, 0, tid);
+    wb.load_w2(f.W2, I, 0, tid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + i * 256, row = p >> 4, ch = p & 15;
+      *reinterpret_cast<uint4*>(sW + row * LDH + ch * 8) = xr[i];
+    }
+  }
+  __syncthreads();
+  bf16x8 xa[H / 16];
+#pragma unroll
+  for (int ks = 0; ks < H / 16; ++ks) xa[ks] = FR::get(sW, LDH, wr * 32, ks * 16);
+
+  f32x16 accy[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accy[j][r] = 0.f;
+
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();  // the previous chunk's second GEMM (or the fragment reads above) is done with sW and sG
+    wa.commit_w1(sW, tid);  // W1 chunk c
+    __syncthreads();
+    if (c + 1 < nchunk) wa.load_w1(f.W1, c + 1, tid);
+    f32x16 accu[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accu[j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < H / 16; ++ks) {
+      bf16x8 fb[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = FR::get(sW, LDH, wc * (CH / 2) + j * 32, ks * 16);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) accu[j] = xf_mma(xa[ks], fb[j], accu[j]);
+    }
+    // u = acc + b1 -> bf16 -> sG (accumulator layout: element r of lane l = row (r&3) + 8 (r>>2) + 4 (l>>5), col l&31)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = wc * (CH / 2) + j * 32 + (lane & 31);
+      const float b = f.b1[c * CH + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sG[(wr * 32 + xf_acc_row(r, lane)) * LDC + col] = (__bf16)(accu[j][r] + b);
+    }
+    __syncthreads();  // sG holds u; every wave is done with the W1 chunk
+    // row-major pass over sG in 16-byte pieces: g = gelu(u) and gelu'(u) -> HBM, g back in place (the second GEMM's A operand)
+#pragma unroll
+    for (int i = 0; i < BM * PC / 256; ++i) {
+      const int p = tid + i * 256, row = p / PC, ch = p % PC;
+      float4* cell = reinterpret_cast<float4*>(sG + row * LDC + ch * 8);
+      const float4 u8 = *cell;
+      float4 d8;
+      const float4 g8 = xf_gelu_both_bf16x8(u8, d8);
+      if (m0 + row < M) {
+        if (f.G) *reinterpret_cast<float4*>(f.G + (m0 + row) * I + c * CH + ch * 8) = g8;
+        if (f.D) *reinterpret_cast<float4*>(f.D + (m0 + row) * I + c * CH + ch * 8) = d8;
+      }
+      *cell = g8;
+    }
+    wb.commit_w2(sW, tid);  // W2 chunk c
+    __syncthreads();
+    if (c + 1 < nchunk) wb.load_w2(f.W2, I, c + 1, tid);
+#pragma unroll
+    for (int ks = 0; ks < CH / 16; ++ks) {
+      const bf16x8 fa = FR::get(sG, LDC, wr * 32, ks * 16);
+      bf16x8 fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = FR::get(sW, LDC, wc * 64 + j * 32, ks * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) accy[j] = xf_mma(fa, fb[j], accy[j]);
+    }
+  }
+  __syncthreads();  // everyone is done with sW: the epilogue's scratch aliases it
+  epi_drop_res_ln_64x128(accy, reinterpret_cast<unsigned char*>(sW), f.e, m0, wid, lane);
+}
+
 // Deterministic column sums of a [rows, cols] fp32 matrix: block (x, y) sums rows [y*rows_per, (y+1)*rows_per)
 // of 64 columns with 4 row groups in flight (each wave instruction reads 256 contiguous bytes), combines the
 // groups through LDS in a fixed order and writes dst[y*cols + col]. Used for bias gradients (two levels) and
@@ -934,6 +1156,35 @@ int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y,
                     uint32_t site, int32_t precision, void* stream) {
   return xf_linear_fwd_ex(x, w, bias, y, M, N, K, epilogue, residual, aux_out, dropout_p, seed, site, precision, 0,
                           (hipStream_t)stream);
+}
+
+int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, const void* w2_16, const float* b2,
+                        void* g16, void* d16, float* pre, int64_t M, int32_t H, int32_t I, const float* residual, float dropout_p,
+                        uint64_t seed, uint32_t site, const float* gamma, const float* beta, float eps, float* y,
+                        void* y16, float* mean, float* rstd, hipStream_t st) {
+  if (!x16 || !w1_16 || !b1 || !w2_16 || !pre || !residual || !gamma || !beta || !y || !mean || !rstd || M <= 0)
+    return XFMR_EINVAL;
+  if (H != 128 || I <= 0 || (I % 128)) return XFMR_EUNSUPPORTED;
+  if (!xf_aligned16(x16) || !xf_aligned16(w1_16) || !xf_aligned16(w2_16) || !xf_aligned16(pre) || !xf_aligned16(residual) ||
+      !xf_aligned16(y) || (g16 && !xf_aligned16(g16)) || (d16 && !xf_aligned16(d16)) || (y16 && !xf_aligned16(y16)) || !xf_aligned16(b1) ||
+      (b2 && !xf_aligned16(b2)) || !xf_aligned16(gamma) || !xf_aligned16(beta))
+    return XFMR_EALIGN;
+  FfnFwdArgs f{};
+  f.X = (const __bf16*)x16; f.W1 = (const __bf16*)w1_16; f.b1 = b1; f.W2 = (const __bf16*)w2_16; f.G = (__bf16*)g16; f.D = (__bf16*)d16;
+  f.I = I;
+  GemmArgs& g = f.e;
+  g.C = pre; g.ldc = H; g.M = M; g.N = H; g.K = I; g.bias = b2; g.R = residual;
+  g.drop = xf_make_dropout(dropout_p, seed, site);
+  g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps; g.Y = y; g.Y16 = y16; g.ln_mean = mean; g.ln_rstd = rstd;
+  g.nt_n = 1; g.nt_m = (int)((M + 63) / 64); g.nt_z = 1;
+  const int64_t groups = (g.nt_m + 7) / 8;
+  if (groups * 8 > 0x7fffffffll) return XFMR_EUNSUPPORTED;
+  const char* ce = getenv("XFMR_FFN_CHUNK");  // (per call) 128: the wider chunk, two workgroups per CU -- measured slower
+  const int chunk = ce ? atoi(ce) : 64;
+  if (chunk == 64) hipLaunchKernelGGL(ffn_fwd_fused_kernel<64>, dim3((unsigned)(groups * 8)), dim3(256), 0, st, f);
+  else hipLaunchKernelGGL(ffn_fwd_fused_kernel<128>, dim3((unsigned)(groups * 8)), dim3(256), 0, st, f);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
 }
 
 int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int32_t N, int32_t K,
