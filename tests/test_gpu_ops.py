@@ -370,8 +370,9 @@ def test_ffn_forward_in_one_kernel_vs_the_two_gemm_form(ops, M, I, p_drop, chunk
     """xf_ffn_fwd_fused_ex (FFN1 -> GELU -> FFN2 -> dropout + residual + LayerNorm, TF:modeling_bert.py:325-351, in one
     kernel; the encoder forward's path at T >= 16 384, H = 128) against the two launches it replaces
     (xf_linear_fwd_ex with the GELU epilogue, xf_linear_ln_fwd_ex). The only arithmetic difference: the fused kernel
-    rounds the pre-activation to bf16 before the GELU (as bf16 autocast holds it), the two-kernel form rounds after --
-    so g / gelu' agree to a bf16 ulp and everything downstream to bf16 rounding noise; against an fp64 restatement of
+    rounds the pre-activation u to bf16 before the GELU (as bf16 autocast holds it) and saves u where the two-kernel form
+    saves gelu'(u) -- so g agrees to a bf16 ulp (+ gelu's slope times an ulp of u), gelu'(u) evaluated from the saved u
+    agrees with the saved gelu', and everything downstream agrees to bf16 rounding noise; against an fp64 restatement of
     the fused kernel's own rounding points the pre-LayerNorm sum agrees to fp32 accumulation error. Partial last tile,
     dropout, the benchmark's row count, and both chunk widths (XFMR_FFN_CHUNK, read per call)."""
     import ctypes as C
@@ -391,7 +392,7 @@ def test_ffn_forward_in_one_kernel_vs_the_two_gemm_form(ops, M, I, p_drop, chunk
     beta = (0.1 * torch.randn(H, generator=g)).to(DEV)
 
     def outs():
-        return dict(g=torch.empty(M, I, device=DEV, dtype=torch.bfloat16), d=torch.empty(M, I, device=DEV, dtype=torch.bfloat16),
+        return dict(g=torch.empty(M, I, device=DEV, dtype=torch.bfloat16), d=torch.empty(M, I, device=DEV, dtype=torch.bfloat16),  # d: gelu' (two-kernel form) / u (fused)
                     pre=torch.empty(M, H, device=DEV), y=torch.empty(M, H, device=DEV),
                     y16=torch.empty(M, H, device=DEV, dtype=torch.bfloat16), mean=torch.empty(M, device=DEV),
                     rstd=torch.empty(M, device=DEV))
@@ -423,16 +424,17 @@ def test_ffn_forward_in_one_kernel_vs_the_two_gemm_form(ops, M, I, p_drop, chunk
 
     def run():
         o = outs()
-        rc = fn(N.ptr(x16), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), N.ptr(o["g"]), N.ptr(o["d"]), N.ptr(o["pre"]), M, H,
+        rc = fn(N.ptr(x16), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), N.ptr(o["d"]), N.ptr(o["g"]), N.ptr(o["pre"]), M, H,
                 I, N.ptr(res), p_drop, 5, 9, N.ptr(gamma), N.ptr(beta), 1e-12, N.ptr(o["y"]), N.ptr(o["y16"]),
                 N.ptr(o["mean"]), N.ptr(o["rstd"]), N.stream())
         assert rc == 0, rc
         return o
 
     got = run()
-    # g and gelu': one bf16 ulp of each other (rounding u first moves the result by at most the rounding of u)
-    for k in ("g", "d"):
-        a, b = got[k].float(), ref[k].float()
+    # g, and gelu' of the saved u against the saved gelu': a bf16 ulp of each other
+    u = got["d"].double()
+    gelu_grad = 0.5 * (1 + torch.erf(u / 2 ** 0.5)) + u * torch.exp(-u * u / 2) / (2 * torch.pi) ** 0.5
+    for k, a, b in (("g", got["g"].float(), ref["g"].float()), ("gelu'", gelu_grad.float(), ref["d"].float())):
         # two roundings (u, then the value) against one: a bf16 ulp of the value plus gelu's slope times a bf16 ulp of u
         assert bool(((a - b).abs() <= 2.0 ** -6 * b.abs() + 4e-3).all()), k
         assert rel_l2(a, b) <= 5e-3, k
@@ -441,6 +443,7 @@ def test_ffn_forward_in_one_kernel_vs_the_two_gemm_form(ops, M, I, p_drop, chunk
     # the fused kernel's own rounding points, restated in fp64 (without dropout: the mask is the shared hash)
     if p_drop == 0.0:
         u = (x16.double() @ w1.double().T + b1.double()).to(torch.bfloat16)
+        assert int((u != got["d"]).sum()) <= 2e-3 * u.numel()
         gg = torch.nn.functional.gelu(u.double()).to(torch.bfloat16)
         n_off = int((gg != got["g"]).sum())  # fp32-vs-fp64 accumulation flips a bf16 rounding now and then
         assert n_off <= 2e-3 * gg.numel(), n_off

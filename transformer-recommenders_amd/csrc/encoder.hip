@@ -95,7 +95,9 @@ bool mixed_storage(const xfmr_encoder_cfg* c) {
   return c->precision == XFMR_PREC_BF16 && !force_fp32;
 }
 // FFN1 -> GELU -> FFN2 -> LayerNorm as one forward kernel (gemm.hip: ffn_fwd_fused_kernel): same conditions as the
-// LayerNorm-fused GEMM epilogues plus I a multiple of its chunk widths. It saves the tensors the two-kernel form saves.
+// LayerNorm-fused GEMM epilogues plus I a multiple of its chunk widths. The forward and the backward of one step must
+// agree on it (f1 holds u after the fused kernel, gelu'(u) after the two-kernel form): a pure function of the
+// configuration and the XFMR_FFN_UNFUSED / XFMR_LN_UNFUSED switches.
 bool ffn_fused(const xfmr_encoder_cfg* c, int64_t T) {
   auto on = [](const char* name) { const char* e = getenv(name); return e && *e && *e != '0'; };
   return mixed_storage(c) && c->hidden == 128 && T >= 16384 && (c->inter % 128) == 0 && !on("XFMR_LN_UNFUSED") &&
@@ -300,8 +302,8 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
                                  l.rstd1, T, H, cfg->ln_eps, st));
     }
     const bool last = i == cfg->layers - 1;
-    if (fuse_ffn) {  // FFN1 -> GELU -> FFN2 -> dropout + residual + LayerNorm in one kernel; g, f1 <- gelu, gelu'
-      XF_TRY(xf_ffn_fwd_fused_ex(l.x1b, W(p.w1), params + p.b1, W(p.w2), params + p.b2, l.g, l.f1, l.pre2, T, H, I, l.x1,
+    if (fuse_ffn) {  // FFN1 -> GELU -> FFN2 -> dropout + residual + LayerNorm in one kernel; f1 <- the PRE-activation, g <- gelu
+      XF_TRY(xf_ffn_fwd_fused_ex(l.x1b, W(p.w1), params + p.b1, W(p.w2), params + p.b2, l.f1, l.g, l.pre2, T, H, I, l.x1,
                                  cfg->hidden_dropout, cfg->seed, site_ffn(i), params + p.ln2g, params + p.ln2b,
                                  cfg->ln_eps, out, last ? nullptr : l.x2b, l.mean2, l.rstd2, st));
       x = out;
@@ -360,6 +362,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   // layer i. The top layer's LN2 and the embedding LayerNorm keep their own launches.
   const bool no_fuse = [] { const char* e = getenv("XFMR_LN_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
   const bool fuse_lnb = mix && H == 128 && T >= 16384 && !no_fuse;
+  const bool fuse_ffn = ffn_fused(cfg, T);  // what the forward of this step did
   bool ln2_done = false;  // layer i's LN2 backward already ran inside layer i+1's QKV dX GEMM
   bool emb_ln_done = false;  // ... and the embedding LayerNorm's inside layer 0's
   for (int i = cfg->layers - 1; i >= 0; --i) {
@@ -387,7 +390,9 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     const void* dlin = lin_copy ? a.dLin : (const void*)a.dA;
     XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, st));
     seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
-    XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), a.dI, T, H, I, nullptr, l.f1, prec, sA | sC | sP | sB | XF_AUX_GELU_GRAD, st));
+    // (after the fused FFN forward f1 holds the pre-activation u, not gelu'(u): the epilogue evaluates gelu'(u))
+    XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), a.dI, T, H, I, nullptr, l.f1, prec,
+                               sA | sC | sP | sB | (fuse_ffn ? 0 : XF_AUX_GELU_GRAD), st));
     XF_TRY(xf_linear_bwd_dw_deferred(a.dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, st));  // + b1 partial rows
     seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
     seg(r.b1, grads + p.b1, splits, I, I);

@@ -67,16 +67,14 @@ struct GemmArgs {
   XfDropout drop2;  // EPI_DX_LNBWD: dropout that was applied to the LayerNorm OUTPUT (embedding site); off otherwise
 };
 
-// gelu and gelu' of eight bf16 values (one erf / exp each), both rounded back to bf16
-__device__ __forceinline__ float4 xf_gelu_both_bf16x8(float4 raw4, float4& grad8) {
+// gelu of eight bf16 values riding in a float4, rounded back to bf16
+__device__ __forceinline__ float4 xf_gelu_bf16x8(float4 raw4) {
   const uint4 raw = *reinterpret_cast<const uint4*>(&raw4);
   float4 lo = xf_bf16x4_to_f32(make_uint2(raw.x, raw.y)), hi = xf_bf16x4_to_f32(make_uint2(raw.z, raw.w));
-  float4 dl, dh;
-  lo.x = xf_gelu_both(lo.x, dl.x); lo.y = xf_gelu_both(lo.y, dl.y); lo.z = xf_gelu_both(lo.z, dl.z); lo.w = xf_gelu_both(lo.w, dl.w);
-  hi.x = xf_gelu_both(hi.x, dh.x); hi.y = xf_gelu_both(hi.y, dh.y); hi.z = xf_gelu_both(hi.z, dh.z); hi.w = xf_gelu_both(hi.w, dh.w);
-  const uint2 a = xf_f32x4_to_bf16(lo), b = xf_f32x4_to_bf16(hi), c = xf_f32x4_to_bf16(dl), d = xf_f32x4_to_bf16(dh);
-  const uint4 o = make_uint4(a.x, a.y, b.x, b.y), od = make_uint4(c.x, c.y, d.x, d.y);
-  grad8 = *reinterpret_cast<const float4*>(&od);
+  lo.x = xf_gelu(lo.x); lo.y = xf_gelu(lo.y); lo.z = xf_gelu(lo.z); lo.w = xf_gelu(lo.w);
+  hi.x = xf_gelu(hi.x); hi.y = xf_gelu(hi.y); hi.z = xf_gelu(hi.z); hi.w = xf_gelu(hi.w);
+  const uint2 a = xf_f32x4_to_bf16(lo), b = xf_f32x4_to_bf16(hi);
+  const uint4 o = make_uint4(a.x, a.y, b.x, b.y);
   return *reinterpret_cast<const float4*>(&o);
 }
 
@@ -753,25 +751,28 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
 // ---- fused FFN forward (bf16 storage, H = 128) -----------------------------------------------------------------------
 //   u = x W1^T + b1 (T x I)  ->  g = gelu(u)  ->  y = g W2^T + b2  ->  dropout, + residual, LayerNorm
 // (TF:modeling_bert.py:325-351) in ONE kernel: a workgroup owns 64 token rows and walks I in chunks of CH columns; the
-// second GEMM reads g from LDS, never from HBM. g and gelu'(u) are still WRITTEN (bf16): the backward's dW2 GEMM and
-// FFN2 dX epilogue read them, exactly as after the two-kernel form -- the saved tensors are the same, so either
-// forward pairs with the one backward. (Storing only u and applying gelu on the dW2 GEMM's way into LDS was measured:
-// the dW2 GEMM went from 27 to 53 us, more than the 105 MB of writes it saved.) u is rounded to bf16 BEFORE the GELU, as
-// the reference's bf16 autocast holds the Linear's output. Per layer at T = 102 400, I = 512: 418 MB instead of 524 MB.
+// second GEMM reads g from LDS, never from HBM. Written for the backward (bf16): g (the dW2 GEMM's operand) and the
+// PRE-activation u, from which the FFN2 dX epilogue evaluates gelu'(u) -- the two-kernel form saves gelu'(u) instead;
+// the backward is told which (encoder.hip: ffn_fused). Measured alternatives: writing gelu'(u) from here (one erf gives
+// both, but +16 us in this kernel against +4 us in the dX epilogue); storing only u and applying gelu on the dW2 GEMM's
+// way into LDS (that GEMM went from 27 to 53 us, more than the 105 MB of writes saved). u is rounded to bf16 BEFORE the
+// GELU, as the reference's bf16 autocast holds the Linear's output. Per layer at T = 102 400, I = 512: 418 MB instead
+// of 524 MB.
 //   LDS (CH = 64): sG [64][72] bf16 (u, then g in place: the A operand of the second GEMM) + sW 18 KB (the W1 chunk
 //   [64][136], then the W2 chunk [128][72]; the x tile before the first chunk, the epilogue's scratch after the last):
 //   27.6 KB. The x tile's MFMA fragments stay in registers for the whole tile (32 VGPRs); 168 VGPRs = 3 waves per SIMD.
 //   Weights stream from L2 (256 KB per layer, shared by every workgroup) through two register sets, a chunk ahead.
-//   Measured at T = 102 400 (rocprofv3): 110 us against 59 + 65 us for the two launches it replaces; the step gains
-//   0 ... 0.7 % (the pair was not bound by the re-read of g). Tried and not kept: 128-column chunks (two workgroups
-//   per CU: 118 us); barriers that leave global operations in flight (s_waitcnt lgkmcnt(0) + s_barrier: 127 us).
+//   Measured at T = 102 400 (rocprofv3): 110 us against 59 + 65 us for the two launches it replaces (the pair was not
+//   bound by the re-read of g: the kernel is as sensitive to its VALU work as to its bytes). Tried and not kept:
+//   128-column chunks (two workgroups per CU: 118 us); barriers that leave global operations in flight
+//   (s_waitcnt lgkmcnt(0) + s_barrier instead of __syncthreads: no change).
 struct FfnFwdArgs {
   const __bf16* X;    // [M][128]
   const __bf16* W1;   // [I][128]
   const float* b1;    // [I]
   const __bf16* W2;   // [128][I]
-  __bf16* G;          // [M][I] gelu(u) out: the dW2 operand (null: not stored -- inference)
-  __bf16* D;          // [M][I] gelu'(u) out: the FFN2 dX epilogue's factor (null: not stored)
+  __bf16* U;          // [M][I] pre-activation out: the FFN2 dX epilogue evaluates gelu'(u) (null: not stored -- inference)
+  __bf16* G;          // [M][I] gelu(u) out: the dW2 operand (null: not stored)
   int I;
   GemmArgs e;         // the LayerNorm epilogue's arguments: M, N = 128, ldc = 128, bias = b2, R, C, drop, ln_*, Y, Y16
 };
@@ -898,17 +899,16 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
       for (int r = 0; r < 16; ++r) sG[(wr * 32 + xf_acc_row(r, lane)) * LDC + col] = (__bf16)(accu[j][r] + b);
     }
     __syncthreads();  // sG holds u; every wave is done with the W1 chunk
-    // row-major pass over sG in 16-byte pieces: g = gelu(u) and gelu'(u) -> HBM, g back in place (the second GEMM's A operand)
+    // row-major pass over sG in 16-byte pieces: u and g = gelu(u) -> HBM, g back in place (the second GEMM's A operand)
 #pragma unroll
     for (int i = 0; i < BM * PC / 256; ++i) {
       const int p = tid + i * 256, row = p / PC, ch = p % PC;
       float4* cell = reinterpret_cast<float4*>(sG + row * LDC + ch * 8);
       const float4 u8 = *cell;
-      float4 d8;
-      const float4 g8 = xf_gelu_both_bf16x8(u8, d8);
+      const float4 g8 = xf_gelu_bf16x8(u8);
       if (m0 + row < M) {
+        if (f.U) *reinterpret_cast<float4*>(f.U + (m0 + row) * I + c * CH + ch * 8) = u8;
         if (f.G) *reinterpret_cast<float4*>(f.G + (m0 + row) * I + c * CH + ch * 8) = g8;
-        if (f.D) *reinterpret_cast<float4*>(f.D + (m0 + row) * I + c * CH + ch * 8) = d8;
       }
       *cell = g8;
     }
@@ -1159,18 +1159,18 @@ int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y,
 }
 
 int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, const void* w2_16, const float* b2,
-                        void* g16, void* d16, float* pre, int64_t M, int32_t H, int32_t I, const float* residual, float dropout_p,
+                        void* u16, void* g16, float* pre, int64_t M, int32_t H, int32_t I, const float* residual, float dropout_p,
                         uint64_t seed, uint32_t site, const float* gamma, const float* beta, float eps, float* y,
                         void* y16, float* mean, float* rstd, hipStream_t st) {
   if (!x16 || !w1_16 || !b1 || !w2_16 || !pre || !residual || !gamma || !beta || !y || !mean || !rstd || M <= 0)
     return XFMR_EINVAL;
   if (H != 128 || I <= 0 || (I % 128)) return XFMR_EUNSUPPORTED;
   if (!xf_aligned16(x16) || !xf_aligned16(w1_16) || !xf_aligned16(w2_16) || !xf_aligned16(pre) || !xf_aligned16(residual) ||
-      !xf_aligned16(y) || (g16 && !xf_aligned16(g16)) || (d16 && !xf_aligned16(d16)) || (y16 && !xf_aligned16(y16)) || !xf_aligned16(b1) ||
+      !xf_aligned16(y) || (u16 && !xf_aligned16(u16)) || (g16 && !xf_aligned16(g16)) || (y16 && !xf_aligned16(y16)) || !xf_aligned16(b1) ||
       (b2 && !xf_aligned16(b2)) || !xf_aligned16(gamma) || !xf_aligned16(beta))
     return XFMR_EALIGN;
   FfnFwdArgs f{};
-  f.X = (const __bf16*)x16; f.W1 = (const __bf16*)w1_16; f.b1 = b1; f.W2 = (const __bf16*)w2_16; f.G = (__bf16*)g16; f.D = (__bf16*)d16;
+  f.X = (const __bf16*)x16; f.W1 = (const __bf16*)w1_16; f.b1 = b1; f.W2 = (const __bf16*)w2_16; f.U = (__bf16*)u16; f.G = (__bf16*)g16;
   f.I = I;
   GemmArgs& g = f.e;
   g.C = pre; g.ldc = H; g.M = M; g.N = H; g.K = I; g.bias = b2; g.R = residual;

@@ -19,10 +19,10 @@ extern "C" {
 int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, int64_t M, int32_t N, int32_t K,
                      int32_t epilogue, const float* residual, void* aux_out, float dropout_p, uint64_t seed,
                      uint32_t site, int32_t precision, uint32_t s16, hipStream_t st);
-// FFN forward in one kernel (bf16 storage, H = 128, I a multiple of 128): u = bf16(x W1^T + b1), g16 <- gelu(u), d16 <- gelu'(u) (either may be null),
+// FFN forward in one kernel (bf16 storage, H = 128, I a multiple of 128): u16 <- bf16(x W1^T + b1), g16 <- gelu(u16) (either may be null),
 // pre <- dropout(g16 W2^T + b2) + residual, y / y16 / mean / rstd <- LayerNorm(pre). gemm.hip: ffn_fwd_fused_kernel.
 int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, const void* w2_16, const float* b2,
-                        void* g16, void* d16, float* pre, int64_t M, int32_t H, int32_t I, const float* residual, float dropout_p,
+                        void* u16, void* g16, float* pre, int64_t M, int32_t H, int32_t I, const float* residual, float dropout_p,
                         uint64_t seed, uint32_t site, const float* gamma, const float* beta, float eps, float* y,
                         void* y16, float* mean, float* rstd, hipStream_t st);
 int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int32_t N, int32_t K,
