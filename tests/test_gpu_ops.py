@@ -312,6 +312,41 @@ def test_attention_dropout_keep_rate(ops, prec):
     assert float(kept[:, -1, :].mean()) / L == pytest.approx(1 - p, abs=0.02)
 
 
+def test_hidden_dropout_keep_rate_and_structure(ops):
+    """Hidden-state dropout (the Linear + dropout + residual epilogues, the LayerNorm kernels) decides from a hash of the
+    ROW spent once per row and one xor-multiply per element (common.h: xf_drop4). x = 0, bias = 1, residual = 0 makes
+    the output of the epilogue the mask itself times 1/(1-p): the keep rate must be 1 - p overall, per row and per column
+    within sampling error, neighbouring elements / rows uncorrelated, and another site or seed another mask."""
+    from xfmr_rec_amd import _native as N
+
+    M, K, Nn, p = 8192, 64, 128, 0.1
+    x = torch.zeros(M, K, device=DEV)
+    w = torch.zeros(Nn, K, device=DEV)
+    b = torch.ones(Nn, device=DEV)
+    res = torch.zeros(M, Nn, device=DEV)
+
+    def mask(seed, site):
+        y = ops.linear_fwd(x, w, b, epilogue=N.EPI_BIAS_DROP_RES, residual=res, dropout_p=p, seed=seed, site=site,
+                           precision="bf16")
+        assert bool(((y == 0) | ((y - 1 / (1 - p)).abs() < 1e-6)).all())
+        return (y != 0).float()
+
+    m = mask(7, 3)
+    n = m.numel()
+    sigma = (p * (1 - p) / n) ** 0.5
+    assert abs(float(m.mean()) - (1 - p)) <= 5 * sigma
+    assert float((m.mean(1) - (1 - p)).abs().max()) <= 6 * (p * (1 - p) / Nn) ** 0.5   # per row (128 samples each)
+    assert float((m.mean(0) - (1 - p)).abs().max()) <= 6 * (p * (1 - p) / M) ** 0.5    # per column
+    c = m - m.mean()
+    var = float((c * c).mean())
+    for shifted in (torch.roll(c, 1, 1), torch.roll(c, 1, 0), torch.roll(c, 4, 1), torch.roll(torch.roll(c, 1, 0), 1, 1)):
+        assert abs(float((c * shifted).mean()) / var) <= 6 / n ** 0.5  # lag-1 / lag-4 / diagonal correlations
+    for other in (mask(7, 4), mask(8, 3)):
+        agree = float((other == m).float().mean())
+        assert abs(agree - ((1 - p) ** 2 + p * p)) <= 6 * 0.4 / n ** 0.5  # independent masks agree at (1-p)^2 + p^2
+    assert torch.equal(mask(7, 3), m)
+
+
 # K = 96: not a multiple of 64 -> 32-deep K slices, whose operand images are SMALLER than the epilogue's scratch strips
 # plus exchange records (the LDS allocation must be sized by the epilogue there)
 @pytest.mark.parametrize("K,M,p_drop", [(128, 300, 0.0), (512, 1000, 0.0), (128, 4096 + 17, 0.2), (96, 1000, 0.1)])

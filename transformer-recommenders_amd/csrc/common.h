@@ -305,11 +305,8 @@ static inline XfDropout xf_make_dropout(float p, uint64_t seed, uint32_t site) {
   d.scale = d.on ? 1.f / (1.f - p) : 1.f;
   return d;
 }
-__device__ __forceinline__ float xf_keep_scale(const XfDropout& d, uint32_t element) {
-  return (xf_hash32(element ^ d.key) >= d.thresh) ? d.scale : 0.f;
-}
-// Two-index form for the attention probabilities (score of query row `row`, key column `col`): the full hash is
-// spent once per ROW (xf_drop_rowkey) and a score costs one xor + one multiply + the threshold test on
+// Two-index form (attention probabilities: query row, key column; hidden states: token row, feature column): the full hash is
+// spent once per ROW (xf_drop_rowkey) and an element costs one xor + one multiply + the threshold test on
 // (rowkey ^ col * kDropColMul) * C -- the high bits of that product, which decide the comparison, depend on every
 // bit of both indices. Keep rate, row / column rates, neighbour correlations and 4-pattern chi-squares measured the
 // same as for the per-element hash; the per-element hash was ~1/5 of the attention kernels' time.
@@ -319,6 +316,18 @@ __host__ __device__ __forceinline__ uint32_t xf_drop_rowkey(const XfDropout& d, 
 }
 __host__ __device__ __forceinline__ float xf_keep_scale_rc(const XfDropout& d, uint32_t rowkey, uint32_t colmix) {
   return ((rowkey ^ colmix) * 0x7feb352dU >= d.thresh) ? d.scale : 0.f;
+}
+// Hidden-state dropout (embedding output, attention-output / FFN-output Linears): element (row, col) of a [rows][N]
+// tensor. Every kernel that applies or differentiates one dropout site goes through these two, so the masks agree.
+// (Until round 2 these sites spent the full 32-bit hash per ELEMENT: 11 vector instructions, two of them quarter-rate
+// multiplies, on 234 M elements per step in epilogues that are sensitive to their VALU work.)
+__device__ __forceinline__ float xf_keep_scale_2d(const XfDropout& d, uint32_t row, uint32_t col) {
+  return xf_keep_scale_rc(d, xf_drop_rowkey(d, row), col * kDropColMul);
+}
+__device__ __forceinline__ void xf_drop4(const XfDropout& d, uint32_t row, uint32_t col, float4& v) {  // cols col .. col + 3
+  const uint32_t rk = xf_drop_rowkey(d, row), cm = col * kDropColMul;
+  v.x *= xf_keep_scale_rc(d, rk, cm); v.y *= xf_keep_scale_rc(d, rk, cm + kDropColMul);
+  v.z *= xf_keep_scale_rc(d, rk, cm + 2 * kDropColMul); v.w *= xf_keep_scale_rc(d, rk, cm + 3 * kDropColMul);
 }
 
 // ---------------------------------------------------------------------------------------------------

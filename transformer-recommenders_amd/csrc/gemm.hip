@@ -318,9 +318,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
       float4 v = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
       v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
       if (g.drop.on) {
-        const uint32_t e = (uint32_t)(m * g.N + n);
-        v.x *= xf_keep_scale(g.drop, e); v.y *= xf_keep_scale(g.drop, e + 1);
-        v.z *= xf_keep_scale(g.drop, e + 2); v.w *= xf_keep_scale(g.drop, e + 3);
+        xf_drop4(g.drop, (uint32_t)m, (uint32_t)(n), v);
       }
       v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
       if (m >= g.M) v = make_float4(0, 0, 0, 0);
@@ -544,9 +542,7 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
           float4 dy = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
           dy.x += aux[ps].x; dy.y += aux[ps].y; dy.z += aux[ps].z; dy.w += aux[ps].w;
           if (g.drop2.on) {
-            const uint32_t e = (uint32_t)(m * g.N + n);
-            dy.x *= xf_keep_scale(g.drop2, e); dy.y *= xf_keep_scale(g.drop2, e + 1);
-            dy.z *= xf_keep_scale(g.drop2, e + 2); dy.w *= xf_keep_scale(g.drop2, e + 3);
+            xf_drop4(g.drop2, (uint32_t)m, (uint32_t)(n), dy);
           }
           if (m >= g.M) dy = make_float4(0, 0, 0, 0);
           float4 h;
@@ -585,9 +581,7 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = d;
           float4 dl = d;
           if (g.drop.on) {
-            const uint32_t e = (uint32_t)(m * g.N + n);
-            dl.x *= xf_keep_scale(g.drop, e); dl.y *= xf_keep_scale(g.drop, e + 1);
-            dl.z *= xf_keep_scale(g.drop, e + 2); dl.w *= xf_keep_scale(g.drop, e + 3);
+            xf_drop4(g.drop, (uint32_t)m, (uint32_t)(n), dl);
           }
           if (g.D16) xf_st4<true>(g.D16, m * g.ldc + n, dl);
           dbias.x += dl.x; dbias.y += dl.y; dbias.z += dl.z; dbias.w += dl.w;
@@ -725,9 +719,7 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
             }
           } else if (EPI == EPI_DROP_RES) {
             if (g.drop.on) {
-              const uint32_t e = (uint32_t)(m * g.N + n + 4 * q);
-              v[q].x *= xf_keep_scale(g.drop, e); v[q].y *= xf_keep_scale(g.drop, e + 1);
-              v[q].z *= xf_keep_scale(g.drop, e + 2); v[q].w *= xf_keep_scale(g.drop, e + 3);
+              xf_drop4(g.drop, (uint32_t)m, (uint32_t)(n + 4 * q), v[q]);
             }
             v[q].x += ax.x; v[q].y += ax.y; v[q].z += ax.z; v[q].w += ax.w;
           } else if (EPI == EPI_GELU_GRAD) {

@@ -247,14 +247,20 @@ __device__ __forceinline__ void loss_epilogue_infonce_pinned(f32x16& s, float& l
 //     once per row (st.nce, st.logi hold the log2 sums until loss_logging_masked_finish);
 //   * cosine heads in the query-norm-free form: with sc = s / |e|, c < c_pos <=> sc < pos / |e_pos| and
 //     max(c - 1 + margin, 0) = (1 / |q|) max(sc - (1 - margin) |q|, 0): one multiply per logit, 1 / |q| once per row;
-//   * min / max through NaN (fminf / fmaxf = minNum / maxNum return the other operand): one select for both.
+//   * min / max through NaN (fminf / fmaxf = minNum / maxNum return the other operand): one select for both;
+//   * ONE exponential per logit (SHARE): 2^(y - c) = 2^y 2^-c, so the pairwise-logistic term takes e = 2^y from the NCE
+//     term and a per-row constant (as does the InfoNCE sum when the temperature is 1, the reference's default); the clamps
+//     move from the exponent to the value (min(e k, 2^100), min(e k, 1)). Transcendentals issue at a quarter of the
+//     vector rate: 5 -> 3 (4 -> 3 without the log-sum-exp) took 7-15 % off the pass. Rows whose constants leave
+//     [2^-64, 2^64] (|logit of the positive| > 44) make their wave take the two-exponential form.
 // HEAD code -3: without the InfoNCE log-sum-exp (its value comes from the gradient pass), -4: with it.
 constexpr int HEAD_LOG_MASKED = -3, HEAD_LOG_MASKED_LSE = -4;
 struct LogConst {
   float pos_dot, sc2, m, chinge, clog2e /* chinge * log2e */, kpos_c /* pos / |e_pos| */, kappa_c /* (1 - margin) |q| */;
   int pos_item;
+  float kexp /* 2^-clog2e */, k2m /* 2^-m */;  // SHARE
 };
-template <bool CHECK_VALID, bool LSE>
+template <bool CHECK_VALID, bool LSE, bool SHARE>
 __device__ __forceinline__ void loss_epilogue_logging_masked(const f32x16& s, RowState& st, const LogConst& k,
                                                              const int* nid_sb, const float* rc_sb, const float* mu_sb,
                                                              int hh) {
@@ -276,12 +282,17 @@ __device__ __forceinline__ void loss_epilogue_logging_masked(const f32x16& s, Ro
       const bool cd = (sv < k.pos_dot) & other;
       const float md = cd ? mu[u] : 0.f;
       st.cnt_d += md;
-      if (LSE) st.l = fmaf(xf_exp2(fminf(fmaf(sv, k.sc2, -k.m), 0.f)), md, st.l);
       const float y = sv * kLog2e;
-      st.nce = fmaf(xf_log2(1.f + xf_exp2(fminf(y, 100.f))), md, st.nce);
+      const float e = xf_exp2(fminf(y, 100.f));
+      if (LSE) {
+        if (SHARE) st.l = fmaf(fminf(e * k.k2m, 1.f), md, st.l);  // (temperature 1: sc2 == log2 e)
+        else st.l = fmaf(xf_exp2(fminf(fmaf(sv, k.sc2, -k.m), 0.f)), md, st.l);
+      }
+      st.nce = fmaf(xf_log2(1.f + e), md, st.nce);
       const float d = sv - k.chinge;
       st.hinge = fmaf(fmaxf(d, 0.f), md, st.hinge);
-      st.logi = fmaf(xf_log2(1.f + xf_exp2(fminf(y - k.clog2e, 100.f))), md, st.logi);
+      if (SHARE) st.logi = fmaf(xf_log2(1.f + fminf(e * k.kexp, 0x1p100f)), md, st.logi);
+      else st.logi = fmaf(xf_log2(1.f + xf_exp2(fminf(y - k.clog2e, 100.f))), md, st.logi);
       const float sc = sv * rc[u];
       const float mc = ((sc < k.kpos_c) & other) ? mu[u] : 0.f;
       st.cnt_c += mc;

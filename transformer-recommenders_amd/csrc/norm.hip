@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     const int c = lane + 64 * i;
     if (c < H) {
       float o = (v[i] - mean) * rstd * a.gamma[c] + a.beta[c];
-      if (a.drop.on) o *= xf_keep_scale(a.drop, (uint32_t)(row * H + c));
+      if (a.drop.on) o *= xf_keep_scale_2d(a.drop, (uint32_t)row, (uint32_t)c);
       a.y[row * H + c] = o;
       if (a.y16) a.y16[row * H + c] = (__bf16)o;
     }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
       float dyv = 0.f, xv = 0.f;
       if (c < H) {
         dyv = a.dy[row * H + c];
-        if (a.drop_out.on) dyv *= xf_keep_scale(a.drop_out, (uint32_t)(row * H + c));
+        if (a.drop_out.on) dyv *= xf_keep_scale_2d(a.drop_out, (uint32_t)row, (uint32_t)c);
         xv = (a.x[row * H + c] - mean) * rstd;
       }
       xh[i] = xv;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         const float d = rstd * (g[i] - mg - xh[i] * mgx);
         a.dx[row * H + c] = d;
         float dl = d;
-        if (a.drop_lin.on) dl = d * xf_keep_scale(a.drop_lin, (uint32_t)(row * H + c));
+        if (a.drop_lin.on) dl = d * xf_keep_scale_2d(a.drop_lin, (uint32_t)row, (uint32_t)c);
         if (a.d_lin) {
           if (a.lin16) reinterpret_cast<__bf16*>(a.d_lin)[row * H + c] = (__bf16)dl;
           else reinterpret_cast<float*>(a.d_lin)[row * H + c] = dl;
@@ -215,9 +215,7 @@ __global__ __launch_bounds__(256) void ln_fwd_v4_kernel(LnFwdArgs a) {
   float4 o;
   o.x = dx * rstd * g.x + b.x; o.y = dy * rstd * g.y + b.y; o.z = dz * rstd * g.z + b.z; o.w = dw * rstd * g.w + b.w;
   if (a.drop.on) {
-    const uint32_t e = (uint32_t)(row * H + c);
-    o.x *= xf_keep_scale(a.drop, e); o.y *= xf_keep_scale(a.drop, e + 1);
-    o.z *= xf_keep_scale(a.drop, e + 2); o.w *= xf_keep_scale(a.drop, e + 3);
+    xf_drop4(a.drop, (uint32_t)row, (uint32_t)(c), o);
   }
   *reinterpret_cast<float4*>(a.y + row * H + c) = o;
   if (a.y16) xf_st4<true>(a.y16, row * H + c, o);
@@ -244,9 +242,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(LnBwdArgs a) {
       mean = a.mean[row];
       rstd = a.rstd[row];
       if (a.drop_out.on) {
-        const uint32_t e = (uint32_t)(row * H + c);
-        dy.x *= xf_keep_scale(a.drop_out, e); dy.y *= xf_keep_scale(a.drop_out, e + 1);
-        dy.z *= xf_keep_scale(a.drop_out, e + 2); dy.w *= xf_keep_scale(a.drop_out, e + 3);
+        xf_drop4(a.drop_out, (uint32_t)row, (uint32_t)(c), dy);
       }
     }
     float4 xh, g;
@@ -263,9 +259,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(LnBwdArgs a) {
       *reinterpret_cast<float4*>(a.dx + row * H + c) = d;
       float4 dl = d;
       if (a.drop_lin.on) {
-        const uint32_t e = (uint32_t)(row * H + c);
-        dl.x *= xf_keep_scale(a.drop_lin, e); dl.y *= xf_keep_scale(a.drop_lin, e + 1);
-        dl.z *= xf_keep_scale(a.drop_lin, e + 2); dl.w *= xf_keep_scale(a.drop_lin, e + 3);
+        xf_drop4(a.drop_lin, (uint32_t)row, (uint32_t)(c), dl);
       }
       if (a.d_lin) {
         if (a.lin16) xf_st4<true>(a.d_lin, row * H + c, dl);
