@@ -312,6 +312,44 @@ def test_attention_dropout_keep_rate(ops, prec):
     assert float(kept[:, -1, :].mean()) / L == pytest.approx(1 - p, abs=0.02)
 
 
+def test_multi_segment_row_reduction(ops):
+    """xf_multi_rowsum (one launch reduces every split-K slab, bias partial and LayerNorm partial record of the encoder
+    backward): tall strided segments (the LayerNorm records: 1600 x 128 out of a [1600][3][128] buffer), wide short ones
+    (weight slabs), a segment whose width is not a multiple of 4 (one-column form), fewer rows than row groups -- against
+    fp64 sums, and bit-for-bit equal over repeated launches."""
+    import ctypes as C
+
+    from xfmr_rec_amd import _native as N
+
+    class Seg(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int),
+                    ("pad", C.c_int)]
+
+    g = torch.Generator().manual_seed(0)
+    rec = torch.randn(1600, 3, 128, generator=g).to(DEV)           # LayerNorm partial records
+    slab = torch.randn(62, 4096, generator=g).to(DEV)               # split-K slabs
+    odd = torch.randn(37, 6, generator=g).to(DEV)                   # cols % 4 != 0
+    few = torch.randn(3, 256, generator=g).to(DEV)                  # rows < 16
+    tall = torch.randn(1000, 64, generator=g).to(DEV)               # a partial last round (1000 = 3 * 256 + 232)
+    cases = [(rec[:, 0], 1600, 128, 384), (rec[:, 1], 1600, 128, 384), (rec[:, 2], 1600, 128, 384),
+             (slab, 62, 4096, 4096), (odd, 37, 6, 6), (few, 3, 256, 256), (tall, 1000, 64, 64)]
+    outs = [torch.full((c,), float("nan"), device=DEV) for _, _, c, _ in cases]
+    segs = (Seg * len(cases))()
+    for i, ((src, rows, cols, ld), dst) in enumerate(zip(cases, outs)):
+        segs[i] = Seg(src.data_ptr(), dst.data_ptr(), rows, cols, ld, 0)
+    fn = N.load().xf_multi_rowsum
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    assert fn(C.cast(segs, C.c_void_p), len(cases), N.stream()) == 0
+    torch.cuda.synchronize()
+    first = [o.clone() for o in outs]
+    for (src, rows, cols, ld), o in zip(cases, outs):
+        torch.testing.assert_close(o.double(), src.double().sum(0), rtol=1e-5, atol=2e-4)
+    assert fn(C.cast(segs, C.c_void_p), len(cases), N.stream()) == 0
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(first, outs))
+
+
 def test_hidden_dropout_keep_rate_and_structure(ops):
     """Hidden-state dropout (the Linear + dropout + residual epilogues, the LayerNorm kernels) decides from a hash of the
     ROW spent once per row and one xor-multiply per element (common.h: xf_drop4). x = 0, bias = 1, residual = 0 makes

@@ -958,17 +958,65 @@ int launch_rowsum(float* dst, const T* src, int64_t rows, int64_t cols, int64_t 
   return XFMR_OK;
 }
 
-// Several row reductions in one launch: blockIdx.y = segment, blockIdx.x = block of 64 columns (segments with
-// fewer columns leave their extra blocks idle). Same per-column arithmetic as rowsum_kernel.
-struct MultiSegs { XfReduceSeg s[64]; };
+// Several row reductions in one launch: a one-dimensional grid of exactly the 64-column blocks the segments have
+// (first[i] = index of segment i's first block; a (max blocks, segments) grid launched 57 k workgroups for 12 k that had
+// work). A block is 16 row groups x 16 lanes of 4 columns: 16-byte loads, 16 of
+// them in flight per thread = 256 rows per round trip. The LayerNorm partial records of the fused dX GEMMs are 1600
+// rows of 128 columns (T / 64 workgroups): with 4 row groups of 64 one-column lanes such a segment was a 25-iteration
+// latency chain on two workgroups and set the kernel's time (88 us for 247 MB; 4-byte loads: 967 k wave instructions).
+// Fixed summation order: bit-reproducible. Segments whose base / ld / cols are not multiples of 4 floats take the
+// one-column form.
+struct MultiSegs { XfReduceSeg s[64]; int first[65]; int n; };
 __global__ __launch_bounds__(256) void multi_rowsum_kernel(MultiSegs m) {
-  __shared__ float red[4][64];
-  const XfReduceSeg sg = m.s[blockIdx.y];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
+  int si = 0;
+#pragma unroll
+  for (int step = 32; step > 0; step >>= 1)  // the last segment whose first block is <= blockIdx.x
+    if (si + step < m.n && m.first[si + step] <= (int)blockIdx.x) si += step;
+  const XfReduceSeg sg = m.s[si];
+  const int bx = (int)blockIdx.x - m.first[si];
+  const bool vec = !((sg.cols | sg.ld) & 3) && !(reinterpret_cast<uintptr_t>(sg.src) & 15);
+  if (vec) {
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = bx * 64 + 4 * cq;
+    float4 s[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s[u] = make_float4(0, 0, 0, 0);
+    if (col < sg.cols) {
+      const float* src = sg.src + col;
+      const int64_t ld = sg.ld;
+      int r = rg;
+      for (; r + 240 < sg.rows; r += 256) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float4 v = *reinterpret_cast<const float4*>(src + (r + 16 * u) * ld);
+          s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {  // the last, partial round: still all loads issued together
+        if (r + 16 * u < sg.rows) {
+          const float4 v = *reinterpret_cast<const float4*>(src + (r + 16 * u) * ld);
+          s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
+        }
+      }
+    }
+    auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    const float4 t = add4(add4(add4(add4(s[0], s[1]), add4(s[2], s[3])), add4(add4(s[4], s[5]), add4(s[6], s[7]))),
+                          add4(add4(add4(s[8], s[9]), add4(s[10], s[11])), add4(add4(s[12], s[13]), add4(s[14], s[15]))));
+    *reinterpret_cast<float4*>(&red[rg][4 * cq]) = t;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int c = threadIdx.x, oc = bx * 64 + c;
+      float acc = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc += red[g][c];
+      if (oc < sg.cols) sg.dst[oc] = acc;
+    }
+    return;
+  }
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + c;
-  if (blockIdx.x * 64 >= sg.cols) return;
-  // 16 loads in flight per thread: the LayerNorm partial records of the fused dX GEMMs are 1600 rows of 128 columns
-  // (T / 64 workgroups) -- with 4 in flight such a segment was a 100-iteration latency chain and set the kernel's time
+  const int col = bx * 64 + c;
   float s[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) s[u] = 0.f;
@@ -1279,13 +1327,16 @@ int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st) {
   for (int base = 0; base < nseg; base += 64) {
     MultiSegs m{};
     const int n = nseg - base < 64 ? nseg - base : 64;
-    int maxcols = 0;
+    int blocks = 0;
     for (int i = 0; i < n; ++i) {
       m.s[i] = segs[base + i];
-      if (m.s[i].cols > maxcols) maxcols = m.s[i].cols;
+      m.first[i] = blocks;
+      blocks += m.s[i].cols > 0 ? (m.s[i].cols + 63) / 64 : 0;
     }
-    if (maxcols <= 0) continue;
-    hipLaunchKernelGGL(multi_rowsum_kernel, dim3((unsigned)((maxcols + 63) / 64), (unsigned)n), dim3(256), 0, st, m);
+    m.first[n] = blocks;
+    m.n = n;
+    if (blocks <= 0) continue;
+    hipLaunchKernelGGL(multi_rowsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, m);
     XF_LAUNCH_CHECK();
   }
   return XFMR_OK;
