@@ -224,3 +224,41 @@ def test_config2_encoder_with_layernorm_in_the_gemm_epilogues_equals_the_separat
     for _ in range(reps):
         tok_f2, grad_f2 = run()
         assert torch.equal(tok_f, tok_f2) and torch.equal(grad_f, grad_f2)
+
+
+@pytest.mark.parametrize("B,I,p_drop", [(512, 512, 0.1), (97, 512, 0.0), (83, 128, 0.1)])
+def test_ffn_backward_dx_chain_in_one_kernel_is_bit_identical_to_the_two_gemm_form(ops, B, I, p_drop):
+    """At T >= 16 384 (H = 128, I a multiple of 128) the encoder backward runs FFN2 dX x gelu'(u) -> dI -> FFN1 dX ->
+    LayerNorm 1 backward as ONE kernel (gemm.hip: ffn_bwd_dx_fused_kernel); XFMR_FFN_BWD_UNFUSED=1 (read per call) keeps
+    the two GEMM launches it replaces. Same MFMA order, same epilogue code: every parameter gradient must be equal bit
+    for bit (partial last tile at B = 97 / 83: T = 19 400 / 16 600 is not a multiple of 64)."""
+    import os
+
+    from xfmr_rec_amd import _native as N
+
+    L, H, A, V, nL = 200, 128, 4, 3883, 2
+    g = torch.Generator().manual_seed(5)
+    table = _unit_table(V, H, 1234).to(DEV)
+    cfg = ops.make_encoder_cfg(batch=B, seq_len=L, hidden=H, heads=A, inter=I, layers=nL, max_pos=L, precision="bf16",
+                               hidden_dropout=p_drop, attn_dropout=p_drop, seed=17)
+    n_params = N.load().xfmr_param_count(__import__("ctypes").byref(cfg))
+    flat = (0.05 * torch.randn(n_params, generator=g)).to(DEV)
+    idx = torch.randint(1, V + 1, (B, L), generator=g)
+    idx[:, -31:] = 0
+    idx = idx.to(DEV)
+    d_out = torch.randn(B, L, H, generator=g).to(DEV)
+
+    def run():
+        tok, key_mask, acts = ops.encoder_fwd(cfg, flat, idx, table)
+        return ops.encoder_bwd(cfg, flat, d_out.clone(), key_mask, acts)
+
+    os.environ.pop("XFMR_FFN_BWD_UNFUSED", None)
+    fused = run()
+    os.environ["XFMR_FFN_BWD_UNFUSED"] = "1"
+    try:
+        two = run()
+    finally:
+        os.environ.pop("XFMR_FFN_BWD_UNFUSED", None)
+    assert torch.isfinite(fused).all() and float(fused.abs().max()) > 0
+    assert torch.equal(fused, two)
+

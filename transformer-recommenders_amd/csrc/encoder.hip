@@ -100,7 +100,7 @@ bool mixed_storage(const xfmr_encoder_cfg* c) {
 // configuration and the XFMR_FFN_UNFUSED / XFMR_LN_UNFUSED switches.
 bool ffn_fused(const xfmr_encoder_cfg* c, int64_t T) {
   auto on = [](const char* name) { const char* e = getenv(name); return e && *e && *e != '0'; };
-  return mixed_storage(c) && c->hidden == 128 && T >= 16384 && (c->inter % 128) == 0 && !on("XFMR_LN_UNFUSED") &&
+  return mixed_storage(c) && c->hidden == 128 && T >= 16384 && (c->inter % 128) == 0 && c->inter <= 1024 && !on("XFMR_LN_UNFUSED") &&
          !on("XFMR_FFN_UNFUSED");
 }
 
@@ -363,6 +363,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   const bool no_fuse = [] { const char* e = getenv("XFMR_LN_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
   const bool fuse_lnb = mix && H == 128 && T >= 16384 && !no_fuse;
   const bool fuse_ffn = ffn_fused(cfg, T);  // what the forward of this step did
+  const bool no_ffn_bwd = [] { const char* e = getenv("XFMR_FFN_BWD_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
   bool ln2_done = false;  // layer i's LN2 backward already ran inside layer i+1's QKV dX GEMM
   bool emb_ln_done = false;  // ... and the embedding LayerNorm's inside layer 0's
   for (int i = cfg->layers - 1; i >= 0; --i) {
@@ -390,13 +391,21 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     const void* dlin = lin_copy ? a.dLin : (const void*)a.dA;
     XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, st));
     seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
-    // (after the fused FFN forward f1 holds the pre-activation u, not gelu'(u): the epilogue evaluates gelu'(u))
-    XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), a.dI, T, H, I, nullptr, l.f1, prec,
-                               sA | sC | sP | sB | (fuse_ffn ? 0 : XF_AUX_GELU_GRAD), st));
+    const bool fuse_ffn_bwd = fuse_ffn && fuse_lnb && !no_ffn_bwd;
+    if (fuse_ffn_bwd) {  // FFN2 dX * gelu'(u) -> dI -> FFN1 dX (+= d(pre2)) -> LayerNorm 1 backward in one kernel
+      XF_TRY(xf_ffn_bwd_dx_fused_ex(dlin, W(p.w2), l.f1, W(p.w1), a.dI, T, H, I, a.dA, l.pre1, l.mean1, l.rstd1,
+                                    params + p.ln1g, cfg->hidden_dropout, cfg->seed, site_out(i), dX, a.dLin, r.ln1,
+                                    &blocks, st));
+    } else {
+      // (after the fused FFN forward f1 holds the pre-activation u, not gelu'(u): the epilogue evaluates gelu'(u))
+      XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), a.dI, T, H, I, nullptr, l.f1, prec,
+                                 sA | sC | sP | sB | (fuse_ffn ? 0 : XF_AUX_GELU_GRAD), st));
+    }
     XF_TRY(xf_linear_bwd_dw_deferred(a.dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, st));  // + b1 partial rows
     seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
     seg(r.b1, grads + p.b1, splits, I, I);
-    if (fuse_lnb) {  // dX of FFN1 (+= d(pre2)) and LayerNorm 1 backward in one kernel -> dX = d(pre1), dLin
+    if (fuse_ffn_bwd) {  // (done above)
+    } else if (fuse_lnb) {  // dX of FFN1 (+= d(pre2)) and LayerNorm 1 backward in one kernel -> dX = d(pre1), dLin
       XF_TRY(xf_linear_bwd_dx_lnbwd_ex(a.dI, W(p.w1), T, I, H, a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g,
                                        cfg->hidden_dropout, cfg->seed, site_out(i), dX, a.dLin, r.ln1, &blocks, prec,
                                        sA | sB, st));

@@ -26,6 +26,33 @@
 #ifndef XF_GEMM_PF
 #define XF_GEMM_PF 1  // operand K slices in flight per workgroup (gemm_kernel)
 #endif
+// Barrier of the fused FFN kernels' chunk loops. 1: s_waitcnt lgkmcnt(0) + s_barrier through inline asm -- the LDS hand-off
+// only; __syncthreads() (and __builtin_amdgcn_s_barrier: the backend puts s_waitcnt 0 in front of every S_BARRIER on
+// this target) also drains vmcnt, i.e. every weight / activation prefetch issued since the last barrier.
+// Probe build (-DXF_FFN_STAMP): wave 0 of every workgroup of ffn_fwd_fused_kernel writes s_memtime stamps of its phases to
+// the buffer behind XFMR_FFN_STAMPS (scripts/probe/ffn_fwd_stamps.py); not part of the product build.
+#ifdef XF_FFN_STAMP
+#define XF_STAMP(i) do { if (stamp_on) st_buf[(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define XF_STAMP(i) do {} while (0)
+#endif
+#ifndef XF_FFN_ASM_BARRIER
+#define XF_FFN_ASM_BARRIER 1
+#endif
+#if XF_FFN_ASM_BARRIER
+#define XF_LOOP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define XF_LOOP_BARRIER() __syncthreads()
+#endif
+// The same for the LDS exchanges inside the two LayerNorm epilogues (their barriers sit right behind global stores)
+#ifndef XF_EPI_ASM_BARRIER
+#define XF_EPI_ASM_BARRIER 1
+#endif
+#if XF_EPI_ASM_BARRIER
+#define XF_EPI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define XF_EPI_BARRIER() __syncthreads()
+#endif
 #ifndef XF_FFN_MIN_WAVES
 #define XF_FFN_MIN_WAVES 2
 #endif
@@ -328,7 +355,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();  // every wave is done with its scratch strip before `red` (behind the strips) is written
+  XF_EPI_BARRIER();  // every wave is done with its scratch strip before `red` (behind the strips) is written
   auto row_reduce = [&](float x) {  // over the 16 lanes that hold a row's 64 columns of this wave
     x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
     return x;
@@ -342,7 +369,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
       const float s = row_reduce((v.x + v.y) + (v.z + v.w));
       if (li == 0) red[(wr * 2 + wc) * 32 + 16 * hf + prow + RPPL * ps] = s;
     }
-  __syncthreads();
+  XF_EPI_BARRIER();
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -350,7 +377,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
       const int rr = 16 * hf + prow + RPPL * ps;
       mean[hf][ps] = (red[(wr * 2) * 32 + rr] + red[(wr * 2 + 1) * 32 + rr]) * (1.f / 128.f);
     }
-  __syncthreads();
+  XF_EPI_BARRIER();
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -361,7 +388,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
       const float s = row_reduce((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
       if (li == 0) red[(wr * 2 + wc) * 32 + 16 * hf + prow + RPPL * ps] = s;
     }
-  __syncthreads();
+  XF_EPI_BARRIER();
   const float4 gm = *reinterpret_cast<const float4*>(g.ln_gamma + n);
   const float4 bt = *reinterpret_cast<const float4*>(g.ln_beta + n);
 #pragma unroll
@@ -384,6 +411,124 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
         g.ln_rstd[m] = rs;
       }
     }
+}
+
+// Epilogue of a 64 x 128 dX tile whose rows are gradients of a LayerNorm OUTPUT (2 x 2 waves, acc[j] = the wave's 32 x 32
+// block j): + residual gradient (dropout of the LayerNorm output where drop2 is on) -> LayerNorm backward -> C (gradient of
+// the LayerNorm input, fp32), D16 (its dropout-scaled bf16 copy: the gradient of the Linear that fed the LayerNorm), one
+// partial record [3][128] (d gamma, d beta, d bias) per tile. `smem`: >= 4 strips of 16 x 68 floats + 896 floats.
+__device__ __forceinline__ void epi_dx_lnbwd_64x128(const f32x16 (&acc)[2], unsigned char* smem, const GemmArgs& g,
+                                                    const int64_t m0, const int tile_m, const int wid, const int lane) {
+  // Same lane map as EPI_DROP_RES_LN: lane -> (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3). A half strip
+  // (16 rows) at a time: the two row sums of the LayerNorm backward are exchanged with the partner wave per half.
+  constexpr int LPRL = 16, RPPL = 4, NPL = 4, WM = 32, WN = 64, NI = 2, SCR_LD = WN + 4;
+  const int wr = wid >> 1, wc = wid & 1;
+  float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
+  float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 hf][2 wr][2 wc][16 rows][2]
+  float* const colred = red + 2 * 2 * 2 * 16 * 2;                       // [2 wr][3][128]
+  const int prow = lane / LPRL, li = lane % LPRL, c0 = li * 4;
+  const int n = wc * WN + c0;
+  const float4 gam = *reinterpret_cast<const float4*>(g.ln_gamma + n);
+  float4 dgam = make_float4(0, 0, 0, 0), dbet = dgam, dbias = dgam;
+  auto row_reduce = [&](float x) {
+    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+    return x;
+  };
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int64_t mb = m0 + wr * WM + 16 * hf;
+    float4 aux[NPL], xv[NPL];
+    float mu[NPL], rs[NPL];
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      aux[ps] = xv[ps] = make_float4(0, 0, 0, 0);
+      mu[ps] = rs[ps] = 0.f;
+      const int64_t m = mb + prow + RPPL * ps;
+      if (m < g.M) {
+        if (g.R) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * g.ldc + n);
+        xv[ps] = *reinterpret_cast<const float4*>(g.lnb_x + m * g.ldc + n);
+        mu[ps] = g.lnb_mean[m];
+        rs[ps] = g.lnb_rstd[m];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[j][8 * hf + r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float4 gv[NPL], xh[NPL];
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      const int row = prow + RPPL * ps;
+      const int64_t m = mb + row;
+      float4 dy = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
+      dy.x += aux[ps].x; dy.y += aux[ps].y; dy.z += aux[ps].z; dy.w += aux[ps].w;
+      if (g.drop2.on) {
+        xf_drop4(g.drop2, (uint32_t)m, (uint32_t)(n), dy);
+      }
+      if (m >= g.M) dy = make_float4(0, 0, 0, 0);
+      float4 h;
+#if !(XF_LN_DIAG & 32)
+      // each per-row scalar is pinned in a 32-bit VGPR of its own: see XF_PIN_SCALAR
+      XF_PIN_SCALAR(mu[ps]);
+      XF_PIN_SCALAR(rs[ps]);
+#endif
+      h.x = (xv[ps].x - mu[ps]) * rs[ps]; h.y = (xv[ps].y - mu[ps]) * rs[ps];
+      h.z = (xv[ps].z - mu[ps]) * rs[ps]; h.w = (xv[ps].w - mu[ps]) * rs[ps];
+      dgam.x += dy.x * h.x; dgam.y += dy.y * h.y; dgam.z += dy.z * h.z; dgam.w += dy.w * h.w;
+      dbet.x += dy.x; dbet.y += dy.y; dbet.z += dy.z; dbet.w += dy.w;
+      float4 gg;
+      gg.x = dy.x * gam.x; gg.y = dy.y * gam.y; gg.z = dy.z * gam.z; gg.w = dy.w * gam.w;
+      gv[ps] = gg; xh[ps] = h;
+      const float s1 = row_reduce((gg.x + gg.y) + (gg.z + gg.w));
+      const float s2 = row_reduce((gg.x * h.x + gg.y * h.y) + (gg.z * h.z + gg.w * h.w));
+      if (li == 0) {
+        float* rp = red + ((((hf * 2 + wr) * 2 + wc) * 16) + row) * 2;
+        rp[0] = s1; rp[1] = s2;
+      }
+    }
+    XF_EPI_BARRIER();  // (also: the scratch strip may be overwritten by the next half)
+#pragma unroll
+    for (int ps = 0; ps < NPL; ++ps) {
+      const int row = prow + RPPL * ps;
+      const int64_t m = mb + row;
+      const float* r0 = red + ((((hf * 2 + wr) * 2 + 0) * 16) + row) * 2;
+      const float* r1 = red + ((((hf * 2 + wr) * 2 + 1) * 16) + row) * 2;
+      const float mg = (r0[0] + r1[0]) * (1.f / 128.f), mgx = (r0[1] + r1[1]) * (1.f / 128.f);
+      if (m >= g.M) continue;
+      const float4 gg = gv[ps], h = xh[ps];
+      float4 d;
+      d.x = rs[ps] * (gg.x - mg - h.x * mgx); d.y = rs[ps] * (gg.y - mg - h.y * mgx);
+      d.z = rs[ps] * (gg.z - mg - h.z * mgx); d.w = rs[ps] * (gg.w - mg - h.w * mgx);
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = d;
+      float4 dl = d;
+      if (g.drop.on) {
+        xf_drop4(g.drop, (uint32_t)m, (uint32_t)(n), dl);
+      }
+      if (g.D16) xf_st4<true>(g.D16, m * g.ldc + n, dl);
+      dbias.x += dl.x; dbias.y += dl.y; dbias.z += dl.z; dbias.w += dl.w;
+    }
+  }
+  // column sums of the workgroup's 64 rows: the 4 row groups of the wave (lanes with equal li), then the two
+  // waves that share the columns (wr = 0, 1), fixed order
+  auto fold = [&](float4& v) {
+#pragma unroll
+    for (int o = LPRL; o < 64; o <<= 1) {
+      v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+      v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+    }
+  };
+  fold(dgam); fold(dbet); fold(dbias);
+  if (prow == 0) {
+    *reinterpret_cast<float4*>(&colred[(wr * 3 + 0) * 128 + n]) = dgam;
+    *reinterpret_cast<float4*>(&colred[(wr * 3 + 1) * 128 + n]) = dbet;
+    *reinterpret_cast<float4*>(&colred[(wr * 3 + 2) * 128 + n]) = dbias;
+  }
+  XF_EPI_BARRIER();
+  for (int o = threadIdx.x; o < 3 * 128; o += 256)
+    g.lnb_partials[(int64_t)tile_m * 3 * 128 + o] = colred[o] + colred[3 * 128 + o];
 }
 
 // S = XF_S16_* storage mask (compile time: a runtime switch between the fp32 and bf16 load paths cost the
@@ -495,117 +640,7 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
     return;
   }
   if constexpr (EPI == EPI_DX_LNBWD) {
-    if constexpr (BM == 64 && BN == 128) {
-      // Same lane map as EPI_DROP_RES_LN: lane -> (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3). A half strip
-      // (16 rows) at a time: the two row sums of the LayerNorm backward are exchanged with the partner wave per half.
-      constexpr int LPRL = 16, RPPL = 4, NPL = 4;
-      float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
-      float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 hf][2 wr][2 wc][16 rows][2]
-      float* const colred = red + 2 * 2 * 2 * 16 * 2;                       // [2 wr][3][128]
-      const int prow = lane / LPRL, li = lane % LPRL, c0 = li * 4;
-      const int n = wc * WN + c0;
-      const float4 gam = *reinterpret_cast<const float4*>(g.ln_gamma + n);
-      float4 dgam = make_float4(0, 0, 0, 0), dbet = dgam, dbias = dgam;
-      auto row_reduce = [&](float x) {
-        x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
-        return x;
-      };
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int64_t mb = m0 + wr * WM + 16 * hf;
-        float4 aux[NPL], xv[NPL];
-        float mu[NPL], rs[NPL];
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          aux[ps] = xv[ps] = make_float4(0, 0, 0, 0);
-          mu[ps] = rs[ps] = 0.f;
-          const int64_t m = mb + prow + RPPL * ps;
-          if (m < g.M) {
-            if (g.R) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * g.ldc + n);
-            xv[ps] = *reinterpret_cast<const float4*>(g.lnb_x + m * g.ldc + n);
-            mu[ps] = g.lnb_mean[m];
-            rs[ps] = g.lnb_rstd[m];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[0][j][8 * hf + r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        float4 gv[NPL], xh[NPL];
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          const int row = prow + RPPL * ps;
-          const int64_t m = mb + row;
-          float4 dy = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c0);
-          dy.x += aux[ps].x; dy.y += aux[ps].y; dy.z += aux[ps].z; dy.w += aux[ps].w;
-          if (g.drop2.on) {
-            xf_drop4(g.drop2, (uint32_t)m, (uint32_t)(n), dy);
-          }
-          if (m >= g.M) dy = make_float4(0, 0, 0, 0);
-          float4 h;
-#if !(XF_LN_DIAG & 32)
-          // each per-row scalar is pinned in a 32-bit VGPR of its own: see XF_PIN_SCALAR
-          XF_PIN_SCALAR(mu[ps]);
-          XF_PIN_SCALAR(rs[ps]);
-#endif
-          h.x = (xv[ps].x - mu[ps]) * rs[ps]; h.y = (xv[ps].y - mu[ps]) * rs[ps];
-          h.z = (xv[ps].z - mu[ps]) * rs[ps]; h.w = (xv[ps].w - mu[ps]) * rs[ps];
-          dgam.x += dy.x * h.x; dgam.y += dy.y * h.y; dgam.z += dy.z * h.z; dgam.w += dy.w * h.w;
-          dbet.x += dy.x; dbet.y += dy.y; dbet.z += dy.z; dbet.w += dy.w;
-          float4 gg;
-          gg.x = dy.x * gam.x; gg.y = dy.y * gam.y; gg.z = dy.z * gam.z; gg.w = dy.w * gam.w;
-          gv[ps] = gg; xh[ps] = h;
-          const float s1 = row_reduce((gg.x + gg.y) + (gg.z + gg.w));
-          const float s2 = row_reduce((gg.x * h.x + gg.y * h.y) + (gg.z * h.z + gg.w * h.w));
-          if (li == 0) {
-            float* rp = red + ((((hf * 2 + wr) * 2 + wc) * 16) + row) * 2;
-            rp[0] = s1; rp[1] = s2;
-          }
-        }
-        __syncthreads();  // (also: the scratch strip may be overwritten by the next half)
-#pragma unroll
-        for (int ps = 0; ps < NPL; ++ps) {
-          const int row = prow + RPPL * ps;
-          const int64_t m = mb + row;
-          const float* r0 = red + ((((hf * 2 + wr) * 2 + 0) * 16) + row) * 2;
-          const float* r1 = red + ((((hf * 2 + wr) * 2 + 1) * 16) + row) * 2;
-          const float mg = (r0[0] + r1[0]) * (1.f / 128.f), mgx = (r0[1] + r1[1]) * (1.f / 128.f);
-          if (m >= g.M) continue;
-          const float4 gg = gv[ps], h = xh[ps];
-          float4 d;
-          d.x = rs[ps] * (gg.x - mg - h.x * mgx); d.y = rs[ps] * (gg.y - mg - h.y * mgx);
-          d.z = rs[ps] * (gg.z - mg - h.z * mgx); d.w = rs[ps] * (gg.w - mg - h.w * mgx);
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = d;
-          float4 dl = d;
-          if (g.drop.on) {
-            xf_drop4(g.drop, (uint32_t)m, (uint32_t)(n), dl);
-          }
-          if (g.D16) xf_st4<true>(g.D16, m * g.ldc + n, dl);
-          dbias.x += dl.x; dbias.y += dl.y; dbias.z += dl.z; dbias.w += dl.w;
-        }
-      }
-      // column sums of the workgroup's 64 rows: the 4 row groups of the wave (lanes with equal li), then the two
-      // waves that share the columns (wr = 0, 1), fixed order
-      auto fold = [&](float4& v) {
-#pragma unroll
-        for (int o = LPRL; o < 64; o <<= 1) {
-          v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
-          v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
-        }
-      };
-      fold(dgam); fold(dbet); fold(dbias);
-      if (prow == 0) {
-        *reinterpret_cast<float4*>(&colred[(wr * 3 + 0) * 128 + n]) = dgam;
-        *reinterpret_cast<float4*>(&colred[(wr * 3 + 1) * 128 + n]) = dbet;
-        *reinterpret_cast<float4*>(&colred[(wr * 3 + 2) * 128 + n]) = dbias;
-      }
-      __syncthreads();
-      for (int o = threadIdx.x; o < 3 * 128; o += 256)
-        g.lnb_partials[(int64_t)tix.m * 3 * 128 + o] = colred[o] + colred[3 * 128 + o];
-    }
+    if constexpr (BM == 64 && BN == 128) epi_dx_lnbwd_64x128(acc[0], smem, g, m0, tix.m, wid, lane);
     return;
   }
   if (do_bias) {  // combine the threads that share an operand row group (4 rows fp32, 8 rows bf16), fixed order
@@ -767,6 +802,7 @@ struct FfnFwdArgs {
   __bf16* G;          // [M][I] gelu(u) out: the dW2 operand (null: not stored)
   int I;
   GemmArgs e;         // the LayerNorm epilogue's arguments: M, N = 128, ldc = 128, bias = b2, R, C, drop, ln_*, Y, Y16
+  unsigned long long* stamps;  // probe build only
 };
 
 // One weight chunk of the fused FFN forward in flight in registers: W1 rows [c CH, +CH) x 128 (image [CH][136]) or
@@ -820,6 +856,7 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
   constexpr int W_ELEMS = CH * LDH > H * LDC ? CH * LDH : H * LDC;
   __shared__ __attribute__((aligned(16))) __bf16 sG[BM * LDC];
   __shared__ __attribute__((aligned(16))) __bf16 sW[W_ELEMS];
+  __shared__ float sB1[1024];  // b1: a global load inside the chunk loop would be a vmcnt(0) drain per chunk
   static_assert(W_ELEMS >= BM * LDH, "the x tile is staged through sW");
   static_assert(W_ELEMS * 2 >= 4 * 16 * 68 * 4 + 128 * 4, "the LayerNorm epilogue's scratch aliases sW");
   using FR = Frag<PrecBF16, false>;
@@ -830,6 +867,11 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
   const int64_t m0 = (int64_t)tix.m * BM;
   const int64_t M = f.e.M;
   const int I = f.I, nchunk = I / CH;
+#ifdef XF_FFN_STAMP
+  const bool stamp_on = f.stamps && threadIdx.x == 0;
+  unsigned long long* st_buf = f.stamps + (int64_t)blockIdx.x * 64;
+#endif
+  XF_STAMP(0);
 
   // two weight chunks in flight, each for a whole chunk period: W1(c + 1) from the first GEMM of chunk c on, W2(c + 1)
   // from its second GEMM on (with ONE set, issued a GEMM ahead, the L2 round trip was exposed twice per chunk)
@@ -847,6 +889,7 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
     }
     wa.load_w1(f.W1, 0, tid);
     wb.load_w2(f.W2, I, 0, tid);
+    for (int i = tid; i < I; i += 256) sB1[i] = f.b1[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int p = tid + i * 256, row = p >> 4, ch = p & 15;
@@ -857,6 +900,7 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
   bf16x8 xa[H / 16];
 #pragma unroll
   for (int ks = 0; ks < H / 16; ++ks) xa[ks] = FR::get(sW, LDH, wr * 32, ks * 16);
+  XF_STAMP(1);
 
   f32x16 accy[2];
 #pragma unroll
@@ -865,32 +909,42 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
     for (int r = 0; r < 16; ++r) accy[j][r] = 0.f;
 
   for (int c = 0; c < nchunk; ++c) {
-    __syncthreads();  // the previous chunk's second GEMM (or the fragment reads above) is done with sW and sG
+    XF_LOOP_BARRIER();  // the previous chunk's second GEMM (or the fragment reads above) is done with sW and sG
+    if (c < 2) XF_STAMP(2 + 6 * c);
     wa.commit_w1(sW, tid);  // W1 chunk c
-    __syncthreads();
+    XF_LOOP_BARRIER();
+    if (c < 2) XF_STAMP(3 + 6 * c);
     if (c + 1 < nchunk) wa.load_w1(f.W1, c + 1, tid);
     f32x16 accu[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accu[j][r] = 0.f;
+    {  // the B fragments of the next k-step are read while this one's MFMAs run
+      bf16x8 fb[2][NJ];
 #pragma unroll
-    for (int ks = 0; ks < H / 16; ++ks) {
-      bf16x8 fb[NJ];
+      for (int j = 0; j < NJ; ++j) fb[0][j] = FR::get(sW, LDH, wc * (CH / 2) + j * 32, 0);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = FR::get(sW, LDH, wc * (CH / 2) + j * 32, ks * 16);
+      for (int ks = 0; ks < H / 16; ++ks) {
+        if (ks + 1 < H / 16) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) accu[j] = xf_mma(xa[ks], fb[j], accu[j]);
+          for (int j = 0; j < NJ; ++j) fb[(ks + 1) & 1][j] = FR::get(sW, LDH, wc * (CH / 2) + j * 32, (ks + 1) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) accu[j] = xf_mma(xa[ks], fb[ks & 1][j], accu[j]);
+      }
     }
     // u = acc + b1 -> bf16 -> sG (accumulator layout: element r of lane l = row (r&3) + 8 (r>>2) + 4 (l>>5), col l&31)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = wc * (CH / 2) + j * 32 + (lane & 31);
-      const float b = f.b1[c * CH + col];
+      const float b = sB1[c * CH + col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) sG[(wr * 32 + xf_acc_row(r, lane)) * LDC + col] = (__bf16)(accu[j][r] + b);
     }
-    __syncthreads();  // sG holds u; every wave is done with the W1 chunk
+    if (c < 2) XF_STAMP(4 + 6 * c);
+    XF_LOOP_BARRIER();  // sG holds u; every wave is done with the W1 chunk
+    if (c < 2) XF_STAMP(5 + 6 * c);
     // row-major pass over sG in 16-byte pieces: u and g = gelu(u) -> HBM, g back in place (the second GEMM's A operand)
 #pragma unroll
     for (int i = 0; i < BM * PC / 256; ++i) {
@@ -905,7 +959,9 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
       *cell = g8;
     }
     wb.commit_w2(sW, tid);  // W2 chunk c
-    __syncthreads();
+    if (c < 2) XF_STAMP(6 + 6 * c);
+    XF_LOOP_BARRIER();
+    if (c < 2) XF_STAMP(7 + 6 * c);
     if (c + 1 < nchunk) wb.load_w2(f.W2, I, c + 1, tid);
 #pragma unroll
     for (int ks = 0; ks < CH / 16; ++ks) {
@@ -917,8 +973,170 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
       for (int j = 0; j < 2; ++j) accy[j] = xf_mma(fa, fb[j], accy[j]);
     }
   }
+  XF_STAMP(14);
   __syncthreads();  // everyone is done with sW: the epilogue's scratch aliases it
+  XF_STAMP(15);
   epi_drop_res_ln_64x128(accy, reinterpret_cast<unsigned char*>(sW), f.e, m0, wid, lane);
+  XF_STAMP(16);
+}
+
+// ---- fused FFN backward, dX chain (bf16 storage, H = 128) ----------------------------------------------------------------
+//   dI = (dy W2) * gelu'(u)  ->  dx = dI W1 (+ residual gradient)  ->  LayerNorm 1 backward
+// in ONE kernel, the mirror of ffn_fwd_fused_kernel: a workgroup owns 64 token rows and walks I in 64-column chunks; the
+// second GEMM reads the dI chunk from LDS. dI is still WRITTEN once (bf16): it is the dW1 GEMM's operand. Same MFMA
+// order as the two launches it replaces (the FFN2 dX GEMM with the gelu' epilogue, the FFN1 dX GEMM with the LayerNorm
+// backward epilogue): bit-identical dI, dx, d_lin and partial records. Per layer at T = 102 400, I = 512: 418 MB instead of
+// 523 MB.
+//   LDS: sF [64][68] fp32 (dy W2 chunk: accumulator layout -> row-major) + sG [64][72] (the dI chunk: A operand of the
+//   second GEMM; the u chunk never goes through LDS: a thread multiplies the piece it loaded) + sW 24 KB (the W2 chunk as
+//   a [128 k][64 + 32] image, then the W1 chunk as [64 k][128 + 32]: both are B operands stored k-major, read through
+//   ds_read_b64_tr_b16; the dy tile before the first chunk, the epilogue's scratch after the last) = 51 KB.
+struct FfnBwdArgs {
+  const __bf16* DY;   // [M][128] gradient of the FFN2 Linear's output
+  const __bf16* W2;   // [128][I]
+  const __bf16* U;    // [M][I] pre-activation saved by the fused forward
+  const __bf16* W1;   // [I][128]
+  __bf16* DI;         // [M][I] out: gradient of the FFN1 Linear's output
+  int I;
+  GemmArgs e;         // epi_dx_lnbwd_64x128's arguments
+};
+
+__global__ __launch_bounds__(256, 3) void ffn_bwd_dx_fused_kernel(FfnBwdArgs f) {
+  constexpr int H = 128, BM = 64, CH = 64, LDH = H + 8, LDC = CH + 8;
+  constexpr int LD1 = CH + 32;  // W2 chunk image [128 k][CH rows]
+  constexpr int LD2 = H + 32;   // W1 chunk image [CH k][128 rows]
+  constexpr int W_ELEMS = H * LD1 > CH * LD2 ? H * LD1 : CH * LD2;
+  constexpr int LDF = CH + 4;
+  __shared__ __attribute__((aligned(16))) float sF[BM * LDF];  // dG = dy W2 chunk, fp32, accumulator layout -> row-major
+  __shared__ __attribute__((aligned(16))) __bf16 sG[BM * LDC];
+  __shared__ __attribute__((aligned(16))) __bf16 sW[W_ELEMS];
+  static_assert(W_ELEMS >= BM * LDH, "the dy tile is staged through sW");
+  static_assert(W_ELEMS * 2 >= (4 * 16 * 68 + 2 * 2 * 2 * 16 * 2 + 2 * 3 * 128) * 4, "the epilogue's scratch aliases sW");
+  using FN = Frag<PrecBF16, false>;
+  using FT = Frag<PrecBF16, true>;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tid = threadIdx.x;
+  const int wr = wid >> 1, wc = wid & 1;
+  const TileIdx tix = tile_of(1, f.e.nt_m, 1);
+  if (!tix.valid) return;
+  const int64_t m0 = (int64_t)tix.m * BM;
+  const int64_t M = f.e.M;
+  const int I = f.I, nchunk = I / CH;
+
+  bf16x8 wa[4], wb[4], ur[2];  // W2 chunk, W1 chunk, u chunk in flight (native vectors: see WeightChunk)
+  auto load_w2 = [&](int c) {  // W2[k][c CH + j]: 128 rows of 8 pieces
+    xf_static_for<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, k = p >> 3, ch = p & 7;
+      wa[i] = *reinterpret_cast<const bf16x8*>(f.W2 + (int64_t)k * I + c * CH + ch * 8);
+    });
+  };
+  auto commit_w2 = [&]() {
+    xf_static_for<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, k = p >> 3, ch = p & 7;
+      *reinterpret_cast<bf16x8*>(sW + k * LD1 + ch * 8) = wa[i];
+    });
+  };
+  auto load_w1 = [&](int c) {  // W1[c CH + k][n]: 64 rows of 16 pieces
+    xf_static_for<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, k = p >> 4, ch = p & 15;
+      wb[i] = *reinterpret_cast<const bf16x8*>(f.W1 + (int64_t)(c * CH + k) * H + ch * 8);
+    });
+  };
+  auto commit_w1 = [&]() {
+    xf_static_for<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, k = p >> 4, ch = p & 15;
+      *reinterpret_cast<bf16x8*>(sW + k * LD2 + ch * 8) = wb[i];
+    });
+  };
+  auto load_u = [&](int c) {  // u[m0 + row][c CH + ..]: 64 rows of 8 pieces
+    xf_static_for<2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, row = p >> 3, ch = p & 7;
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+      if (m0 + row < M) z = *reinterpret_cast<const bf16x8*>(f.U + (m0 + row) * I + c * CH + ch * 8);
+      ur[i] = z;
+    });
+  };
+
+  // dy tile -> sW (as a [64][136] image) -> this wave's A fragments of all 8 k-steps
+  {
+    uint4 yr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + i * 256, row = p >> 4, ch = p & 15;
+      yr[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (m0 + row < M) yr[i] = *reinterpret_cast<const uint4*>(f.DY + (m0 + row) * H + ch * 8);
+    }
+    load_w2(0);
+    load_u(0);
+    load_w1(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + i * 256, row = p >> 4, ch = p & 15;
+      *reinterpret_cast<uint4*>(sW + row * LDH + ch * 8) = yr[i];
+    }
+  }
+  __syncthreads();
+  bf16x8 ya[H / 16];
+#pragma unroll
+  for (int ks = 0; ks < H / 16; ++ks) ya[ks] = FN::get(sW, LDH, wr * 32, ks * 16);
+
+  f32x16 accx[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[j][r] = 0.f;
+
+  for (int c = 0; c < nchunk; ++c) {
+    XF_LOOP_BARRIER();  // the previous chunk's second GEMM (or the fragment reads above) is done with sW and sG
+    commit_w2();
+    XF_LOOP_BARRIER();
+    if (c + 1 < nchunk) load_w2(c + 1);
+    f32x16 accg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accg[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < H / 16; ++ks) accg = xf_mma(ya[ks], FT::get(sW, LD1, wc * 32, ks * 16), accg);
+    // dG (fp32, accumulator layout: element r of lane l = row (r&3) + 8 (r>>2) + 4 (l>>5), col l&31) -> sF
+    {
+      const int col = wc * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sF[(wr * 32 + xf_acc_row(r, lane)) * LDF + col] = accg[r];
+    }
+    XF_LOOP_BARRIER();  // sF holds dG; every wave is done with the W2 chunk
+    // row-major pass, 8 columns per thread and piece: dI = dG * gelu'(u) with u straight from the registers it was
+    // loaded into -> HBM (16-byte pieces: a wave instruction = 8 rows x 128 B) and -> sG, the second GEMM's A operand
+    xf_static_for<2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int p = tid + i * 256, row = p >> 3, ch = p & 7;
+      const float4 g0 = *reinterpret_cast<const float4*>(sF + row * LDF + ch * 8);
+      const float4 g1 = *reinterpret_cast<const float4*>(sF + row * LDF + ch * 8 + 4);
+      const bf16x8 u8 = ur[i];
+      bf16x8 d8;
+      d8[0] = (__bf16)(g0.x * xf_gelu_grad((float)u8[0])); d8[1] = (__bf16)(g0.y * xf_gelu_grad((float)u8[1]));
+      d8[2] = (__bf16)(g0.z * xf_gelu_grad((float)u8[2])); d8[3] = (__bf16)(g0.w * xf_gelu_grad((float)u8[3]));
+      d8[4] = (__bf16)(g1.x * xf_gelu_grad((float)u8[4])); d8[5] = (__bf16)(g1.y * xf_gelu_grad((float)u8[5]));
+      d8[6] = (__bf16)(g1.z * xf_gelu_grad((float)u8[6])); d8[7] = (__bf16)(g1.w * xf_gelu_grad((float)u8[7]));
+      if (m0 + row < M) *reinterpret_cast<bf16x8*>(f.DI + (m0 + row) * I + c * CH + ch * 8) = d8;
+      *reinterpret_cast<bf16x8*>(sG + row * LDC + ch * 8) = d8;
+    });
+    commit_w1();
+    XF_LOOP_BARRIER();
+    if (c + 1 < nchunk) { load_w1(c + 1); load_u(c + 1); }
+#pragma unroll
+    for (int ks = 0; ks < CH / 16; ++ks) {
+      const bf16x8 fa = FN::get(sG, LDC, wr * 32, ks * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) accx[j] = xf_mma(fa, FT::get(sW, LD2, wc * 64 + j * 32, ks * 16), accx[j]);
+    }
+  }
+  __syncthreads();  // everyone is done with sW: the epilogue's scratch aliases it
+  epi_dx_lnbwd_64x128(accx, reinterpret_cast<unsigned char*>(sW), f.e, m0, tix.m, wid, lane);
 }
 
 // Deterministic column sums of a [rows, cols] fp32 matrix: block (x, y) sums rows [y*rows_per, (y+1)*rows_per)
@@ -1204,7 +1422,7 @@ int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, con
                         void* y16, float* mean, float* rstd, hipStream_t st) {
   if (!x16 || !w1_16 || !b1 || !w2_16 || !pre || !residual || !gamma || !beta || !y || !mean || !rstd || M <= 0)
     return XFMR_EINVAL;
-  if (H != 128 || I <= 0 || (I % 128)) return XFMR_EUNSUPPORTED;
+  if (H != 128 || I <= 0 || (I % 128) || I > 1024) return XFMR_EUNSUPPORTED;  // (b1 is staged in 4 KB of LDS)
   if (!xf_aligned16(x16) || !xf_aligned16(w1_16) || !xf_aligned16(w2_16) || !xf_aligned16(pre) || !xf_aligned16(residual) ||
       !xf_aligned16(y) || (u16 && !xf_aligned16(u16)) || (g16 && !xf_aligned16(g16)) || (y16 && !xf_aligned16(y16)) || !xf_aligned16(b1) ||
       (b2 && !xf_aligned16(b2)) || !xf_aligned16(gamma) || !xf_aligned16(beta))
@@ -1212,6 +1430,9 @@ int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, con
   FfnFwdArgs f{};
   f.X = (const __bf16*)x16; f.W1 = (const __bf16*)w1_16; f.b1 = b1; f.W2 = (const __bf16*)w2_16; f.U = (__bf16*)u16; f.G = (__bf16*)g16;
   f.I = I;
+#ifdef XF_FFN_STAMP
+  if (const char* e = getenv("XFMR_FFN_STAMPS")) f.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
   GemmArgs& g = f.e;
   g.C = pre; g.ldc = H; g.M = M; g.N = H; g.K = I; g.bias = b2; g.R = residual;
   g.drop = xf_make_dropout(dropout_p, seed, site);
@@ -1223,6 +1444,36 @@ int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, con
   const int chunk = ce ? atoi(ce) : 64;
   if (chunk == 64) hipLaunchKernelGGL(ffn_fwd_fused_kernel<64>, dim3((unsigned)(groups * 8)), dim3(256), 0, st, f);
   else hipLaunchKernelGGL(ffn_fwd_fused_kernel<128>, dim3((unsigned)(groups * 8)), dim3(256), 0, st, f);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int xf_ffn_bwd_dx_fused_ex(const void* dy16, const void* w2_16, const void* u16, const void* w1_16, void* di16, int64_t M,
+                           int32_t H, int32_t I, const float* residual_grad, const float* ln_x, const float* ln_mean,
+                           const float* ln_rstd, const float* ln_gamma, float dropout_p, uint64_t seed, uint32_t site,
+                           float* dx, void* d_lin16, float* partials, int* blocks_out, hipStream_t st) {
+  if (!dy16 || !w2_16 || !u16 || !w1_16 || !di16 || !ln_x || !ln_mean || !ln_rstd || !ln_gamma || !dx || !partials ||
+      !blocks_out || M <= 0)
+    return XFMR_EINVAL;
+  if (H != 128 || I <= 0 || (I % 64)) return XFMR_EUNSUPPORTED;
+  if (!xf_aligned16(dy16) || !xf_aligned16(w2_16) || !xf_aligned16(u16) || !xf_aligned16(w1_16) || !xf_aligned16(di16) ||
+      !xf_aligned16(dx) || !xf_aligned16(ln_x) || (residual_grad && !xf_aligned16(residual_grad)) ||
+      (d_lin16 && !xf_aligned16(d_lin16)) || !xf_aligned16(ln_gamma))
+    return XFMR_EALIGN;
+  FfnBwdArgs f{};
+  f.DY = (const __bf16*)dy16; f.W2 = (const __bf16*)w2_16; f.U = (const __bf16*)u16; f.W1 = (const __bf16*)w1_16;
+  f.DI = (__bf16*)di16; f.I = I;
+  GemmArgs& g = f.e;
+  g.C = dx; g.ldc = H; g.M = M; g.N = H; g.K = I; g.R = residual_grad;
+  g.drop = xf_make_dropout(dropout_p, seed, site);
+  g.drop2 = xf_make_dropout(0.f, 0, 0);
+  g.ln_gamma = ln_gamma; g.lnb_x = ln_x; g.lnb_mean = ln_mean; g.lnb_rstd = ln_rstd; g.D16 = d_lin16;
+  g.lnb_partials = partials;
+  g.nt_n = 1; g.nt_m = (int)((M + 63) / 64); g.nt_z = 1;
+  *blocks_out = g.nt_m;
+  const int64_t groups = (g.nt_m + 7) / 8;
+  if (groups * 8 > 0x7fffffffll) return XFMR_EUNSUPPORTED;
+  hipLaunchKernelGGL(ffn_bwd_dx_fused_kernel, dim3((unsigned)(groups * 8)), dim3(256), 0, st, f);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }

@@ -25,6 +25,12 @@ int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, con
                         void* u16, void* g16, float* pre, int64_t M, int32_t H, int32_t I, const float* residual, float dropout_p,
                         uint64_t seed, uint32_t site, const float* gamma, const float* beta, float eps, float* y,
                         void* y16, float* mean, float* rstd, hipStream_t st);
+// The dX chain of the FFN backward in one kernel (bf16 storage, H = 128, I a multiple of 64; after the fused forward:
+// u16 = the saved pre-activation): di16 <- (dy16 W2) * gelu'(u16), then exactly xf_linear_bwd_dx_lnbwd_ex on di16 / W1.
+int xf_ffn_bwd_dx_fused_ex(const void* dy16, const void* w2_16, const void* u16, const void* w1_16, void* di16, int64_t M,
+                           int32_t H, int32_t I, const float* residual_grad, const float* ln_x, const float* ln_mean,
+                           const float* ln_rstd, const float* ln_gamma, float dropout_p, uint64_t seed, uint32_t site,
+                           float* dx, void* d_lin16, float* partials, int* blocks_out, hipStream_t st);
 int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int32_t N, int32_t K,
                         const float* residual_grad, const void* gelu_pre, int32_t precision, uint32_t s16,
                         hipStream_t st);
