@@ -343,6 +343,17 @@ __device__ __forceinline__ float xf_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// Sum over the 16 lanes of a DPP row (lanes 16 i .. 16 i + 15), result in every lane, through data-parallel-primitive
+// operands of the adds themselves: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8. (__shfl_xor compiles to
+// ds_bpermute_b32 -- an LDS-crossbar instruction plus a separate add per step; the LayerNorm epilogues do 16-22 such
+// reductions per tile and are bound by instruction issue.)
+__device__ __forceinline__ float xf_row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+  return x;
+}
 __device__ __forceinline__ float xf_half_swap(float v) { return __shfl_xor(v, 32, 64); }  // lane <-> lane^32
 
 // raw transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32: 1 ulp, no denormal fix-up code around them)

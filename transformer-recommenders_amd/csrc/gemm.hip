@@ -356,10 +356,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
     __builtin_amdgcn_wave_barrier();
   }
   XF_EPI_BARRIER();  // every wave is done with its scratch strip before `red` (behind the strips) is written
-  auto row_reduce = [&](float x) {  // over the 16 lanes that hold a row's 64 columns of this wave
-    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
-    return x;
-  };
+  auto row_reduce = [&](float x) { return xf_row16_sum(x); };  // the 16 lanes that hold a row's 64 columns of this wave
   float mean[2][NPL];
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf)
@@ -430,10 +427,7 @@ __device__ __forceinline__ void epi_dx_lnbwd_64x128(const f32x16 (&acc)[2], unsi
   const int n = wc * WN + c0;
   const float4 gam = *reinterpret_cast<const float4*>(g.ln_gamma + n);
   float4 dgam = make_float4(0, 0, 0, 0), dbet = dgam, dbias = dgam;
-  auto row_reduce = [&](float x) {
-    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
-    return x;
-  };
+  auto row_reduce = [&](float x) { return xf_row16_sum(x); };
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
     const int64_t mb = m0 + wr * WM + 16 * hf;
