@@ -314,6 +314,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
   // The wave owns 32 rows x 64 columns; a row's other 64 columns are with the partner wave (wc ^ 1). Lane ->
   // (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3): 16 lanes per row, 8 rows per lane, all kept in registers.
   constexpr int LPRL = 16, RPPL = 4, NPL = 4, WM = 32, WN = 64, NI = 2, SCR_LD = WN + 4;
+  constexpr int64_t LDC = 128;  // (N == ldc == 128 by construction: offsets are shifts, not 64-bit multiplies)
   const int wr = wid >> 1, wc = wid & 1;
   float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
   float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 wr][2 wc][32 rows] x 2 (sum, sumsq)
@@ -329,7 +330,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
     for (int ps = 0; ps < NPL; ++ps) {
       aux[ps] = make_float4(0, 0, 0, 0);
       const int64_t m = mb + prow + RPPL * ps;
-      if (m < g.M) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * g.ldc + n);
+      if (m < g.M) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * LDC + n);
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j)
@@ -349,7 +350,7 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
       }
       v.x += aux[ps].x; v.y += aux[ps].y; v.z += aux[ps].z; v.w += aux[ps].w;
       if (m >= g.M) v = make_float4(0, 0, 0, 0);
-      else *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = v;
+      else *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * LDC + n) = v;
       vv[hf][ps] = v;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -401,8 +402,8 @@ __device__ __forceinline__ void epi_drop_res_ln_64x128(const f32x16 (&acc)[2], u
       float4 o;
       o.x = d.x * rs * gm.x + bt.x; o.y = d.y * rs * gm.y + bt.y;
       o.z = d.z * rs * gm.z + bt.z; o.w = d.w * rs * gm.w + bt.w;
-      *reinterpret_cast<float4*>(g.Y + m * g.ldc + n) = o;
-      if (g.Y16) xf_st4<true>(g.Y16, m * g.ldc + n, o);
+      *reinterpret_cast<float4*>(g.Y + m * LDC + n) = o;
+      if (g.Y16) xf_st4<true>(g.Y16, m * LDC + n, o);
       if (wc == 0 && li == 0) {
         g.ln_mean[m] = mean[hf][ps];
         g.ln_rstd[m] = rs;
@@ -419,6 +420,7 @@ __device__ __forceinline__ void epi_dx_lnbwd_64x128(const f32x16 (&acc)[2], unsi
   // Same lane map as EPI_DROP_RES_LN: lane -> (row = prow + 4 ps + 16 hf, columns c0 .. c0 + 3). A half strip
   // (16 rows) at a time: the two row sums of the LayerNorm backward are exchanged with the partner wave per half.
   constexpr int LPRL = 16, RPPL = 4, NPL = 4, WM = 32, WN = 64, NI = 2, SCR_LD = WN + 4;
+  constexpr int64_t LDC = 128;  // (N == ldc == 128 by construction: offsets are shifts, not 64-bit multiplies)
   const int wr = wid >> 1, wc = wid & 1;
   float* const scr = reinterpret_cast<float*>(smem) + wid * (16 * SCR_LD);
   float* const red = reinterpret_cast<float*>(smem) + 4 * 16 * SCR_LD;  // [2 hf][2 wr][2 wc][16 rows][2]
@@ -439,8 +441,8 @@ __device__ __forceinline__ void epi_dx_lnbwd_64x128(const f32x16 (&acc)[2], unsi
       mu[ps] = rs[ps] = 0.f;
       const int64_t m = mb + prow + RPPL * ps;
       if (m < g.M) {
-        if (g.R) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * g.ldc + n);
-        xv[ps] = *reinterpret_cast<const float4*>(g.lnb_x + m * g.ldc + n);
+        if (g.R) aux[ps] = *reinterpret_cast<const float4*>(g.R + m * LDC + n);
+        xv[ps] = *reinterpret_cast<const float4*>(g.lnb_x + m * LDC + n);
         mu[ps] = g.lnb_mean[m];
         rs[ps] = g.lnb_rstd[m];
       }
@@ -496,12 +498,12 @@ __device__ __forceinline__ void epi_dx_lnbwd_64x128(const f32x16 (&acc)[2], unsi
       float4 d;
       d.x = rs[ps] * (gg.x - mg - h.x * mgx); d.y = rs[ps] * (gg.y - mg - h.y * mgx);
       d.z = rs[ps] * (gg.z - mg - h.z * mgx); d.w = rs[ps] * (gg.w - mg - h.w * mgx);
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = d;
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * LDC + n) = d;
       float4 dl = d;
       if (g.drop.on) {
         xf_drop4(g.drop, (uint32_t)m, (uint32_t)(n), dl);
       }
-      if (g.D16) xf_st4<true>(g.D16, m * g.ldc + n, dl);
+      if (g.D16) xf_st4<true>(g.D16, m * LDC + n, dl);
       dbias.x += dl.x; dbias.y += dl.y; dbias.z += dl.z; dbias.w += dl.w;
     }
   }
