@@ -20,12 +20,16 @@ TH, TI, T3H = T * H, T * I, T * 3 * H
 # kernel-name fragment -> (description, algorithmic bytes per launch (average over the launches that share the name), flops)
 K = [
     ("gemm_kernel<PrecBF16, 64, 128, 64, false, false, 0,", "QKV Linear fwd", TH * b16 + T3H * b16, 2 * T * 3 * H * H),
-    ("gemm_kernel<PrecBF16, 64, 128, 64, false, false, 1,", "FFN1 Linear fwd + GELU (+ gelu')", TH * b16 + 2 * TI * b16, 2 * T * I * H),
-    ("gemm_kernel<PrecBF16, 64, 128, 64, false, false, 5,", "out-proj / FFN2 Linear fwd + dropout + residual + LayerNorm (avg)",
-     ((TH * b16 + TH * f32 * 3 + TH * b16) + (TI * b16 + TH * f32 * 3 + TH * b16)) / 2, (2 * T * H * H + 2 * T * H * I) / 2),
-    ("gemm_kernel<PrecBF16, 64, 128, 64, false, true, 6,", "FFN1 / QKV dX + residual grad + LayerNorm bwd (avg)",
-     ((TI * b16 + TH * f32 * 3 + TH * b16) + (T3H * b16 + TH * f32 * 3 + TH * b16)) / 2, (2 * T * H * I + 2 * T * H * 3 * H) / 2),
-    ("gemm_kernel<PrecBF16, 64, 64, 64, false, true, 3,", "FFN2 dX x gelu'", TH * b16 + 2 * TI * b16, 2 * T * I * H),
+    ("ffn_fwd_fused_kernel", "FFN fwd in one kernel: FFN1 + GELU + FFN2 + dropout + residual + LayerNorm (writes u, g)",
+     TH * b16 + TH * f32 + 2 * TI * b16 + 2 * TH * f32 + TH * b16, 4 * T * I * H),
+    ("gemm_kernel<PrecBF16, 64, 128, 64, false, false, 1,", "FFN1 Linear fwd + GELU (+ gelu') [two-kernel form]", TH * b16 + 2 * TI * b16, 2 * T * I * H),
+    ("gemm_kernel<PrecBF16, 64, 128, 64, false, false, 5,", "out-proj Linear fwd + dropout + residual + LayerNorm",
+     TH * b16 + TH * f32 * 3 + TH * b16, 2 * T * H * H),
+    ("ffn_bwd_dx_fused_kernel", "FFN bwd dX chain in one kernel: FFN2 dX x gelu'(u) -> dI -> FFN1 dX + LayerNorm bwd",
+     TH * b16 + 2 * TI * b16 + TH * f32 * 3 + TH * b16, 4 * T * I * H),
+    ("gemm_kernel<PrecBF16, 64, 128, 64, false, true, 6,", "QKV dX + residual grad + LayerNorm bwd",
+     T3H * b16 + TH * f32 * 3 + TH * b16, 2 * T * H * 3 * H),
+    ("gemm_kernel<PrecBF16, 64, 64, 64, false, true, 3,", "FFN2 dX x gelu' [two-kernel form]", TH * b16 + 2 * TI * b16, 2 * T * I * H),
     ("gemm_kernel<PrecBF16, 64, 64, 64, false, true, 0, 7u", "out-proj dX", 2 * TH * b16, 2 * T * H * H),
     ("gemm_kernel<PrecBF16, 64, 64, 64, false, true, 0, 3u", "QKV dX + residual grad (layer 0)", T3H * b16 + 2 * TH * f32, 2 * T * H * 3 * H),
     ("gemm_kernel<PrecBF16, 128, 64, 128, true, true, 4,", "dW split-K (avg of the 4 weights; operands only, + 14 MB of slabs)",
@@ -37,9 +41,9 @@ K = [
     ("loss_main_dma_kernel<128, 7>", "loss gradient pass", 0, 4.0 * T * ND * H),
     ("loss_main_dma_kernel<128, -3>", "loss logging pass (6 heads + statistics; masked fast path)", 0, 2.0 * T * ND * H),
     ("loss_main_dma_kernel<128, -2>", "loss logging pass (6 heads + statistics)", 0, 2.0 * T * ND * H),
-    ("loss_combine_kernel", "loss combine", 2 * TH * f32 + TH * f32 + TH * f32, 0),
-    ("multi_rowsum_kernel", "split-K slab / partial-record reduction", 0, 0),
-    ("scale_kernel", "d_tok *= upstream gradient", 2 * TH * f32, 0),
+    ("loss_combine_kernel", "loss combine (values only)", 0, 0),
+    ("multi_rowsum_kernel", "split-K slab / partial-record reduction", 247e6, 0),
+    ("scale_kernel", "d_tok *= upstream gradient (returns at once when it is 1)", 0, 0),
 ]
 
 import argparse
@@ -66,7 +70,7 @@ for frag, desc, nbytes, flops in K:
     tb = f"{nbytes / (avg * 1e-6) / 1e12:.2f}" if nbytes else "—"
     tf = f"{flops / (avg * 1e-6) / 1e12:.0f}" if flops else "—"
     lines.append(f"| {desc} (`{frag.strip(', ')}`) | {calls / steps:.1f} | {avg:.1f} | {nbytes / MB:.0f} | {tb} | {tf} |")
-    if frag.startswith("gemm_kernel"):
+    if frag.startswith(("gemm_kernel", "ffn_")):
         gemm_bytes += nbytes * calls / steps
         gemm_ns += tot / steps
 if args.json:
