@@ -72,6 +72,9 @@ struct Acts {
   float* emb_ln;  // embedding LayerNorm partial records
   float *dA, *dB;
   void *dLin, *dCtx, *dI, *dQKV;  // bf16 when mixed
+  // one set PER LAYER for the side-stream dW GEMMs (xfmr_encoder_bwd): dLin in its two roles (gradient of the FFN2 / of
+  // the out-proj Linear's output), dI and dQKV -- no buffer is rewritten while a weight-gradient GEMM may still read it
+  void *dLinF[64], *dLinO[64], *dI2[64], *dQKV2[64];
   void* wbf;      // bf16 copy of the flat parameter buffer (mixed storage): the B operand of the forward / dX GEMMs
   void* scratch;  // ln-bwd partials / dW slabs / colsum partials (used one at a time)
   size_t scratch_bytes;
@@ -104,6 +107,12 @@ bool ffn_fused(const xfmr_encoder_cfg* c, int64_t T) {
          !on("XFMR_FFN_UNFUSED");
 }
 
+// Shapes whose backward runs the weight-gradient GEMMs on the side stream (xfmr_encoder_bwd): those of the LayerNorm-fused
+// dX GEMMs. The workspace holds one set of the gradient buffers per layer for them.
+bool dw_side_shape(const xfmr_encoder_cfg* c, int64_t T) {
+  return mixed_storage(c) && c->hidden == 128 && T >= 16384 && c->layers <= 64;
+}
+
 // Carves `base` (may be null: size query). Layer i's activations are returned in *la when i >= 0.
 Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs* la, RedBufs* rb = nullptr) {
   const size_t T = (size_t)c->batch * c->seq_len, H = c->hidden, I = c->inter, A = c->heads;
@@ -122,6 +131,13 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   a.dA = take(T * H); a.dB = take(T * H);
   a.dLin = take_bytes(T * H * es); a.dCtx = take_bytes(T * H * es);
   a.dI = take_bytes(T * I * es); a.dQKV = take_bytes(T * 3 * H * es);
+  const bool per_layer = dw_side_shape(c, (int64_t)T);  // (+236 MB per layer at T = 102 400, I = 512)
+  for (int i = 0; i < c->layers && i < 64; ++i) {
+    a.dLinF[i] = (per_layer && i) ? take_bytes(T * H * es) : a.dLin;
+    a.dLinO[i] = per_layer ? take_bytes(T * H * es) : a.dLin;
+    a.dI2[i] = (per_layer && i) ? take_bytes(T * I * es) : a.dI;
+    a.dQKV2[i] = (per_layer && i) ? take_bytes(T * 3 * H * es) : a.dQKV;
+  }
   a.wbf = take_bytes(mixed_storage(c) ? (size_t)xfmr_param_count(c) * 2 : 0);
   size_t sc = xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H);
   size_t s2 = xfmr_linear_bwd_dw_workspace((int64_t)T, (int32_t)(3 * H), (int32_t)H);
@@ -364,6 +380,34 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   const bool fuse_lnb = mix && H == 128 && T >= 16384 && !no_fuse;
   const bool fuse_ffn = ffn_fused(cfg, T);  // what the forward of this step did
   const bool no_ffn_bwd = [] { const char* e = getenv("XFMR_FFN_BWD_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
+  // The weight-gradient GEMMs (16 of the backward's launches, 0.49 ms at batch 512) run on a LOW-PRIORITY side stream: the
+  // dX -> LayerNorm -> attention chain keeps the CUs it wants, and the dW workgroups fill what its 64-row-tile kernels
+  // leave idle in their last rounds (1600 tiles over 768 / 1024 workgroup slots: section 4 of DESIGN.md). Same priority
+  // was measured in round 1 and gained nothing (each side slowed by what the overlap gave). Dependencies: a dW GEMM
+  // starts after an event recorded behind the producers of its operands; the gradient buffers the chain used to reuse layer
+  // after layer (dLin in both roles, dI, dQKV) exist once PER LAYER in this mode, so nothing a dW GEMM reads is rewritten
+  // before the chain joins the side stream in front of the reduction launch (with two sets alternating by layer parity
+  // and write-after-read events the chain kept stalling on the lagging side stream: 0.4 % instead of 2 %).
+  // XFMR_DW_SIDE=0: everything on `st`.
+  static thread_local hipStream_t side = nullptr;
+  static thread_local hipEvent_t ev_in = nullptr, ev_done = nullptr;
+  const bool dw_side = fuse_lnb && dw_side_shape(cfg, T) && [] { const char* e = getenv("XFMR_DW_SIDE"); return !(e && *e == '0'); }();
+  if (dw_side && !side) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess)
+      return XFMR_EHIP;
+  }
+  bool side_used = false;
+  int side_rc = XFMR_OK;
+  auto dw_stream = [&]() -> hipStream_t {  // everything enqueued on `st` so far is visible to the side stream
+    if (!dw_side) return st;
+    if (hipEventRecord(ev_in, st) != hipSuccess || hipStreamWaitEvent(side, ev_in, 0) != hipSuccess) side_rc = XFMR_EHIP;
+    side_used = true;
+    return side;
+  };
   bool ln2_done = false;  // layer i's LN2 backward already ran inside layer i+1's QKV dX GEMM
   bool emb_ln_done = false;  // ... and the embedding LayerNorm's inside layer 0's
   for (int i = cfg->layers - 1; i >= 0; --i) {
@@ -378,54 +422,58 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       x_in_g = mix ? prev.x2b : (const void*)prev.x2;
     }
     int blocks = 0, splits = 0;
+    void* const dLinF = dw_side ? a.dLinF[i] : a.dLin;   // gradient of the FFN2 Linear's output (dropout-scaled d(pre2))
+    void* const dLinO = dw_side ? a.dLinO[i] : a.dLin;   // gradient of the out-proj Linear's output
+    void* const dI = dw_side ? a.dI2[i] : a.dI;
+    void* const dQKV = dw_side ? a.dQKV2[i] : a.dQKV;
     // LayerNorm 2 -> dA = d(pre2); d_lin = gradient of the FFN output Linear (dropout-scaled copy of it)
     const bool lin_copy = hdrop || mix;  // without dropout and with fp32 storage d_lin IS dx
     if (!ln2_done) {
-      XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, lin_copy ? a.dLin : nullptr,
+      XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, lin_copy ? dLinF : nullptr,
                                    mix, nullptr, nullptr, nullptr, T, H, off,
                                    xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_ffn(i)), r.ln2, st, &blocks));
       seg(r.ln2, grads + p.ln2g, blocks, H, 3 * H);
       seg(r.ln2 + H, grads + p.ln2b, blocks, H, 3 * H);
       seg(r.ln2 + 2 * H, grads + p.b2, blocks, H, 3 * H);
     }
-    const void* dlin = lin_copy ? a.dLin : (const void*)a.dA;
-    XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, st));
+    const void* dlin = lin_copy ? dLinF : (const void*)a.dA;
+    XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, dw_stream()));
     seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
     const bool fuse_ffn_bwd = fuse_ffn && fuse_lnb && !no_ffn_bwd;
     if (fuse_ffn_bwd) {  // FFN2 dX * gelu'(u) -> dI -> FFN1 dX (+= d(pre2)) -> LayerNorm 1 backward in one kernel
-      XF_TRY(xf_ffn_bwd_dx_fused_ex(dlin, W(p.w2), l.f1, W(p.w1), a.dI, T, H, I, a.dA, l.pre1, l.mean1, l.rstd1,
-                                    params + p.ln1g, cfg->hidden_dropout, cfg->seed, site_out(i), dX, a.dLin, r.ln1,
+      XF_TRY(xf_ffn_bwd_dx_fused_ex(dlin, W(p.w2), l.f1, W(p.w1), dI, T, H, I, a.dA, l.pre1, l.mean1, l.rstd1,
+                                    params + p.ln1g, cfg->hidden_dropout, cfg->seed, site_out(i), dX, dLinO, r.ln1,
                                     &blocks, st));
     } else {
       // (after the fused FFN forward f1 holds the pre-activation u, not gelu'(u): the epilogue evaluates gelu'(u))
-      XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), a.dI, T, H, I, nullptr, l.f1, prec,
+      XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), dI, T, H, I, nullptr, l.f1, prec,
                                  sA | sC | sP | sB | (fuse_ffn ? 0 : XF_AUX_GELU_GRAD), st));
     }
-    XF_TRY(xf_linear_bwd_dw_deferred(a.dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, st));  // + b1 partial rows
+    XF_TRY(xf_linear_bwd_dw_deferred(dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, dw_stream()));  // + b1 partial rows
     seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
     seg(r.b1, grads + p.b1, splits, I, I);
     if (fuse_ffn_bwd) {  // (done above)
     } else if (fuse_lnb) {  // dX of FFN1 (+= d(pre2)) and LayerNorm 1 backward in one kernel -> dX = d(pre1), dLin
-      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(a.dI, W(p.w1), T, I, H, a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g,
-                                       cfg->hidden_dropout, cfg->seed, site_out(i), dX, a.dLin, r.ln1, &blocks, prec,
+      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(dI, W(p.w1), T, I, H, a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g,
+                                       cfg->hidden_dropout, cfg->seed, site_out(i), dX, dLinO, r.ln1, &blocks, prec,
                                        sA | sB, st));
     } else {
-      XF_TRY(xf_linear_bwd_dx_ex(a.dI, W(p.w1), a.dA, T, I, H, a.dA, nullptr, prec, sA | sB, st));  // += d(pre2)
+      XF_TRY(xf_linear_bwd_dx_ex(dI, W(p.w1), a.dA, T, I, H, a.dA, nullptr, prec, sA | sB, st));  // += d(pre2)
       // LayerNorm 1 -> dX = d(pre1)
-      XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, lin_copy ? a.dLin : nullptr,
+      XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, lin_copy ? dLinO : nullptr,
                                    mix, nullptr, nullptr, nullptr, T, H, off,
                                    xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_out(i)), r.ln1, st, &blocks));
     }
     seg(r.ln1, grads + p.ln1g, blocks, H, 3 * H);
     seg(r.ln1 + H, grads + p.ln1b, blocks, H, 3 * H);
     seg(r.ln1 + 2 * H, grads + p.bo, blocks, H, 3 * H);
-    dlin = lin_copy ? a.dLin : (const void*)dX;
-    XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.ctx, T, H, H, prec, sAB, r.wo, nullptr, &splits, st));
+    dlin = lin_copy ? dLinO : (const void*)dX;
+    XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.ctx, T, H, H, prec, sAB, r.wo, nullptr, &splits, dw_stream()));
     seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
-    XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, a.dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
+    XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
                           site_attn(i), prec, mix, causal, st));
-    XF_TRY(xf_linear_bwd_dw_deferred(a.dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, st));
+    XF_TRY(xf_linear_bwd_dw_deferred(dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, dw_stream()));
     seg(r.wqkv, grads + p.wqkv, splits, (int64_t)3 * H * H, (int64_t)3 * H * H);
     seg(r.bqkv, grads + p.bqkv, splits, 3 * H, 3 * H);
     ln2_done = false;
@@ -433,9 +481,9 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       RedBufs rp;
       carve(cfg, base, i - 1, &prev, &rp);
       const LayerParams pp = layer_params(cfg, i - 1);
-      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(a.dQKV, W(p.wqkv), T, 3 * H, H, dX, prev.pre2, prev.mean2, prev.rstd2,
-                                       params + pp.ln2g, cfg->hidden_dropout, cfg->seed, site_ffn(i - 1), a.dA, a.dLin,
-                                       rp.ln2, &blocks, prec, sA | sB, st));
+      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(dQKV, W(p.wqkv), T, 3 * H, H, dX, prev.pre2, prev.mean2, prev.rstd2,
+                                       params + pp.ln2g, cfg->hidden_dropout, cfg->seed, site_ffn(i - 1), a.dA,
+                                       dw_side ? a.dLinF[i - 1] : a.dLin, rp.ln2, &blocks, prec, sA | sB, st));
       seg(rp.ln2, grads + pp.ln2g, blocks, H, 3 * H);
       seg(rp.ln2 + H, grads + pp.ln2b, blocks, H, 3 * H);
       seg(rp.ln2 + 2 * H, grads + pp.b2, blocks, H, 3 * H);
@@ -443,14 +491,14 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     } else if (fuse_lnb) {  // layer 0: dX of QKV (+= d(pre1)) and the EMBEDDING LayerNorm backward -> dA
       ParamLayout pe;
       layer_base(cfg, 0, &pe);
-      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(a.dQKV, W(p.wqkv), T, 3 * H, H, dX, a.emb_pre, a.emb_mean, a.emb_rstd,
+      XF_TRY(xf_linear_bwd_dx_lnbwd_ex(dQKV, W(p.wqkv), T, 3 * H, H, dX, a.emb_pre, a.emb_mean, a.emb_rstd,
                                        params + pe.eg, 0.f, cfg->seed, 0, a.dA, nullptr, a.emb_ln, &blocks, prec,
                                        sA | sB, st, cfg->hidden_dropout, SITE_EMB));
       seg(a.emb_ln, grads + pe.eg, blocks, H, 3 * H);
       seg(a.emb_ln + H, grads + pe.eb, blocks, H, 3 * H);
       emb_ln_done = true;
     } else {
-      XF_TRY(xf_linear_bwd_dx_ex(a.dQKV, W(p.wqkv), dX, T, 3 * H, H, dX, nullptr, prec, sA | sB, st));  // += d(pre1)
+      XF_TRY(xf_linear_bwd_dx_ex(dQKV, W(p.wqkv), dX, T, 3 * H, H, dX, nullptr, prec, sA | sB, st));  // += d(pre1)
     }
   }
   ParamLayout pl;
@@ -465,6 +513,10 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   }
   // (Measured and not kept: the weight-gradient GEMMs on a side stream beside the dX -> LayerNorm -> attention chain.
   // The kernels do overlap, and each slows down by what the overlap would have gained: 1.910 vs 1.904 ms/step.)
+  if (side_used) {  // the chain joins the side stream: the reduction launch reads every slab
+    if (hipEventRecord(ev_done, side) != hipSuccess || hipStreamWaitEvent(st, ev_done, 0) != hipSuccess) side_rc = XFMR_EHIP;
+  }
+  if (side_rc != XFMR_OK) return side_rc;
   XF_TRY(xf_multi_rowsum(segs, nseg, st));  // every weight / bias / LayerNorm gradient of the encoder, one launch
   XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
   return XFMR_OK;
