@@ -75,6 +75,12 @@ enum {
 
 const char* xfmr_strerror(int code);
 int xfmr_abi_version(void);
+/* A non-blocking HIP stream of the device's LOWEST priority (hipStreamCreateWithPriority), for work that should fill
+ * what the training chain leaves idle rather than compete with it: the deferred logging pass of the loss
+ * (xfmr_rec_amd/trainer.py), the weight-gradient GEMMs inside xfmr_encoder_bwd. The caller owns it
+ * (xfmr_stream_destroy). torch only offers "normal" and "high". */
+int xfmr_low_priority_stream_create(void** stream);
+int xfmr_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder configuration and the flat parameter layout.

@@ -228,6 +228,21 @@ const char* xfmr_strerror(int code) {
 }
 int xfmr_abi_version(void) { return XFMR_ABI_VERSION; }
 
+int xfmr_low_priority_stream_create(void** stream) {
+  if (!stream) return XFMR_EINVAL;
+  int lo = 0, hi = 0;
+  hipStream_t s = nullptr;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess)
+    return XFMR_EHIP;
+  *stream = s;
+  return XFMR_OK;
+}
+int xfmr_stream_destroy(void* stream) {
+  if (!stream) return XFMR_EINVAL;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? XFMR_OK : XFMR_EHIP;
+}
+
 int64_t xfmr_param_count(const xfmr_encoder_cfg* cfg) {
   if (!cfg || cfg->layers <= 0) return XFMR_EINVAL;
   ParamLayout pl;

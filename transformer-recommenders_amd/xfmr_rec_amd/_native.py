@@ -64,6 +64,8 @@ _P = C.c_void_p
 _SIGNATURES = {
     "xfmr_strerror": (C.c_char_p, [C.c_int]),
     "xfmr_abi_version": (C.c_int, []),
+    "xfmr_low_priority_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "xfmr_stream_destroy": (C.c_int, [_P]),
     "xfmr_param_count": (C.c_int64, [C.POINTER(EncoderCfg)]),
     "xfmr_param_offsets": (C.c_int32, [C.POINTER(EncoderCfg), C.POINTER(C.c_int64), C.c_int32]),
     "xfmr_embed_ln_fwd": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,

@@ -120,7 +120,20 @@ class RecommenderLightningModule(_Base):
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.model.device)
+            # lowest priority: the logging pass fills what the training chain leaves idle instead of competing with it
+            # (XFMR_LOG_STREAM_PRIORITY overrides; torch: lower number = higher priority, 0 = the default stream's)
+            # (torch offers only "normal" and "high": the stream comes from the library. XFMR_LOG_STREAM_PRIORITY=0:
+            # a normal-priority torch stream.)
+            import ctypes
+            import os
+
+            if os.environ.get("XFMR_LOG_STREAM_PRIORITY", "low") == "0":
+                self._side = torch.cuda.Stream(device=self.model.device)
+            else:
+                handle = ctypes.c_void_p()
+                with torch.cuda.device(self.model.device):
+                    N.check(N.load().xfmr_low_priority_stream_create(ctypes.byref(handle)), "xfmr_low_priority_stream_create")
+                self._side = torch.cuda.ExternalStream(handle.value, device=self.model.device)
         return self._side
 
     def sync_logging(self) -> None:
@@ -403,7 +416,7 @@ class Trainer:
 
             allreduce_flat_grad_(m.model.flat.grad, self.process_group)
         self.optimizer.step()
-        m.sync_logging()
+        m.sync_logging()  # (leaving the pass to finish underneath the next step's forward measured no gain: 3.411 vs 3.414 ms)
         return loss.detach()
 
     def fit(self, batches, max_steps: int | None = None) -> list[float]:
