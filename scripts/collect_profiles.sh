@@ -12,7 +12,9 @@ mkdir -p "$OUT"
 cd "$ROOT"
 timeout -k 10 420 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- \
+# per-kernel durations: ONE stream (no side-stream logging pass, weight-gradient GEMMs in line), so that no kernel's
+# duration contains another's; the overlapped run the bench line is measured in follows
+XFMR_DW_SIDE=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- \
   python3 "$ROOT/bench.py" --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline --overlap off > "$OUT/trace.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_overlap" -o bench -- \
   python3 "$ROOT/bench.py" --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline --overlap on > "$OUT/trace_overlap.log" 2>&1
