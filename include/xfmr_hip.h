@@ -24,11 +24,14 @@
  *   - return value: 0 on success, a negative XFMR_E* code otherwise (never throws, never aborts).
  *     Asynchronous HIP errors surface at the caller's next synchronisation.
  *   - re-entrant: no device-side state survives a call, nothing is retained between calls; safe for one process
- *     per GPU and for several host threads on different streams. Two qualifications, neither touching results:
+ *     per GPU and for several host threads on different streams. Three qualifications, none touching results:
  *     (1) the measurement hook xfmr_sampled_loss_profile_* arms a one-shot, PER-HOST-THREAD event pair; (2) kernel
  *     selection reads a few XFMR_* environment variables (tuning / A-B switches listed in DESIGN.md section 5; most
- *     are read once per process, XFMR_LN_UNFUSED and XFMR_LOSS_NSPLIT per call) -- every setting computes the same
- *     function to rounding, none is needed in production.
+ *     are read once per process, XFMR_LN_UNFUSED, XFMR_FFN_*UNFUSED, XFMR_DW_SIDE and XFMR_LOSS_NSPLIT per call) -- every
+ *     setting computes the same function to rounding, none is needed in production; (3) xfmr_encoder_bwd keeps ONE
+ *     lowest-priority side stream and two events PER HOST THREAD (created at the first call that uses them, alive until
+ *     the thread ends) for its weight-gradient GEMMs; it joins that stream into the caller's before it returns its last
+ *     launches, so the caller still sees one stream's ordering.
  *   - the data-parallel gradient exchange (SURVEY.md section 8b lists an `allreduce_flat` op) is deliberately NOT an
  *     entry point here: the flat gradient is one contiguous device buffer, and torch.distributed's all_reduce over
  *     RCCL (xfmr_rec_amd/distributed.py) is the exchange -- there is no kernel of ours in it to export.
