@@ -406,9 +406,17 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   // XFMR_DW_SIDE=0: everything on `st`.
   static thread_local hipStream_t side = nullptr;
   static thread_local hipEvent_t ev_in = nullptr, ev_done = nullptr;
+  static thread_local int side_device = -1;
   const bool dw_side = fuse_lnb && dw_side_shape(cfg, T) && [] { const char* e = getenv("XFMR_DW_SIDE"); return !(e && *e == '0'); }();
+  int cur_device = -1;
+  if (dw_side && hipGetDevice(&cur_device) != hipSuccess) return XFMR_EHIP;
+  if (dw_side && side && side_device != cur_device) {  // this host thread moved to another device: its own stream there
+    (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_in); (void)hipEventDestroy(ev_done);
+    side = nullptr;
+  }
   if (dw_side && !side) {
     int lo = 0, hi = 0;
+    side_device = cur_device;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
         hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess ||
         hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
