@@ -183,16 +183,18 @@ class RecommenderLightningModule(_Base):
             # with sync_logging() before reading them (Trainer.fit_step / bench.py do, after optimizer.step()).
             main = torch.cuda.current_stream()
             side = self._side_stream()
-            train_loss, _l, stats_t = ops.SampledLossFunction.apply(
-                tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts | {"all_heads": False}
-            )
+            # enqueued BEFORE the gradient pass: it needs the forward's output only, and at its lowest priority it takes
+            # what the gradient pass (800 workgroups on 512 slots: 1.56 rounds) leaves idle, then the encoder backward's gaps
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                # all_heads=2: every head except the train head (its value comes from the launch above)
+                # all_heads=2: every head except the train head (its value comes from the launch below)
                 losses, stats, _ = ops.sampled_loss(
                     tok.detach(), key_mask, pos, neg, m.embeddings, m.table_rnorm, need_grad=False,
                     **(opts | {"all_heads": 2})
                 )
+            train_loss, _l, stats_t = ops.SampledLossFunction.apply(
+                tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts | {"all_heads": False}
+            )
             for tns in (tok, key_mask, pos, neg):
                 if tns is not None:
                     tns.record_stream(side)
