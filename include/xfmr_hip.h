@@ -211,6 +211,10 @@ int xfmr_attn_bwd_mode(const float* qkv, const uint8_t* key_mask, const float* c
  * bwd overwrites `grads` (it does not accumulate) from d_tok (B*L,H); d_tok is clobbered.
  * ---------------------------------------------------------------------------------------------- */
 size_t xfmr_encoder_workspace_bytes(const xfmr_encoder_cfg* cfg);
+/* One-shot, per host thread (like xfmr_sampled_loss_profile_*): the next xfmr_encoder_fwd of THIS thread records `event`
+ * (a hipEvent_t) on its stream right after the launch that writes key_mask -- work that needs only the mask
+ * (xfmr_sampled_loss_prepare) can then run on another stream underneath the rest of the forward. NULL cancels. */
+int xfmr_encoder_fwd_mark_embed(void* event);
 int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int64_t* item_idx,
                      const float* table, int64_t n_rows, float* tok, uint8_t* key_mask, void* acts,
                      size_t acts_bytes, void* stream);
@@ -327,6 +331,18 @@ int xfmr_dense_loss(const xfmr_loss_cfg* cfg, const float* query, const float* c
 int xfmr_dense_loss_grads(const xfmr_loss_cfg* cfg, const float* query, const float* cand, const int64_t* target,
                           int32_t target_mode, int64_t N, int32_t C, int32_t H, float* losses, float* stats,
                           float* d_query, float* d_cand, void* workspace, size_t workspace_bytes, void* stream);
+/* xfmr_sampled_loss in two halves. _prepare: everything that depends only on the key mask and the index tensors (the
+ * compacted query list, multiplicities and the distinct-item list of the shared negatives) -- 7 small launches that a
+ * caller can enqueue as soon as the key mask exists (xfmr_encoder_fwd_mark_embed), on another stream, instead of between
+ * the encoder forward and the loss kernels. _prepared: the rest, on a workspace _prepare filled for the same cfg, key
+ * mask, index tensors and sizes. xfmr_sampled_loss == _prepare followed by _prepared on one stream. */
+int xfmr_sampled_loss_prepare(const xfmr_loss_cfg* cfg, const uint8_t* key_mask, const int64_t* pos_idx,
+                              const int64_t* neg_idx, const float* table_rnorm, int64_t n_rows, int64_t positions,
+                              int32_t H, void* workspace, size_t workspace_bytes, void* stream);
+int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
+                               const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
+                               int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* Measurement hook (bench.py) -- the ONE piece of per-host-thread state in the library: the next
  * xfmr_sampled_loss[_lists] call made by THIS host thread records the two hipEvent_t (passed as void*) on its stream
  * immediately before and after one main-kernel launch, then forgets them. Pass NULL, NULL to cancel. No effect on

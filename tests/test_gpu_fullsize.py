@@ -299,3 +299,26 @@ def test_weight_gradient_gemms_on_the_side_stream_give_the_same_bits(ops, B, nL)
     for _ in range(6):
         assert torch.equal(run(), one_stream)
 
+
+@pytest.mark.parametrize("head,heads", [("InfoNCELoss", True), ("PairwiseLogisticLoss", 2), ("AlignmentContrastiveLoss", False)])
+def test_loss_in_two_halves_equals_the_single_call(ops, head, heads):
+    """xfmr_sampled_loss_prepare (query compaction, multiplicities, distinct negatives: needs the key mask and the index
+    tensors only) on ANOTHER stream, then xfmr_sampled_loss_prepared on the main stream, against the single
+    xfmr_sampled_loss call: the same launches on the same data -- losses, statistics and gradient equal bit for bit. This is
+    how the training step runs the index-only half underneath the encoder forward (trainer.py: compute_losses)."""
+    B, L, H, V, table, tok, mask, pos, neg = _config2_inputs()
+    rn, tb = ops.table_prepare(table)
+    kw = dict(train_head=head, all_heads=heads, precision="bf16", table_bf16=tb)
+    need = heads != 2
+    l0, s0, d0 = ops.sampled_loss(tok, mask, pos, neg, table, rn, need_grad=need, **kw)
+    ws = ops.sampled_loss_workspace(tok, tok.shape[0], H, table.shape[0], **kw)
+    side, ev = torch.cuda.Stream(), torch.cuda.Event()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.sampled_loss_prepare(ws, mask, pos, neg, rn, table.shape[0], H, **kw)
+        ev.record(side)
+    torch.cuda.current_stream().wait_event(ev)
+    l1, s1, d1 = ops.sampled_loss(tok, mask, pos, neg, table, rn, need_grad=need, workspace=ws, prepared=True, **kw)
+    assert torch.equal(l0, l1) and torch.equal(s0, s1)
+    assert (d0 is None and d1 is None) or torch.equal(d0, d1)
+

@@ -277,6 +277,12 @@ size_t xfmr_encoder_workspace_bytes(const xfmr_encoder_cfg* cfg) {
   return carve(cfg, nullptr, -1, nullptr).total;
 }
 
+namespace { thread_local hipEvent_t g_embed_event = nullptr; }
+int xfmr_encoder_fwd_mark_embed(void* event) {
+  g_embed_event = (hipEvent_t)event;
+  return XFMR_OK;
+}
+
 int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int64_t* item_idx,
                      const float* table, int64_t n_rows, float* tok, uint8_t* key_mask, void* acts,
                      size_t acts_bytes, void* stream) {
@@ -297,6 +303,10 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
   XF_TRY(xf_embed_ln_fwd_ex(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
                             params + pl.eb, a.x0, mix ? a.x0b : nullptr, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask, B,
                             L, H, cfg->ln_eps, cfg->hidden_dropout, cfg->seed, SITE_EMB, st));
+  if (hipEvent_t ev = g_embed_event) {  // (one-shot) key_mask is written: see xfmr_encoder_fwd_mark_embed
+    g_embed_event = nullptr;
+    if (hipEventRecord(ev, st) != hipSuccess) return XFMR_EHIP;
+  }
   const float* x = a.x0;
   const void* xg = mix ? a.x0b : (const void*)a.x0;  // the same activations as the GEMM operand
   const uint32_t sA = mix ? XF_S16_A : 0;

@@ -1022,14 +1022,16 @@ static int check_loss_args(const xfmr_loss_cfg* cfg, const float* tok, const flo
   return XFMR_OK;
 }
 
-int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
-                      const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
-                      int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
-                      size_t workspace_bytes, void* stream) {
-  if (int rc = check_loss_args(cfg, tok, table, table_rnorm, losses, stats, workspace, d_tok, positions, n_rows))
-    return rc;
-  if (!key_mask || !pos_idx) return XFMR_EINVAL;
+// The part of xfmr_sampled_loss that depends only on the key mask and the index tensors (not on the token embeddings): the
+// compacted query list, the multiplicity histogram of the shared negatives and their distinct-item list, in `workspace`.
+int xfmr_sampled_loss_prepare(const xfmr_loss_cfg* cfg, const uint8_t* key_mask, const int64_t* pos_idx,
+                              const int64_t* neg_idx, const float* table_rnorm, int64_t n_rows, int64_t positions,
+                              int32_t H, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!cfg || !key_mask || !pos_idx || !table_rnorm || !workspace) return XFMR_EINVAL;
+  if (positions <= 0 || n_rows <= 0 || positions > (1 << 30) || n_rows > (1 << 30) || cfg->num_hard_negatives < 0)
+    return XFMR_EINVAL;
   if (cfg->mode == XFMR_NEG_SHARED && !neg_idx) return XFMR_EINVAL;
+  if (!xf_aligned16(workspace)) return XFMR_EALIGN;
   const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0);
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -1049,9 +1051,38 @@ int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t*
   if (shared) {
     if (int rc = launch_distinct(ws, p, n_rows, table_rnorm, st)) return rc;
   }
+  return XFMR_OK;
+}
+
+// ... and the rest, on a workspace xfmr_sampled_loss_prepare filled for the SAME cfg / key mask / index tensors / sizes.
+int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
+                               const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
+                               int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_loss_args(cfg, tok, table, table_rnorm, losses, stats, workspace, d_tok, positions, n_rows))
+    return rc;
+  if (!key_mask || !pos_idx) return XFMR_EINVAL;
+  if (cfg->mode == XFMR_NEG_SHARED && !neg_idx) return XFMR_EINVAL;
+  const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0);
+  if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
   if (d_tok && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
-  return run_loss(cfg, tok, table, table_rnorm, table_bf16, n_rows, T, H, losses, stats, d_tok, ws, p, st);
+  return run_loss(cfg, tok, table, table_rnorm, table_bf16, n_rows, (int)positions, H, losses, stats, d_tok,
+                  (unsigned char*)workspace, p, st);
+}
+
+int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
+                      const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
+                      int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (int rc = check_loss_args(cfg, tok, table, table_rnorm, losses, stats, workspace, d_tok, positions, n_rows))
+    return rc;
+  if (int rc = xfmr_sampled_loss_prepare(cfg, key_mask, pos_idx, neg_idx, table_rnorm, n_rows, positions, H, workspace,
+                                         workspace_bytes, stream))
+    return rc;
+  return xfmr_sampled_loss_prepared(cfg, tok, key_mask, pos_idx, neg_idx, table, table_rnorm, table_bf16, n_rows, positions,
+                                    H, losses, stats, d_tok, workspace, workspace_bytes, stream);
 }
 
 size_t xfmr_sampled_loss_lists_workspace(int64_t n_query, int64_t n_neg, int32_t H, int64_t n_rows) {

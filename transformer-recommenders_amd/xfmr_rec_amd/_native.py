@@ -65,6 +65,7 @@ _SIGNATURES = {
     "xfmr_strerror": (C.c_char_p, [C.c_int]),
     "xfmr_abi_version": (C.c_int, []),
     "xfmr_low_priority_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "xfmr_encoder_fwd_mark_embed": (C.c_int, [_P]),
     "xfmr_stream_destroy": (C.c_int, [_P]),
     "xfmr_param_count": (C.c_int64, [C.POINTER(EncoderCfg)]),
     "xfmr_param_offsets": (C.c_int32, [C.POINTER(EncoderCfg), C.POINTER(C.c_int64), C.c_int32]),
@@ -101,6 +102,10 @@ _SIGNATURES = {
     "xfmr_sampled_loss_workspace_cfg": (C.c_size_t, [C.POINTER(LossCfg), C.c_int64, C.c_int32, C.c_int64]),
     "xfmr_sampled_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32,
                                     _P, _P, _P, _P, C.c_size_t, _P]),
+    "xfmr_sampled_loss_prepare": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P,
+                                            C.c_size_t, _P]),
+    "xfmr_sampled_loss_prepared": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64,
+                                             C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
     "xfmr_sampled_loss_lists_workspace": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int64]),
     "xfmr_sampled_loss_lists_workspace_cfg": (C.c_size_t, [C.POINTER(LossCfg), C.c_int64, C.c_int64, C.c_int32,
                                                            C.c_int64]),

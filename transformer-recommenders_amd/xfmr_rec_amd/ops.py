@@ -231,10 +231,32 @@ def adamw_(params, grads, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, ep
     )
 
 
+def sampled_loss_workspace(like, T, H, n_rows, *, train_head, all_heads=True, mask_false_negatives=True, mode=N.NEG_SHARED,
+                           scale=1.0, margin=0.5, precision="bf16", num_hard_negatives=0, **_):
+    """An (unprepared) workspace for sampled_loss(..., workspace=...) on `like`'s device."""
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives)
+    return _bytes(N.load().xfmr_sampled_loss_workspace_cfg(C.byref(cfg), T, H, n_rows), like)
+
+
+def sampled_loss_prepare(ws, key_mask, pos_idx, neg_idx, rnorm, n_rows, H, *, train_head, all_heads=True,
+                         mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
+                         num_hard_negatives=0, **_):
+    """The index-only half of the loss (query compaction, multiplicities, distinct negatives) into `ws`, on the
+    current stream: needs the key mask, not the token embeddings. Follow with sampled_loss(..., workspace=ws,
+    prepared=True) with the same options."""
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives)
+    N.check(
+        N.load().xfmr_sampled_loss_prepare(C.byref(cfg), N.ptr(key_mask), N.ptr(pos_idx), N.ptr(neg_idx), N.ptr(rnorm),
+                                           n_rows, key_mask.numel(), H, N.ptr(ws), ws.numel(), N.stream()),
+        "xfmr_sampled_loss_prepare",
+    )
+
+
 def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, all_heads=True,
                  mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
-                 need_grad=True, table_bf16=None, num_hard_negatives=0):
-    """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H)."""
+                 need_grad=True, table_bf16=None, num_hard_negatives=0, workspace=None, prepared=False):
+    """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H). `workspace` (sampled_loss_workspace) +
+    `prepared=True`: sampled_loss_prepare already ran on it."""
     H = tok.shape[-1]
     T = tok.numel() // H
     lib = N.load()
@@ -243,14 +265,17 @@ def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, a
     losses = _empty((2 * N.NUM_LOSSES,), tok)
     stats = _empty((N.NUM_STATS,), tok)
     d_tok = torch.empty_like(tok) if need_grad else None
-    nbytes = lib.xfmr_sampled_loss_workspace_cfg(C.byref(cfg), T, H, n_rows)
-    ws = _bytes(nbytes, tok)
+    if workspace is None:
+        assert not prepared
+        nbytes = lib.xfmr_sampled_loss_workspace_cfg(C.byref(cfg), T, H, n_rows)
+        ws = _bytes(nbytes, tok)
+    else:
+        ws, nbytes = workspace, workspace.numel()
+    fn = lib.xfmr_sampled_loss_prepared if prepared else lib.xfmr_sampled_loss
     N.check(
-        lib.xfmr_sampled_loss(C.byref(cfg), N.ptr(tok), N.ptr(key_mask), N.ptr(pos_idx), N.ptr(neg_idx),
-                              N.ptr(table), N.ptr(rnorm), N.ptr(table_bf16), n_rows, T, H, N.ptr(losses),
-                              N.ptr(stats), N.ptr(d_tok),
-                              N.ptr(ws), nbytes, N.stream()),
-        "xfmr_sampled_loss",
+        fn(C.byref(cfg), N.ptr(tok), N.ptr(key_mask), N.ptr(pos_idx), N.ptr(neg_idx), N.ptr(table), N.ptr(rnorm),
+           N.ptr(table_bf16), n_rows, T, H, N.ptr(losses), N.ptr(stats), N.ptr(d_tok), N.ptr(ws), nbytes, N.stream()),
+        "xfmr_sampled_loss_prepared" if prepared else "xfmr_sampled_loss",
     )
     return losses, stats, d_tok
 

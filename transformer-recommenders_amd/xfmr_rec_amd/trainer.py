@@ -163,26 +163,47 @@ class RecommenderLightningModule(_Base):
                              "target_position=None (losses.py:233-238)")
         dev = m.device
         hist = batch["history_item_idx"]
-        tok, key_mask = m._encode_tokens(hist)
-        if m.config.is_normalized:  # models.py:393-394: the queries are the L2-normalised token embeddings
-            tok = ops.l2_normalize(tok)
-        L = tok.shape[1]
+        L = min(hist.shape[1], m.max_seq_length)  # what _encode_tokens keeps of the history
         pos = batch["pos_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
         neg = None if catalogue else batch["neg_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
         opts = dict(train_head=c.train_loss, all_heads=c.log_all_losses, mask_false_negatives=c.mask_false_negatives,
                     mode=N.NEG_CATALOG if catalogue else N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision,
                     table_bf16=m.table_bf16, num_hard_negatives=c.num_hard_negatives)
-        overlap = (defer_logging and c.log_all_losses and tok.requires_grad and torch.is_grad_enabled()
+        overlap = (defer_logging and c.log_all_losses and m.flat.requires_grad and torch.is_grad_enabled()
                    and m.table_bf16 is not None and c.precision == "bf16" and c.num_hard_negatives == 0
                    # unmasked InfoNCE: ONE call runs the logging pass first and pins the gradient pass's running
                    # maximum from its records (lean epilogue) -- worth more than the overlap
                    and not (c.train_loss == "InfoNCELoss" and not c.mask_false_negatives))
+        prep = None
+        if overlap:
+            # The index-only half of both loss calls (query compaction, multiplicities, distinct negatives: 7 small launches
+            # each) needs the key mask, not the token embeddings: it runs on the side stream underneath the forward, behind an
+            # event the encoder forward records right after the launch that writes the mask -- instead of 40 us of small
+            # launches between the forward's last kernel and the loss kernels.
+            H, n_rows, T = m.config.hidden_size, m.embeddings.shape[0], hist.shape[0] * L
+            if getattr(self, "_ev_embed", None) is None:
+                self._ev_embed, self._ev_prep = torch.cuda.Event(), torch.cuda.Event()
+                self._ev_embed.record()  # (creates the handle)
+            ws_log = ops.sampled_loss_workspace(m.flat, T, H, n_rows, **opts)
+            ws_grad = ops.sampled_loss_workspace(m.flat, T, H, n_rows, **opts)
+            N.check(N.load().xfmr_encoder_fwd_mark_embed(self._ev_embed.cuda_event), "xfmr_encoder_fwd_mark_embed")
+            prep = (ws_log, ws_grad, H, n_rows)
+        tok, key_mask = m._encode_tokens(hist)
+        if m.config.is_normalized:  # models.py:393-394: the queries are the L2-normalised token embeddings
+            tok = ops.l2_normalize(tok)
+        assert tok.shape[1] == L
         if overlap:
             # The six logging heads + statistics do not feed the gradient: evaluate them on a side stream so the
             # (VALU-bound) logging pass runs underneath the (latency-bound) encoder backward. The caller joins
             # with sync_logging() before reading them (Trainer.fit_step / bench.py do, after optimizer.step()).
             main = torch.cuda.current_stream()
             side = self._side_stream()
+            ws_log, ws_grad, H, n_rows = prep
+            side.wait_event(self._ev_embed)  # the key mask exists (the forward is still running)
+            with torch.cuda.stream(side):
+                for ws, heads in ((ws_log, 2), (ws_grad, False)):
+                    ops.sampled_loss_prepare(ws, key_mask, pos, neg, m.table_rnorm, n_rows, H, **(opts | {"all_heads": heads}))
+                self._ev_prep.record(side)
             # enqueued BEFORE the gradient pass: it needs the forward's output only, and at its lowest priority it takes
             # what the gradient pass (800 workgroups on 512 slots: 1.56 rounds) leaves idle, then the encoder backward's gaps
             side.wait_stream(main)
@@ -190,11 +211,15 @@ class RecommenderLightningModule(_Base):
                 # all_heads=2: every head except the train head (its value comes from the launch below)
                 losses, stats, _ = ops.sampled_loss(
                     tok.detach(), key_mask, pos, neg, m.embeddings, m.table_rnorm, need_grad=False,
-                    **(opts | {"all_heads": 2})
+                    **(opts | {"all_heads": 2, "workspace": ws_log, "prepared": True})
                 )
+            main.wait_event(self._ev_prep)  # (recorded long ago)
             train_loss, _l, stats_t = ops.SampledLossFunction.apply(
-                tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts | {"all_heads": False}
+                tok, key_mask, pos, neg, m.embeddings, m.table_rnorm,
+                opts | {"all_heads": False, "workspace": ws_grad, "prepared": True}
             )
+            for tns in (ws_log, ws_grad):
+                tns.record_stream(side)
             for tns in (tok, key_mask, pos, neg):
                 if tns is not None:
                     tns.record_stream(side)
