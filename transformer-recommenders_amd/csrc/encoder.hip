@@ -550,12 +550,14 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   // The kernels do overlap, and each slows down by what the overlap would have gained: 1.910 vs 1.904 ms/step.)
   // (Measured and not kept: reducing each layer's slabs and records on the side stream as soon as they are enqueued, so that
   // only layer 0's are left for the end: 3.41 vs 3.34 ms/step -- the low-priority reductions slow the chain's tail.)
+  // the position / type embedding gradients need only the chain's last output: in front of the join, underneath whatever
+  // the side stream still has to do
+  XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
   if (side_used) {  // the chain joins the side stream: the reduction launch reads every slab
     if (hipEventRecord(ev_done, side) != hipSuccess || hipStreamWaitEvent(st, ev_done, 0) != hipSuccess) side_rc = XFMR_EHIP;
   }
   if (side_rc != XFMR_OK) return side_rc;
   XF_TRY(xf_multi_rowsum(segs, nseg, st));  // every weight / bias / LayerNorm gradient of the encoder, one launch
-  XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
   return XFMR_OK;
 }
 
