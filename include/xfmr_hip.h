@@ -343,6 +343,9 @@ int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const
                                const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
                                int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* One-shot, per host thread: the next xfmr_sampled_loss_prepared call of THIS thread does not zero d_tok (rows that are
+ * not queries must read 0): the caller did, e.g. on another stream underneath the encoder forward (52 MB at T = 102 400). */
+int xfmr_sampled_loss_dtok_is_zeroed(void);
 /* Measurement hook (bench.py) -- the ONE piece of per-host-thread state in the library: the next
  * xfmr_sampled_loss[_lists] call made by THIS host thread records the two hipEvent_t (passed as void*) on its stream
  * immediately before and after one main-kernel launch, then forgets them. Pass NULL, NULL to cancel. No effect on

@@ -1054,6 +1054,7 @@ int xfmr_sampled_loss_prepare(const xfmr_loss_cfg* cfg, const uint8_t* key_mask,
   return XFMR_OK;
 }
 
+static thread_local bool g_dtok_zeroed = false;
 // ... and the rest, on a workspace xfmr_sampled_loss_prepare filled for the SAME cfg / key mask / index tensors / sizes.
 int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
                                const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
@@ -1066,10 +1067,17 @@ int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const
   const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0);
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  if (d_tok && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
+  const bool zeroed = g_dtok_zeroed;  // (one-shot) the caller zeroed d_tok itself: xfmr_sampled_loss_dtok_is_zeroed
+  g_dtok_zeroed = false;
+  if (d_tok && !zeroed && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
   return run_loss(cfg, tok, table, table_rnorm, table_bf16, n_rows, (int)positions, H, losses, stats, d_tok,
                   (unsigned char*)workspace, p, st);
+}
+
+int xfmr_sampled_loss_dtok_is_zeroed(void) {
+  g_dtok_zeroed = true;
+  return XFMR_OK;
 }
 
 int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,

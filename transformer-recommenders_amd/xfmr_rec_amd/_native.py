@@ -102,6 +102,7 @@ _SIGNATURES = {
     "xfmr_sampled_loss_workspace_cfg": (C.c_size_t, [C.POINTER(LossCfg), C.c_int64, C.c_int32, C.c_int64]),
     "xfmr_sampled_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32,
                                     _P, _P, _P, _P, C.c_size_t, _P]),
+    "xfmr_sampled_loss_dtok_is_zeroed": (C.c_int, []),
     "xfmr_sampled_loss_prepare": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P,
                                             C.c_size_t, _P]),
     "xfmr_sampled_loss_prepared": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64,

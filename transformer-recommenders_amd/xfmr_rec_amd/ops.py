@@ -254,9 +254,10 @@ def sampled_loss_prepare(ws, key_mask, pos_idx, neg_idx, rnorm, n_rows, H, *, tr
 
 def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, all_heads=True,
                  mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
-                 need_grad=True, table_bf16=None, num_hard_negatives=0, workspace=None, prepared=False):
+                 need_grad=True, table_bf16=None, num_hard_negatives=0, workspace=None, prepared=False, d_tok_zeroed=None):
     """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H). `workspace` (sampled_loss_workspace) +
-    `prepared=True`: sampled_loss_prepare already ran on it."""
+    `prepared=True`: sampled_loss_prepare already ran on it; `d_tok_zeroed`: a zero-filled buffer like tok to take the
+    gradient (the call then skips its own memset)."""
     H = tok.shape[-1]
     T = tok.numel() // H
     lib = N.load()
@@ -264,7 +265,10 @@ def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, a
     n_rows = table.shape[0]
     losses = _empty((2 * N.NUM_LOSSES,), tok)
     stats = _empty((N.NUM_STATS,), tok)
-    d_tok = torch.empty_like(tok) if need_grad else None
+    d_tok = (d_tok_zeroed if d_tok_zeroed is not None else torch.empty_like(tok)) if need_grad else None
+    if d_tok_zeroed is not None and need_grad:
+        assert prepared and d_tok.shape == tok.shape and d_tok.dtype == tok.dtype
+        N.check(lib.xfmr_sampled_loss_dtok_is_zeroed(), "xfmr_sampled_loss_dtok_is_zeroed")
     if workspace is None:
         assert not prepared
         nbytes = lib.xfmr_sampled_loss_workspace_cfg(C.byref(cfg), T, H, n_rows)

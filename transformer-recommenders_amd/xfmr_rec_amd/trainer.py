@@ -203,6 +203,7 @@ class RecommenderLightningModule(_Base):
             with torch.cuda.stream(side):
                 for ws, heads in ((ws_log, 2), (ws_grad, False)):
                     ops.sampled_loss_prepare(ws, key_mask, pos, neg, m.table_rnorm, n_rows, H, **(opts | {"all_heads": heads}))
+                d_tok0 = torch.zeros_like(tok)  # the gradient buffer, zeroed here instead of in front of the gradient pass
                 self._ev_prep.record(side)
             # enqueued BEFORE the gradient pass: it needs the forward's output only, and at its lowest priority it takes
             # what the gradient pass (800 workgroups on 512 slots: 1.56 rounds) leaves idle, then the encoder backward's gaps
@@ -216,10 +217,11 @@ class RecommenderLightningModule(_Base):
             main.wait_event(self._ev_prep)  # (recorded long ago)
             train_loss, _l, stats_t = ops.SampledLossFunction.apply(
                 tok, key_mask, pos, neg, m.embeddings, m.table_rnorm,
-                opts | {"all_heads": False, "workspace": ws_grad, "prepared": True}
+                opts | {"all_heads": False, "workspace": ws_grad, "prepared": True, "d_tok_zeroed": d_tok0}
             )
             for tns in (ws_log, ws_grad):
                 tns.record_stream(side)
+            d_tok0.record_stream(main)  # allocated on the side stream, used on the main one
             for tns in (tok, key_mask, pos, neg):
                 if tns is not None:
                     tns.record_stream(side)
