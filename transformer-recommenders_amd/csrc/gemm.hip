@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "internal.h"
@@ -1575,8 +1576,13 @@ int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st) {
     MultiSegs m{};
     const int n = nseg - base < 64 ? nseg - base : 64;
     int blocks = 0;
+    // tall segments first: a block's lifetime grows with its segment's rows (the LayerNorm records: 1600 rows, 6 round
+    // trips; a weight slab: 62-115 rows, one) and the blocks dispatched last set the launch's end
+    int order[64];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order, order + n, [&](int x, int y) { return segs[base + x].rows > segs[base + y].rows; });
     for (int i = 0; i < n; ++i) {
-      m.s[i] = segs[base + i];
+      m.s[i] = segs[base + order[i]];
       m.first[i] = blocks;
       blocks += m.s[i].cols > 0 ? (m.s[i].cols + 63) / 64 : 0;
     }
