@@ -72,6 +72,9 @@ def parse(argv=None):
                     help="logging heads on a side stream under the encoder backward: pays off once the logging pass is "
                          "long enough (B*L >= 102400: +0.6 %% at B=512, -1.4 %% at B=256, -2 %% at B=128); auto decides by that")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)  # former default switch; no effect
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step as one hipGraph (GraphedStep): auto = when the eager step would be bound by the "
+                         "host's launch rate (B*L <= 32768 tokens, one process)")
     ap.add_argument("--heads", type=int, default=0, help="attention heads (default hidden/32: head size 32)")
     ap.add_argument("--negatives", default="in_batch", choices=["in_batch", "catalogue"],
                     help="catalogue = full-catalogue softmax (BASELINE config 4; SURVEY F9)")
@@ -173,15 +176,18 @@ def unit_table(V, H, seed=1234):
 
 
 class HipEvents:
-    """hipEvent pairs created through the HIP runtime torch already loaded (same soname)."""
+    """Timing hipEvent pairs, created once through the library (xfmr_event_create)."""
 
     def __init__(self, n):
-        self.hip = ctypes.CDLL("libamdhip64.so.7")  # soname: resolves to the HIP runtime torch already loaded
+        from xfmr_rec_amd import _native as N
+
+        self.lib = N.load()
         self.pairs = []
         for _ in range(n):
             a, b = ctypes.c_void_p(), ctypes.c_void_p()
-            assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
-            self.pairs.append((a, b))
+            N.check(self.lib.xfmr_event_create(ctypes.byref(a), 1), "xfmr_event_create")
+            N.check(self.lib.xfmr_event_create(ctypes.byref(b), 1), "xfmr_event_create")
+            self.pairs.append((a.value, b.value))
 
     def elapsed_ms(self, idx=None):
         out = []
@@ -189,7 +195,7 @@ class HipEvents:
             if idx is not None and i not in idx:
                 continue
             ms = ctypes.c_float()
-            if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0:
+            if self.lib.xfmr_event_elapsed_ms(a, b, ctypes.byref(ms)) == 0:
                 out.append(ms.value)
         return out
 
@@ -333,40 +339,44 @@ def main():
 
     overlap = args.overlap == "on" or (args.overlap == "auto" and B * L >= 102400)
 
-    copy_stream = torch.cuda.Stream(device=dev)
-    staged = {}
+    # Host -> HBM hand-over inside the step ("H2D of the 3 index tensors -> ..."): persistent device slots,
+    # pre-created events, one hipMemcpyAsync per batch on a copy stream, the copy of batch i + 1 underneath step i -- the
+    # product's PinnedBatchRing (xfmr_rec_amd/data.py), what Trainer.fit feeds its steps from.
+    from xfmr_rec_amd.data import PinnedBatchRing
 
-    def upload(i):
-        """Batch i: three (B, L) int64 tensors from pinned host memory -> HBM on the copy stream (what a DataLoader with
-        pin_memory hands over; the copy of batch i + 1 runs under step i, as Lightning's prefetching does)."""
-        with torch.cuda.stream(copy_stream):
-            blk = host_batches[i % n_batches].to(dev, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(copy_stream)
-        staged[i] = (blk, done)
+    ring = PinnedBatchRing(dev, B, L)
 
-    def step(i, from_host=False, in_line=False):
-        if from_host:
-            if i not in staged:
-                upload(i)
-            blk, done = staged.pop(i)
-            torch.cuda.current_stream().wait_event(done)
-            blk.record_stream(torch.cuda.current_stream())
-            batch = dict(zip(KEYS, blk.unbind(0)))
-            upload(i + 1)  # in flight while this step computes
+    use_graph = world == 1 and (args.graph == "on" or (args.graph == "auto" and B * L <= 32768))
+    gstep = None
+    if use_graph:
+        mod.defer_logging = bool(overlap)
+        gstep = X.GraphedStep(trainer, batches[0])
+
+    def step(i, from_host=False, in_line=False, profile=None):
+        """zero_grad -> training_step -> backward -> [all-reduce] -> optimizer.step -> on_train_batch_end: the module's
+        Lightning seam in Lightning's order (= Trainer.fit_step)."""
+        if from_host == "inline":  # Lightning's plain batch transfer: three copies on the compute stream itself
+            batch = {k: host_batches[i % n_batches][j].to(dev, non_blocking=True) for j, k in enumerate(KEYS)}
+        elif from_host:
+            if ring.pending == 0:
+                ring.stage(host_batches[i % n_batches])
+            batch = ring.take()
+            ring.stage(host_batches[(i + 1) % n_batches])  # in flight while this step computes
         else:
             batch = batches[i % n_batches]
+        if gstep is not None and not in_line and profile is None:
+            return gstep(batch), mod.last_out  # one hipGraph launch: the same step, captured (GraphedStep)
         opt = trainer.optimizer
         opt.zero_grad(set_to_none=True)
-        # metrics stay on the device (no host sync per step)
-        out = mod.compute_losses(batch, sync_metrics=False, defer_logging=overlap and not in_line)
-        loss = out[f"loss/{conf.train_loss}"]
+        mod.defer_logging = bool(overlap and not in_line)
+        mod.profile_events = profile
+        loss = mod.training_step(batch, i)
         loss.backward()
         if world > 1:
             D.allreduce_flat_grad_(mod.model.flat.grad)
         opt.step()
-        mod.sync_logging()
-        return loss, out
+        mod.on_train_batch_end(loss, batch, i)
+        return loss, mod.last_out
 
     lib = N.load()
 
@@ -377,10 +387,10 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
-            if events is not None:  # even steps time the gradient pass, odd steps the logging pass (one-shot hooks)
-                lib.xfmr_sampled_loss_profile_pass(events.pairs[i][0], events.pairs[i][1],
-                                                   N.PROFILE_LOGGING_PASS if (i & 1) else N.PROFILE_GRADIENT_PASS)
-            loss, out = step(i, from_host)
+            prof = None
+            if events is not None:  # even steps time the gradient pass, odd steps the logging pass (xfmr_loss_cfg.profile_*)
+                prof = (None, events.pairs[i]) if (i & 1) else (events.pairs[i], None)
+            loss, out = step(i, from_host, profile=prof)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -399,29 +409,34 @@ def main():
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
-    ev = HipEvents(args.steps)
-    elapsed, loss, out = timed(args.steps, ev)
-    h2d_s, _, _ = timed(args.steps, None, from_host=True)
+    ev = HipEvents(args.steps) if gstep is None else None  # (a captured step has no per-launch events: see `alone_ms`)
+    # THE timed region: batch in page-locked host memory -> H2D of the three index tensors -> gather ->
+    # encoder -> loss -> backward -> [all-reduce] -> AdamW
+    for i in range(2):
+        step(i, True)
+    elapsed, loss, out = timed(args.steps, ev, from_host=True)
+    resident_s, _, _ = timed(args.steps)  # the same steps on batches that already lie in HBM
+    inline_s, _, _ = timed(args.steps, None, from_host="inline")
     # The dominant kernel once more with nothing beside it (outside the timed region): in the timed region the logging pass
     # sits on a lowest-priority stream underneath the encoder backward, so its duration there includes the time it is held
     # back -- what a one-stream rocprofv3 trace (profiles/*_kernel_stats.md) sees is this figure.
     alone_ms, alone_grad_ms = [], []
-    if overlap and not args.lean:
+    if (overlap or gstep is not None) and not args.lean:
         ev2 = HipEvents(12)
         for i in range(12):  # even: the gradient pass, odd: the logging pass -- both on the main stream, one after the other
-            lib.xfmr_sampled_loss_profile_pass(ev2.pairs[i][0], ev2.pairs[i][1],
-                                               N.PROFILE_LOGGING_PASS if (i & 1) else N.PROFILE_GRADIENT_PASS)
-            step(i, in_line=True)
+            step(i, in_line=True, profile=(None, ev2.pairs[i]) if (i & 1) else (ev2.pairs[i], None))
         torch.cuda.synchronize()
         alone_ms = ev2.elapsed_ms({i for i in range(12) if i & 1})
         alone_grad_ms = ev2.elapsed_ms({i for i in range(12) if not (i & 1)})
-    staged.clear()
 
     stats = out["stats/device"].tolist()
     n_valid, n_query = stats[N.STAT["n_valid"]], stats[N.STAT["n_query"]]
     n_cols = stats[N.STAT["neg_distinct"]]
-    grad_ms = ev.elapsed_ms({i for i in range(args.steps) if not (i & 1)})
-    log_ms = ev.elapsed_ms({i for i in range(args.steps) if (i & 1)}) if not args.lean else []
+    if ev is not None:
+        grad_ms = ev.elapsed_ms({i for i in range(args.steps) if not (i & 1)})
+        log_ms = ev.elapsed_ms({i for i in range(args.steps) if (i & 1)}) if not args.lean else []
+    else:  # graph replay: the kernels are timed in the eager in-line steps after the timed region only
+        grad_ms, log_ms = list(alone_grad_ms), list(alone_ms)
     grad_avg = sum(grad_ms) / max(len(grad_ms), 1)
     log_avg = sum(log_ms) / max(len(log_ms), 1)
     peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -443,26 +458,28 @@ def main():
                           grad_avg, len(grad_ms))
     k_log = kernel_entry("loss_main_dma_kernel, logging pass (six logging heads + LogitsStatistics, values only; "
                          "VALU-issue-bound: profiles/)", log_flops, log_avg, len(log_ms))
-    note = ("avg_launch_ms / achieved / frac: in the timed region, where the logging pass runs on a lowest-priority stream "
-            "beside the gradient pass and underneath the encoder backward (each pass's duration includes what the other "
-            "takes from it); *_in_line: 6 further steps after the timed region with both passes on the main stream, one "
-            "after the other, nothing beside them -- the figure a one-stream rocprofv3 trace shows")
+    note = ("avg_launch_ms / achieved / frac: the kernel with nothing beside it -- 6 further steps after the timed region "
+            "with both loss passes on the main stream, one after the other: the figure a one-stream rocprofv3 trace "
+            "(profiles/*_kernel_stats.md) shows; *_overlapped: in the timed region, where the logging pass runs on a "
+            "lowest-priority stream beside the gradient pass and underneath the encoder backward (each pass's duration "
+            "then includes what the others take from it)")
     for k, ms, fl in ((k_log, alone_ms, log_flops), (k_grad, alone_grad_ms, grad_flops)):
         if ms:
             a = sum(ms) / len(ms)
             tf = fl / (a * 1e-3) / 1e12
-            k |= {"avg_launch_ms_in_line": round(a, 4), "achieved_in_line": round(tf, 2), "frac_in_line": round(tf / peak, 5),
-                  "note": note}
+            k |= {"avg_launch_ms_overlapped": k["avg_launch_ms"], "achieved_overlapped": k["achieved"],
+                  "frac_overlapped": k["frac"]}
+            k |= {"avg_launch_ms": round(a, 4), "achieved": round(tf, 2), "frac": round(tf / peak, 5), "note": note}
     # dominant = the longer kernel with nothing beside it (profiles/*_kernel_stats.md); the timed-region durations overlap
-    log_cmp = k_log.get("avg_launch_ms_in_line", log_avg)
-    grad_cmp = k_grad.get("avg_launch_ms_in_line", grad_avg)
+    log_cmp = k_log["avg_launch_ms"]
+    grad_cmp = k_grad["avg_launch_ms"]
     dominant = k_log if (log_ms and log_cmp > grad_cmp) else k_grad
     # whole step: executed flops of the encoder (fwd + bwd, valid tokens) and of the two loss passes / step time
     step_ms = elapsed / args.steps * 1e3
     enc_flops = n_valid * encoder_flops_per_token(tokens_per_seq, H, args.inter, args.layers)
     step_flops = enc_flops + grad_flops + (log_flops if log_ms else 0.0)
     step_tf = step_flops / (step_ms * 1e-3) / 1e12
-    static = static_profile("r02_bench_static.json") or {}
+    static = static_profile("r03_bench_static.json") or static_profile("r02_bench_static.json") or {}
 
     if rank == 0:
         seqs = B * world * args.steps
@@ -503,11 +520,17 @@ def main():
                 "mean_tokens_per_sequence": round(tokens_per_seq, 1),
                 "loss_heads_evaluated": "train head only" if args.lean else "all 7 + LogitsStatistics (reference training_step)",
                 "dropout": 0.0 if args.no_dropout else 0.1, "parallelism": f"dp{world}",
+                "launch": "one hipGraph replay per step (GraphedStep)" if gstep is not None else "eager launches",
                 "final_loss": round(float(loss.detach()), 4),
             },
-            "h2d_inclusive": {"value": round(seqs / h2d_s, 2), "ms_per_step": round(h2d_s / args.steps * 1e3, 4),
-                              "note": "same timed region with every step's 3 x (B, L) int64 index tensors (one pinned block) copied from "
-                                      "pinned host memory (copy stream, one batch ahead of the compute stream)"},
+            "h2d": {"included_in_value": True, "bytes_per_step": 3 * B * L * 8,
+                    "how": "page-locked (3, B, L) int64 host block -> persistent device slot, ONE hipMemcpyAsync per batch on a "
+                           "copy stream one batch ahead of the compute stream, pre-created events (PinnedBatchRing)"},
+            "resident": {"value": round(seqs / resident_s, 2), "ms_per_step": round(resident_s / args.steps * 1e3, 4),
+                         "note": "the same timed region on batches that already lie in HBM (no copy in the step)"},
+            "h2d_on_compute_stream": {"value": round(seqs / inline_s, 2), "ms_per_step": round(inline_s / args.steps * 1e3, 4),
+                                      "note": "Lightning's plain batch transfer: three .to(device, non_blocking=True) copies on "
+                                              "the compute stream itself, nothing prefetched"},
             "cold_start": {"value": round(seqs / cold_s, 2), "ms_per_step": round(cold_s / args.steps * 1e3, 4),
                            "note": f"the first {args.steps} steps after {args.warmup} warm-up steps only, before the spin-up"},
             "roofline": roofline,

@@ -10,9 +10,15 @@
  *
  * Conventions
  *   - plain pointers and sizes only; every buffer (inputs, outputs, workspace) is owned by the caller
- *     and lives in device memory of the current HIP device; nothing is allocated, freed or retained.
- *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream);
- *     no entry point synchronises, so all of them may be captured into a hipGraph.
+ *     and lives in device memory of the current HIP device; no entry point allocates, frees or retains device memory.
+ *     The only objects the library creates are the ones the caller asks for and owns: streams, events
+ *     (xfmr_stream_create / xfmr_event_create ...) and the xfmr_context object: a side stream + two events.
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream); no compute entry
+ *     point synchronises the host or creates a HIP object, so a sequence of them can be captured into a hipGraph
+ *     (stream capture follows the event fork / join onto the context's side stream). What changes from step to step
+ *     in a captured step -- the dropout stream and AdamW's step count -- is read from device memory:
+ *     xfmr_encoder_cfg.step_device, xfmr_adamw_dev, xfmr_step_advance. (xfmr_batch_upload and xfmr_event_synchronize
+ *     do wait on the host, by design; they are not part of the step's kernels.)
  *   - all floating-point tensors in HBM are fp32, row-major, contiguous unless a stride is given.
  *     `precision` selects the matrix-core arithmetic of every contraction:
  *         XFMR_PREC_F32  : v_mfma_f32_32x32x2_f32  (exact fp32 fma chain; parity mode)
@@ -23,15 +29,13 @@
  *   - item indices are int64 as the reference's batches carry them (xfmr_rec/data.py:534-540).
  *   - return value: 0 on success, a negative XFMR_E* code otherwise (never throws, never aborts).
  *     Asynchronous HIP errors surface at the caller's next synchronisation.
- *   - re-entrant: no device-side state survives a call, nothing is retained between calls; safe for one process
- *     per GPU and for several host threads on different streams. Three qualifications, none touching results:
- *     (1) the measurement hook xfmr_sampled_loss_profile_* arms a one-shot, PER-HOST-THREAD event pair; (2) kernel
- *     selection reads a few XFMR_* environment variables (tuning / A-B switches listed in DESIGN.md section 5; most
- *     are read once per process, XFMR_LN_UNFUSED, XFMR_FFN_*UNFUSED, XFMR_DW_SIDE and XFMR_LOSS_NSPLIT per call) -- every
- *     setting computes the same function to rounding, none is needed in production; (3) xfmr_encoder_bwd keeps ONE
- *     lowest-priority side stream and two events PER HOST THREAD (created at the first call that uses them, alive until
- *     the thread ends) for its weight-gradient GEMMs; it joins that stream into the caller's before it returns its last
- *     launches, so the caller still sees one stream's ordering.
+ *   - re-entrant: no device-side state survives a call and the library keeps no per-thread or global mutable state;
+ *     safe for one process per GPU and for several host threads on different streams (each with its own xfmr_context).
+ *     Everything optional about a call is an argument: an event to record, "d_tok is already zero", profiling events,
+ *     fusion switches are fields of the cfg structs (ABI 1 had one-shot per-thread hooks for them). A few XFMR_*
+ *     environment variables (tile / split tuning only, listed in DESIGN.md section 5; none changes what a forward pass
+ *     leaves for its backward) exist for experiments; every setting computes the same function to rounding, none is
+ *     needed in production.
  *   - the data-parallel gradient exchange (SURVEY.md section 8b lists an `allreduce_flat` op) is deliberately NOT an
  *     entry point here: the flat gradient is one contiguous device buffer, and torch.distributed's all_reduce over
  *     RCCL (xfmr_rec_amd/distributed.py) is the exchange -- there is no kernel of ours in it to export.
@@ -46,7 +50,7 @@
 extern "C" {
 #endif
 
-#define XFMR_ABI_VERSION 1
+#define XFMR_ABI_VERSION 2
 
 enum {
   XFMR_OK = 0,
@@ -61,8 +65,17 @@ enum { XFMR_PREC_F32 = 0, XFMR_PREC_BF16 = 1 };
 /* Self-attention mask. CAUSAL is what the reference builds (BertConfig(is_decoder=True), xfmr_rec/models.py:355);
  * BIDIRECTIONAL is BertConfig.is_decoder=False: the key-padding mask alone (TF:masking_utils.py bidirectional mask). */
 enum { XFMR_ATTN_CAUSAL = 0, XFMR_ATTN_BIDIRECTIONAL = 1 };
-/* xfmr_encoder_cfg.flags */
-enum { XFMR_ENC_BIDIRECTIONAL = 1u };
+/* xfmr_encoder_cfg.flags. The *_UNFUSED / DW_INLINE bits select the separate-launch forms of fused kernels (A/B
+ * measurements, parity of fused vs unfused forms in tests/): the forward and the backward of a step get the same cfg, so
+ * they agree on what the saved activations hold. */
+enum {
+  XFMR_ENC_BIDIRECTIONAL = 1u,
+  XFMR_ENC_LN_UNFUSED = 2u,      /* LayerNorm (and its backward) as launches of their own, not GEMM epilogues      */
+  XFMR_ENC_FFN_UNFUSED = 4u,     /* FFN forward as two GEMM launches                                               */
+  XFMR_ENC_FFN_BWD_UNFUSED = 8u, /* FFN backward dX chain as two GEMM launches                                     */
+  XFMR_ENC_DW_INLINE = 16u,      /* weight-gradient GEMMs on the caller's stream even when cfg.context is given     */
+  XFMR_ENC_FLAGS_ALL = 31u
+};
 
 /* Loss heads, in the order of the reference's LOSS_CLASSES (xfmr_rec/losses.py:546-554). */
 enum {
@@ -83,7 +96,32 @@ int xfmr_abi_version(void);
  * (xfmr_rec_amd/trainer.py), the weight-gradient GEMMs inside xfmr_encoder_bwd. The caller owns it
  * (xfmr_stream_destroy). torch only offers "normal" and "high". */
 int xfmr_low_priority_stream_create(void** stream);
+int xfmr_stream_create(void** stream); /* non-blocking, default priority (the copy stream of xfmr_batch_upload) */
 int xfmr_stream_destroy(void* stream);
+/* hipEvent_t objects (timing != 0: usable with xfmr_event_elapsed_ms). Created once by the caller and re-recorded every
+ * step: the training step creates no HIP object on its way. */
+int xfmr_event_create(void** event, int32_t timing);
+int xfmr_event_destroy(void* event);
+int xfmr_event_record(void* event, void* stream);
+int xfmr_stream_wait_event(void* stream, void* event);
+int xfmr_event_elapsed_ms(void* start_event, void* stop_event, float* ms);
+int xfmr_event_synchronize(void* event); /* blocks the HOST until the event has completed */
+int xfmr_event_query(void* event);       /* 1 = completed, 0 = not yet, < 0 = error */
+
+/* ------------------------------------------------------------------------------------------------
+ * Host -> HBM hand-over of one collated batch: what Lightning's batch transfer does with the output of the
+ * reference's pin_memory DataLoader (xfmr_rec/data.py:915-927: DataLoader(..., pin_memory=True); the SeqBatch's three
+ * (B,L) int64 index tensors, data.py:534-540, 799-805). ONE hipMemcpyAsync of `bytes` from page-locked host memory into
+ * a device slot on `copy_stream`, `ready_event` recorded behind it; the compute stream waits for that event with
+ * xfmr_stream_wait_event in front of the step that reads the slot. `slot_free_event` (recorded by the caller on the
+ * compute stream after the last kernel that read the slot; NULL = never used) guards the slot's reuse: the call waits
+ * for it ON THE HOST -- which returns at once unless the host is a whole ring of slots ahead of the GPU (bounded
+ * run-ahead). It is deliberately not a stream wait: a hipStreamWaitEvent in front of a copy makes hipMemcpyAsync itself
+ * block the host until the event has completed (measured: 0.9 ms per step at the bench shape).
+ * Nothing is allocated (xfmr_rec_amd/data.py: PinnedBatchRing keeps the slots, the copy stream and the events).
+ * ---------------------------------------------------------------------------------------------- */
+int xfmr_batch_upload(void* dst_device, const void* src_pinned, size_t bytes, void* copy_stream, void* slot_free_event,
+                      void* ready_event);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder configuration and the flat parameter layout.
@@ -114,7 +152,22 @@ typedef struct xfmr_encoder_cfg {
   float attn_dropout;    /* 0.1 in training, 0 for eval / parity                     */
   uint32_t flags;     /* XFMR_ENC_* bits; 0 = the reference's setting (causal decoder-style mask) */
   uint64_t seed;      /* dropout stream of this step; fwd and bwd must pass the same */
+  /* ---- ABI 2: everything optional about a call is an argument (all three may be NULL) ---- */
+  const uint32_t* step_device; /* device counter mixed into the dropout stream ON THE DEVICE (kernel entry): a captured
+                                  hipGraph replays the same `seed`, the counter (xfmr_step_advance) makes every replay
+                                  a new mask. Forward and backward of a step must see the same value.               */
+  void* embed_event;  /* hipEvent_t: xfmr_encoder_fwd records it on `stream` right after the launch that writes
+                         key_mask -- work that needs only the mask (xfmr_sampled_loss_prepare) can run on another
+                         stream underneath the rest of the forward. Ignored by xfmr_encoder_bwd.                    */
+  void* context;      /* an xfmr_context handle (xfmr_context_create): xfmr_encoder_bwd runs its weight-gradient GEMMs on the
+                         context's lowest-priority side stream and joins it into `stream` before its last launch;
+                         NULL = everything on `stream`.                                                            */
 } xfmr_encoder_cfg;
+
+/* A caller-owned side stream of the device's LOWEST priority plus the two events of the fork / join (created on the
+ * current device). One per host thread / stream that drives xfmr_encoder_bwd concurrently. */
+int xfmr_context_create(void** context);
+int xfmr_context_destroy(void* context);
 
 /* Number of fp32 elements of the flat parameter buffer. */
 int64_t xfmr_param_count(const xfmr_encoder_cfg* cfg);
@@ -211,10 +264,6 @@ int xfmr_attn_bwd_mode(const float* qkv, const uint8_t* key_mask, const float* c
  * bwd overwrites `grads` (it does not accumulate) from d_tok (B*L,H); d_tok is clobbered.
  * ---------------------------------------------------------------------------------------------- */
 size_t xfmr_encoder_workspace_bytes(const xfmr_encoder_cfg* cfg);
-/* One-shot, per host thread (like xfmr_sampled_loss_profile_*): the next xfmr_encoder_fwd of THIS thread records `event`
- * (a hipEvent_t) on its stream right after the launch that writes key_mask -- work that needs only the mask
- * (xfmr_sampled_loss_prepare) can then run on another stream underneath the rest of the forward. NULL cancels. */
-int xfmr_encoder_fwd_mark_embed(void* event);
 int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int64_t* item_idx,
                      const float* table, int64_t n_rows, float* tok, uint8_t* key_mask, void* acts,
                      size_t acts_bytes, void* stream);
@@ -281,6 +330,8 @@ enum {
                                   (catalogue mode), C (dense form). In-batch negatives repeat items; every per-column
                                   term is a function of the item, so it is evaluated once per distinct item and
                                   weighted by the item's multiplicity (exactly the reference's sums).             */
+  XFMR_STAT_POS_DENSITY = 13,  /* batch/positive_density  = Np / (N + 1e-9)            (trainer.py:241-249) */
+  XFMR_STAT_ATTN_DENSITY = 14, /* batch/attention_density = N / (positions + 1e-9)                           */
   XFMR_NUM_STATS = 16
 };
 typedef struct xfmr_loss_cfg {
@@ -295,7 +346,18 @@ typedef struct xfmr_loss_cfg {
   float scale;                  /* LossConfig.scale  (losses.py:29)                                 */
   float margin;                 /* LossConfig.margin (losses.py:30)                                 */
   int32_t num_hard_negatives;   /* LossConfig.num_hard_negatives (losses.py:28, :295-330); 0 = off    */
+  /* ---- ABI 2 (zero / NULL = off) ---- */
+  uint32_t flags;               /* XFMR_LOSS_* bits */
+  void* profile_grad[2];        /* hipEvent_t pair recorded on `stream` right before / after the GRADIENT-pass main
+                                   kernel of this call (or its only main kernel); measurement only (bench.py)      */
+  void* profile_log[2];         /* ... around the values-only LOGGING pass (all seven heads + statistics,
+                                   trainer.py:250-264) when this call runs one beside a gradient pass             */
 } xfmr_loss_cfg;
+enum {
+  XFMR_LOSS_DTOK_ZEROED = 1u    /* xfmr_sampled_loss_prepared: d_tok is already zero-filled (rows that are not queries
+                                   must read 0) -- the caller did it, e.g. on another stream underneath the encoder
+                                   forward (52 MB at T = 102 400) -- so the call skips its memset                  */
+};
 size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows);            /* num_hard_negatives == 0 */
 size_t xfmr_sampled_loss_workspace_cfg(const xfmr_loss_cfg* cfg, int64_t positions, int32_t H, int64_t n_rows);
 int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
@@ -333,7 +395,7 @@ int xfmr_dense_loss_grads(const xfmr_loss_cfg* cfg, const float* query, const fl
                           float* d_query, float* d_cand, void* workspace, size_t workspace_bytes, void* stream);
 /* xfmr_sampled_loss in two halves. _prepare: everything that depends only on the key mask and the index tensors (the
  * compacted query list, multiplicities and the distinct-item list of the shared negatives) -- 7 small launches that a
- * caller can enqueue as soon as the key mask exists (xfmr_encoder_fwd_mark_embed), on another stream, instead of between
+ * caller can enqueue as soon as the key mask exists (xfmr_encoder_cfg.embed_event), on another stream, instead of between
  * the encoder forward and the loss kernels. _prepared: the rest, on a workspace _prepare filled for the same cfg, key
  * mask, index tensors and sizes. xfmr_sampled_loss == _prepare followed by _prepared on one stream. */
 int xfmr_sampled_loss_prepare(const xfmr_loss_cfg* cfg, const uint8_t* key_mask, const int64_t* pos_idx,
@@ -343,18 +405,6 @@ int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const
                                const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
                                int64_t n_rows, int64_t positions, int32_t H, float* losses, float* stats, float* d_tok,
                                void* workspace, size_t workspace_bytes, void* stream);
-/* One-shot, per host thread: the next xfmr_sampled_loss_prepared call of THIS thread does not zero d_tok (rows that are
- * not queries must read 0): the caller did, e.g. on another stream underneath the encoder forward (52 MB at T = 102 400). */
-int xfmr_sampled_loss_dtok_is_zeroed(void);
-/* Measurement hook (bench.py) -- the ONE piece of per-host-thread state in the library: the next
- * xfmr_sampled_loss[_lists] call made by THIS host thread records the two hipEvent_t (passed as void*) on its stream
- * immediately before and after one main-kernel launch, then forgets them. Pass NULL, NULL to cancel. No effect on
- * results. _profile_next = _profile_pass(..., XFMR_PROFILE_GRADIENT_PASS): the gradient pass (or the call's only
- * pass). XFMR_PROFILE_LOGGING_PASS: the values-only pass over all seven heads + statistics (trainer.py:250-264) of the
- * next call that runs one (all_heads != 0 on the bf16 path); calls without one leave the request pending. */
-enum { XFMR_PROFILE_GRADIENT_PASS = 0, XFMR_PROFILE_LOGGING_PASS = 1 };
-int xfmr_sampled_loss_profile_next(void* start_event, void* stop_event);
-int xfmr_sampled_loss_profile_pass(void* start_event, void* stop_event, int32_t which);
 /* table_rnorm[r] = 1 / max(||table[r]||, 1e-8): per-item inverse norms for the cosine heads
  * (torch cosine_similarity, losses.py:206-208); computed once because the table is frozen. */
 int xfmr_table_rnorm(const float* table, float* table_rnorm, int64_t n_rows, int32_t H, void* stream);
@@ -416,6 +466,14 @@ int xfmr_retrieval_metrics(const int64_t* rec_idx, const int64_t* targets, const
 int xfmr_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                void* stream);
+
+/* The same update with the step count read from device memory: step = *step_device + step_offset (1-based, as above).
+ * With xfmr_step_advance(step_device) as the last launch of a step, a captured step replays with the right bias
+ * corrections and (xfmr_encoder_cfg.step_device = the same counter) a new dropout mask. */
+int xfmr_adamw_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, const uint32_t* step_device,
+                   int32_t step_offset, float grad_scale, void* stream);
+int xfmr_step_advance(uint32_t* step_device, void* stream); /* *step_device += 1 (one thread) */
 
 /* Elementwise helpers used by the autograd wrappers. */
 int xfmr_scale_by_device_scalar(float* x, int64_t n, const float* scalar, void* stream);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Isolated timing of the two passes of the fused sampled loss at the bench shape (nothing else on the GPU):
     python scripts/bench_logging.py [--batch 512] [--hidden 128] [--items 3883] [--reps 20]
-HIP events around the kernel through xfmr_sampled_loss_profile_pass. XFMR_HIP_LIB selects another build for A/B runs."""
+HIP events around the kernel through xfmr_loss_cfg.profile_grad / profile_log. XFMR_HIP_LIB selects another build for A/B runs."""
 import argparse
 import ctypes
 import pathlib
@@ -37,28 +37,25 @@ def main():
     mask = torch.ones(B * L, dtype=torch.uint8, device=dev)
     pos = torch.randint(1, V + 1, (B * L,), generator=g).to(dev)
     neg = torch.randint(1, V + 1, (B * L,), generator=g).to(dev)
-    hip = ctypes.CDLL("libamdhip64.so.7")
     lib = N.load()
     print("library:", N.LIB_PATH)
-    has_pass = hasattr(lib, "xfmr_sampled_loss_profile_pass")
     n_cols = int(torch.unique(neg).numel())
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    N.check(lib.xfmr_event_create(ctypes.byref(a), 1), "xfmr_event_create")
+    N.check(lib.xfmr_event_create(ctypes.byref(b), 1), "xfmr_event_create")
+    pair = (a.value, b.value)
     for name, kw, which, flops in (
-        ("gradient pass", dict(all_heads=False, need_grad=True), 0, 4.0 * B * L * n_cols * H),
-        ("logging pass, all 7 heads (-1)", dict(all_heads=True, need_grad=False), 1, 2.0 * B * L * n_cols * H),
-        ("logging pass without the InfoNCE lse (-2)", dict(all_heads=2, need_grad=False), 1, 2.0 * B * L * n_cols * H),
+        ("gradient pass", dict(all_heads=False, need_grad=True), "profile_grad", 4.0 * B * L * n_cols * H),
+        ("logging pass, all 7 heads (-1)", dict(all_heads=True, need_grad=False), "profile_log", 2.0 * B * L * n_cols * H),
+        ("logging pass without the InfoNCE lse (-2)", dict(all_heads=2, need_grad=False), "profile_log", 2.0 * B * L * n_cols * H),
     ):
         ms = []
         for _ in range(args.reps + 3):
-            a, b = ctypes.c_void_p(), ctypes.c_void_p()
-            hip.hipEventCreate(ctypes.byref(a)); hip.hipEventCreate(ctypes.byref(b))
-            if has_pass:
-                lib.xfmr_sampled_loss_profile_pass(a, b, which)
-            else:
-                lib.xfmr_sampled_loss_profile_next(a, b)
-            ops.sampled_loss(tok, mask, pos, neg, table, rn, train_head=args.head, precision="bf16", table_bf16=tb, **kw)
+            ops.sampled_loss(tok, mask, pos, neg, table, rn, train_head=args.head, precision="bf16", table_bf16=tb,
+                             **kw, **{which: pair})
             torch.cuda.synchronize()
             t = ctypes.c_float()
-            if hip.hipEventElapsedTime(ctypes.byref(t), a, b) == 0:
+            if lib.xfmr_event_elapsed_ms(pair[0], pair[1], ctypes.byref(t)) == 0:
                 ms.append(t.value)
         ms = sorted(ms[3:])
         med = ms[len(ms) // 2]

@@ -26,8 +26,8 @@ def disassemble(obj: pathlib.Path) -> str:
         subprocess.run([str(LLVM / "llvm-objdump"), "--offloading", local.name], cwd=td, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         cos = sorted(pathlib.Path(td).glob(local.name + ".*amdgcn*gfx950*"))
-        if not cos:
-            raise SystemExit(f"{obj}: no gfx950 code object found")
+        if not cos:  # a host-only translation unit (runtime.hip: streams / events / copies, no kernel)
+            return ""
         return subprocess.run([str(LLVM / "llvm-objdump"), "-d", str(cos[0])], check=True, capture_output=True,
                               text=True).stdout
 

@@ -33,7 +33,7 @@ mean = torch.empty(M, device=DEV)
 rstd = torch.empty(M, device=DEV)
 fn = lib.xf_ffn_fwd_fused_ex
 fn.restype = C.c_int
-fn.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32,
+fn.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, N.Seed, C.c_uint32,
                                   C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 5
 
 

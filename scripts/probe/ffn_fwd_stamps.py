@@ -38,7 +38,7 @@ def run(M):
     os.environ["XFMR_FFN_STAMPS"] = hex(stamps.data_ptr())
     fn = lib.xf_ffn_fwd_fused_ex
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32,
+    fn.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, N.Seed, C.c_uint32,
                                       C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 5
     for _ in range(3):
         rc = fn(N.ptr(x16), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), N.ptr(u), N.ptr(gg), N.ptr(pre), M, H, I, N.ptr(res),

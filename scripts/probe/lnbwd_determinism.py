@@ -30,7 +30,7 @@ gamma = (1 + 0.1 * torch.randn(K, generator=g)).to(DEV)
 fn = lib.xf_linear_bwd_dx_lnbwd_ex
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [
-    C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int32, C.c_uint32,
+    C.c_float, N.Seed, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int32, C.c_uint32,
     C.c_void_p, C.c_float, C.c_uint32]
 
 

@@ -83,7 +83,7 @@ def test_sampler_training_and_retrieval_learn_the_planted_next_item(train_loss):
         rows = rng.integers(0, len(ds), size=B)
         batch = ds.sample_batch(rows, seed=step)
         losses.append(float(trainer.fit_step(batch)))
-    logged = mod.logged_values(mod.logged)  # every head + statistics were evaluated on the last step, as the reference logs
+    logged = {k: float(v) for k, v in mod.logged.items()}  # every head + statistics were evaluated on the last step, as the reference logs
     assert {f"loss/{c.__name__}" for c in X.LOSS_CLASSES} <= set(logged) and "logits/neg/mean" in logged
     after = _val_ndcg(mod, val)
     chance = 20 / V  # an upper bound of nDCG@20 at random ranking (hit rate <= 20 / (V - |history|))

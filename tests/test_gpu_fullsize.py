@@ -265,10 +265,10 @@ def test_ffn_backward_dx_chain_in_one_kernel_is_bit_identical_to_the_two_gemm_fo
 
 @pytest.mark.parametrize("B,nL", [(512, 4), (330, 3)])
 def test_weight_gradient_gemms_on_the_side_stream_give_the_same_bits(ops, B, nL):
-    """At T >= 65 536 (H = 128) the encoder backward enqueues its 4 x layers weight-gradient GEMMs on a low-priority side
-    stream (they fill the last, partly empty rounds of the dX chain's 64-row-tile kernels); the gradient buffers the chain
-    reuses are doubled by layer parity and guarded by events. XFMR_DW_SIDE=0 (read per call) keeps everything on one
-    stream: the same kernels on the same data, so every gradient must be equal bit for bit -- over repeated runs (a missed
+    """At T >= 65 536 (H = 128) the encoder backward enqueues its 4 x layers weight-gradient GEMMs on the low-priority side
+    stream of the caller's xfmr_context (they fill the last, partly empty rounds of the dX chain's 64-row-tile kernels);
+    the gradient buffers the chain reuses exist once per layer in that mode. XFMR_ENC_DW_INLINE (or no context) keeps
+    everything on one stream: the same kernels on the same data, so every gradient must be equal bit for bit -- over repeated runs (a missed
     dependency would show as a run-to-run difference), with 3 and 4 layers, T a multiple of 64 and not (66 000)."""
     import os
 
@@ -277,8 +277,12 @@ def test_weight_gradient_gemms_on_the_side_stream_give_the_same_bits(ops, B, nL)
     L, H, A, V, I = 200, 128, 4, 3883, 512
     g = torch.Generator().manual_seed(9)
     table = _unit_table(V, H, 1234).to(DEV)
-    cfg = ops.make_encoder_cfg(batch=B, seq_len=L, hidden=H, heads=A, inter=I, layers=nL, max_pos=L, precision="bf16",
-                               hidden_dropout=0.1, attn_dropout=0.1, seed=23)
+    ctx = ops.Context(DEV)  # the caller-owned side stream + fork / join events (xfmr_context_create)
+    kw = dict(batch=B, seq_len=L, hidden=H, heads=A, inter=I, layers=nL, max_pos=L, precision="bf16",
+              hidden_dropout=0.1, attn_dropout=0.1, seed=23)
+    cfg = ops.make_encoder_cfg(**kw, context=ctx.handle)
+    cfg_inline = ops.make_encoder_cfg(**kw, context=ctx.handle, flags=N.ENC_DW_INLINE)
+    cfg_noctx = ops.make_encoder_cfg(**kw)
     n_params = N.load().xfmr_param_count(__import__("ctypes").byref(cfg))
     flat = (0.05 * torch.randn(n_params, generator=g)).to(DEV)
     idx = torch.randint(1, V + 1, (B, L), generator=g)
@@ -286,18 +290,17 @@ def test_weight_gradient_gemms_on_the_side_stream_give_the_same_bits(ops, B, nL)
     idx = idx.to(DEV)
     d_out = torch.randn(B, L, H, generator=g).to(DEV)
 
-    def run():
-        tok, key_mask, acts = ops.encoder_fwd(cfg, flat, idx, table)
-        return ops.encoder_bwd(cfg, flat, d_out.clone(), key_mask, acts)
+    def run(c):
+        tok, key_mask, acts = ops.encoder_fwd(c, flat, idx, table)
+        return ops.encoder_bwd(c, flat, d_out.clone(), key_mask, acts)
 
-    os.environ["XFMR_DW_SIDE"] = "0"
-    try:
-        one_stream = run()
-    finally:
-        os.environ.pop("XFMR_DW_SIDE", None)
+    one_stream = run(cfg_inline)
     assert torch.isfinite(one_stream).all() and float(one_stream.abs().max()) > 0
+    assert torch.equal(run(cfg_noctx), one_stream)  # no context: everything on the caller's stream
     for _ in range(6):
-        assert torch.equal(run(), one_stream)
+        assert torch.equal(run(cfg), one_stream)
+    torch.cuda.synchronize()
+    ctx.close()
 
 
 @pytest.mark.parametrize("head,heads", [("InfoNCELoss", True), ("PairwiseLogisticLoss", 2), ("AlignmentContrastiveLoss", False)])

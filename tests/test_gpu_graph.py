@@ -1,0 +1,96 @@
+"""The training step captured as a hipGraph (xfmr_rec_amd.trainer.GraphedStep): replay == eager, bit for bit, with dropout
+ON -- the dropout stream and AdamW's step count are read from device memory inside the captured kernels
+(xfmr_encoder_cfg.step_device, xfmr_adamw_dev, xfmr_step_advance), so every replay is a new step."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(X, train_loss="InfoNCELoss", B=8, L=24, H=64, V=200, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    table = torch.randn(V + 1, H, generator=g)
+    table = table / table.norm(dim=-1, keepdim=True)
+    table[0] = 0
+    conf = X.LightningConfig(hidden_size=H, num_attention_heads=H // 32, intermediate_size=2 * H, num_hidden_layers=2,
+                             max_seq_length=L, train_loss=train_loss)
+    mod = X.RecommenderLightningModule(conf)
+    mod.configure_model()
+    mod.model.set_table(table.to(DEV))
+    batches = []
+    for i in range(5):
+        b = {k: torch.randint(1, V + 1, (B, L), generator=g) for k in ("history_item_idx", "pos_item_idx", "neg_item_idx")}
+        n = 5 + 3 * i
+        for k in b:
+            b[k][1, n:] = 0  # one ragged row
+        batches.append({k: v.to(DEV) for k, v in b.items()})
+    return mod, batches
+
+
+@pytest.fixture(scope="module")
+def X():
+    import xfmr_rec_amd as X
+
+    return X
+
+
+@pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss"])
+def test_graph_replay_equals_eager_steps_bit_for_bit_with_dropout(X, train_loss):
+    # eager: the same device-side step counter drives dropout and AdamW
+    eager, batches = _setup(X, train_loss)
+    eager.model.use_device_step(True)
+    tr_e = X.Trainer(eager)
+    tr_e.optimizer.step_device = eager.model.step_device
+    graphed, _ = _setup(X, train_loss)
+    tr_g = X.Trainer(graphed)
+    step = X.GraphedStep(tr_g, batches[0], warmup=3)  # 3 eager warm-up steps + 1 captured step on batches[0]
+    for _ in range(4):
+        tr_e.fit_step(batches[0])
+    torch.cuda.synchronize()
+    assert int(eager.model.step_device) == int(graphed.model.step_device) == 4
+    assert torch.equal(eager.model.flat, graphed.model.flat)
+    losses_e, losses_g = [], []
+    for b in batches[1:4]:  # three more steps: eager vs replay
+        losses_e.append(tr_e.fit_step(b).clone())
+        losses_g.append(step(b).clone())
+        torch.cuda.synchronize()
+        assert torch.equal(eager.model.flat, graphed.model.flat)
+        assert torch.equal(eager.model.flat.grad, graphed.model.flat.grad)
+    assert [float(x) for x in losses_e] == [float(x) for x in losses_g]
+    # the masks did change from step to step: the same batch replayed twice gives different losses with dropout on
+    a = float(step(batches[4]).clone())
+    b = float(step(batches[4]).clone())
+    assert a != b
+    # the logged values are device tensors the replay refreshes
+    assert set(step.logged) >= {f"loss/{c.__name__}" for c in X.LOSS_CLASSES} | {"batch/positive_density", "logits/neg/mean"}
+    assert float(step.logged[f"loss/{train_loss}"]) == b
+
+
+def test_device_step_counter_changes_the_dropout_mask_and_matches_adamw_by_value(X):
+    """xfmr_adamw_dev(step read on the device) == xfmr_adamw(step by value), and the encoder forward with the same host
+    seed but another counter value draws another mask."""
+    from xfmr_rec_amd import ops
+
+    n = 4099
+    g = torch.Generator().manual_seed(1)
+    p0, gr = torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    for t in (1, 2, 7, 1000):
+        pa, ma, va = p0.clone(), torch.full((n,), 0.01, device=DEV), torch.full((n,), 0.02, device=DEV)
+        pb, mb, vb = p0.clone(), ma.clone(), va.clone()
+        ops.adamw_(pa, gr, ma, va, lr=1e-3, step=t)
+        cnt = torch.tensor([t - 1], dtype=torch.int32, device=DEV)
+        ops.adamw_(pb, gr, mb, vb, lr=1e-3, step_device=cnt)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), t
+        ops.step_advance_(cnt)
+        assert int(cnt) == t
+    mod, batches = _setup(X)
+    mod.train()
+    m = mod.model
+    m.use_device_step(True)
+    tok0, _ = m._encode_tokens(batches[0]["history_item_idx"])
+    tok0b, _ = m._encode_tokens(batches[0]["history_item_idx"])
+    assert torch.equal(tok0, tok0b)  # same counter -> same mask (the host-side step count no longer enters)
+    ops.step_advance_(m.step_device)
+    tok1, _ = m._encode_tokens(batches[0]["history_item_idx"])
+    assert not torch.equal(tok0, tok1)

@@ -424,7 +424,7 @@ def test_linear_with_layernorm_in_the_epilogue(ops, K, M, p_drop, bf16_storage):
     rstd = torch.empty(M, device=DEV)
     fn = lib.xf_linear_ln_fwd_ex
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32,
+    fn.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, N.Seed, C.c_uint32,
                                       C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 4 + [C.c_int32, C.c_uint32,
                                                                                                C.c_void_p]
     rc = fn(N.ptr(xs), N.ptr(ws), N.ptr(b), N.ptr(pre), M, Nn, K, N.ptr(res), p_drop, 5, 9, N.ptr(gamma), N.ptr(beta),
@@ -475,13 +475,13 @@ def test_ffn_forward_in_one_kernel_vs_the_two_gemm_form(ops, M, I, p_drop, chunk
     f1 = lib.xf_linear_fwd_ex
     f1.restype = C.c_int
     f1.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
-                                      C.c_uint64, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p]
+                                      N.Seed, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p]
     rc = f1(N.ptr(x16), N.ptr(w1), N.ptr(b1), N.ptr(ref["g"]), M, I, H, N.EPI_BIAS_GELU, None, N.ptr(ref["d"]), 0.0, 0, 0,
             N.precision_id("bf16"), 1 | 2 | 4 | 0x100, N.stream())
     assert rc == 0, rc
     f2 = lib.xf_linear_ln_fwd_ex
     f2.restype = C.c_int
-    f2.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32,
+    f2.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, N.Seed, C.c_uint32,
                                       C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 4 + [C.c_int32, C.c_uint32,
                                                                                                C.c_void_p]
     rc = f2(N.ptr(ref["g"]), N.ptr(w2), N.ptr(b2), N.ptr(ref["pre"]), M, H, I, N.ptr(res), p_drop, 5, 9, N.ptr(gamma),
@@ -492,7 +492,7 @@ def test_ffn_forward_in_one_kernel_vs_the_two_gemm_form(ops, M, I, p_drop, chunk
     monkeypatch.setenv("XFMR_FFN_CHUNK", chunk)  # read per call
     fn = lib.xf_ffn_fwd_fused_ex
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32,
+    fn.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, N.Seed, C.c_uint32,
                                       C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 5
 
     def run():
@@ -556,7 +556,7 @@ def test_dx_gemm_with_layernorm_backward_epilogue_vs_separate_kernels_and_bit_re
     fn = lib.xf_linear_bwd_dx_lnbwd_ex
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [
-        C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int32,
+        C.c_float, N.Seed, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int32,
         C.c_uint32, C.c_void_p, C.c_float, C.c_uint32]
 
     def run():

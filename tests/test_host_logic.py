@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(native):
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"declared in include/xfmr_hip.h but not exported: {missing}"
     assert declared == set(native.EXPORTED_SYMBOLS), declared ^ set(native.EXPORTED_SYMBOLS)
-    assert native.load().xfmr_abi_version() == 1
+    assert native.load().xfmr_abi_version() == native.ABI_VERSION == 2
     assert native.load().xfmr_strerror(-2).decode().startswith("shape not supported")
 
 
@@ -92,10 +92,117 @@ def test_config_surface_matches_reference_fields():
     assert [c.__name__ for c in X.LOSS_CLASSES] == [
         "AlignmentLoss", "AlignmentContrastiveLoss", "ContrastiveLoss", "InfoNCELoss", "NCELoss",
         "PairwiseHingeLoss", "PairwiseLogisticLoss"]
-    with pytest.raises(ValueError, match="offline"):
-        X.RecommenderModel(X.ModelConfig())  # hidden_size None would need a model download in the reference
+    with pytest.raises(ValueError, match="offline"):  # an unknown model name and nothing to derive the sizes from
+        X.RecommenderModel(X.ModelConfig(pretrained_model_name="someone/unknown-model", num_attention_heads=None))
     with pytest.raises(ValueError, match="must be 32"):
         X.RecommenderModel(X.ModelConfig(hidden_size=48, num_attention_heads=1))
+
+
+# The `model.config` block of the reference's config.yaml, verbatim (config.yaml:46-79): `hidden_size: null` is what
+# `uv run train` starts from.
+REFERENCE_CONFIG_YAML_MODEL_BLOCK = """
+    vocab_size: 1
+    hidden_size: null
+    num_hidden_layers: 1
+    num_attention_heads: 12
+    intermediate_size: 48
+    max_seq_length: 32
+    is_decoder: true
+    pretrained_model_name: sentence-transformers/all-MiniLM-L6-v2
+    pooling_mode: mean
+    is_normalized: false
+    target_position: first
+    mask_false_negatives: true
+    num_hard_negatives: 0
+    scale: 1.0
+    margin: 0.5
+    train_loss: InfoNCELoss
+    learning_rate: 0.001
+    weight_decay: 0.01
+    items_config:
+      id_col: item_id
+      embedding_col: embedding
+      lancedb_path: lance_db
+      table_name: items
+      text_col: item_text
+      index_metric: cosine
+    users_config:
+      id_col: user_id
+      embedding_col: null
+      lancedb_path: lance_db
+      table_name: users
+      text_col: user_text
+      index_metric: cosine
+    top_k: 20
+"""
+
+
+def test_module_builds_from_the_reference_config_yaml_block_verbatim():
+    """`hidden_size: null` (config.yaml:48) is resolved offline instead of raising: the reference fills it from the
+    pretrained model's config (models.py:80-91 -> 384 for all-MiniLM-L6-v2 = 32 x the 12 heads), and the item table's
+    width is checked against it."""
+    import yaml
+
+    import xfmr_rec_amd as X
+
+    block = yaml.safe_load(REFERENCE_CONFIG_YAML_MODEL_BLOCK)
+    conf = X.LightningConfig(**block)
+    assert conf.hidden_size is None and conf.items_config["index_metric"] == "cosine"
+    mod = X.RecommenderLightningModule(conf)
+    mod.configure_model()
+    c = mod.model.config
+    assert (c.hidden_size, c.num_attention_heads, c.num_hidden_layers, c.intermediate_size, c.max_seq_length) == (384, 12, 1, 48, 32)
+    names, shapes, _, total = X.models.flat_layout(384, 48, 32, 1)
+    assert mod.model.flat.numel() == total
+    # the MiniLM-wide table fits, another width is an error (models.py:336-345: no projection in between)
+    mod.model.configure_embeddings({"embedding": torch.randn(10, 384), "item_id": [f"i{k}" for k in range(10)]})
+    assert mod.model.embeddings.shape == (11, 384) and float(mod.model.embeddings[0].abs().sum()) == 0.0
+    other = X.RecommenderModel(X.ModelConfig())
+    with pytest.raises(ValueError, match="hidden_size"):
+        other.configure_embeddings({"embedding": torch.randn(10, 128), "item_id": list(range(10))})
+    # an unknown model name: hidden_size follows from the head count (head size 32)
+    m2 = X.RecommenderModel(X.ModelConfig(pretrained_model_name="someone/unknown-model", num_attention_heads=4))
+    assert m2.config.hidden_size == 128
+
+
+def test_load_table_from_files(tmp_path):
+    """any (V, H) table FILE -- .npy, .safetensors, .pt (weights only), items.parquet."""
+    import numpy as np
+    from safetensors.torch import save_file
+
+    import xfmr_rec_amd as X
+
+    V, H = 9, 64
+    w = torch.randn(V, H)
+    padded = torch.cat([torch.zeros(1, H), w])
+
+    def fresh():
+        return X.RecommenderModel(X.ModelConfig(hidden_size=H, num_attention_heads=2))
+
+    np.save(tmp_path / "t.npy", w.numpy())
+    m = fresh(); m.load_table(tmp_path / "t.npy")
+    assert torch.equal(m.embeddings, padded)
+    np.save(tmp_path / "p.npy", padded.numpy())  # already carries the padding row
+    m = fresh(); m.load_table(tmp_path / "p.npy")
+    assert torch.equal(m.embeddings, padded)
+    save_file({"embedding": w}, str(tmp_path / "t.safetensors"))
+    m = fresh(); m.load_table(tmp_path / "t.safetensors")
+    assert torch.equal(m.embeddings, padded)
+    torch.save({"embeddings.weight": padded}, tmp_path / "t.pt")  # the reference module's own key
+    m = fresh(); m.load_table(tmp_path / "t.pt")
+    assert torch.equal(m.embeddings, padded)
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    ids = [f"movie{k}" for k in range(V)]
+    pq.write_table(pa.table({"item_id": ids, "item_text": ["x"] * V, "embedding": [r.tolist() for r in w]}),
+                   str(tmp_path / "items.parquet"))
+    m = fresh(); m.load_table(tmp_path / "items.parquet")
+    assert torch.equal(m.embeddings, padded) and int(m.id2idx["movie3"]) == 4
+    with pytest.raises(ValueError, match="hidden_size"):
+        np.save(tmp_path / "w.npy", torch.randn(V, 32).numpy()); fresh().load_table(tmp_path / "w.npy")
+    with pytest.raises(ValueError, match="unsupported file type"):
+        fresh().load_table(tmp_path / "t.csv")
 
 
 def test_model_state_dict_roundtrip_on_cpu():

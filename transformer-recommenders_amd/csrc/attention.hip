@@ -66,7 +66,10 @@ struct AttnSmem {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <class P>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   using elem = typename P::elem;
   using SM = AttnSmem<P>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -144,7 +147,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <class P>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   using elem = typename P::elem;
   using SM = AttnSmem<P>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -219,7 +225,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <class P>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   using elem = typename P::elem;
   using SM = AttnSmem<P>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -414,7 +423,10 @@ __device__ __forceinline__ float dot16(const void* x, const void* y, int64_t off
 }
 
 template <bool S16>
-__global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_block(a);
@@ -501,7 +513,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kernel(AttnArgs a) {
 }
 
 template <bool S16>
-__global__ __launch_bounds__(256, 4) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_bf16_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_block(a);
@@ -578,7 +593,10 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 }
 
 template <bool S16>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_bf16_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_block(a);
@@ -732,7 +750,10 @@ __device__ __forceinline__ AttnBlock attn_seq_block(const AttnArgs& a) {  // as 
 // (tiles - 1 - w) and (tiles - 8 + w). The output goes straight from the accumulator layout (lane = query row) to
 // global memory, so no wave waits for the others before it stores.
 template <bool S16>
-__global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_seq_block(a);
@@ -831,7 +852,10 @@ size_t bf16_smem_fwd_seq(int L) {  // K + V images of the whole sequence, key ma
 }
 
 template <bool S16>
-__global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const AttnBlock blk = attn_seq_block(a);
@@ -1197,7 +1221,7 @@ int check_shape(int B, int L, int A, int H) {
 extern "C" {
 
 int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t A,
-                   int32_t H, float dropout_p, uint64_t seed, uint32_t site, int32_t precision, bool s16,
+                   int32_t H, float dropout_p, XfSeed seed, uint32_t site, int32_t precision, bool s16,
                    bool causal, hipStream_t st) {
   if (!qkv || !key_mask || !ctx || !lse) return XFMR_EINVAL;
   if (int rc = check_shape(B, L, A, H)) return rc;
@@ -1226,7 +1250,7 @@ int xfmr_attn_fwd_mode(const float* qkv, const uint8_t* key_mask, float* ctx, fl
 }
 
 int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* d_ctx,
-                   void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, uint64_t seed,
+                   void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, XfSeed seed,
                    uint32_t site, int32_t precision, bool s16, bool causal, hipStream_t st) {
   if (!qkv || !key_mask || !ctx || !lse || !d_ctx || !d_qkv) return XFMR_EINVAL;
   if (int rc = check_shape(B, L, A, H)) return rc;

@@ -282,6 +282,15 @@ __device__ __forceinline__ void xf_store2<PrecF32>(float* dst, float a, float b)
 
 __device__ __forceinline__ float xf_get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
+// Wave priority of the training chain's kernels (experiment switch -DXF_CHAIN_SETPRIO=n, n = 1..3; default off): the
+// low-priority side streams only decide which WORKGROUP is dispatched first -- once resident, a logging-pass or dW wave
+// arbitrates for issue slots like any other. s_setprio raises the chain's waves above them on a shared SIMD.
+#ifdef XF_CHAIN_SETPRIO
+#define XF_CHAIN_PRIO() __builtin_amdgcn_s_setprio(XF_CHAIN_SETPRIO)
+#else
+#define XF_CHAIN_PRIO() ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // Dropout: stateless per-element hash so that forward and backward kernels with different thread
 // mappings regenerate the same mask. keep  <=>  hash32(element ^ key) >= threshold(p).
@@ -290,19 +299,39 @@ __host__ __device__ __forceinline__ uint32_t xf_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// The dropout stream of a step: the host-side seed, optionally mixed ON THE DEVICE with a step counter read from HBM
+// (xfmr_encoder_cfg.step_device) -- a captured hipGraph replays the same kernel arguments every step, so whatever
+// changes from step to step has to come from device memory. dyn == nullptr: the seed alone (eager launches).
+struct XfSeed {
+  uint64_t seed;
+  const uint32_t* dyn;
+  XfSeed(uint64_t s = 0, const uint32_t* d = nullptr) : seed(s), dyn(d) {}
+};
 struct XfDropout {
   uint32_t key;
   uint32_t thresh;  // drop when hash < thresh
   float scale;      // 1/(1-p); 1 when disabled
   bool on;
+  const uint32_t* dyn;  // device step counter still to be mixed into `key` (xf_drop_resolve at kernel entry); or null
 };
-static inline XfDropout xf_make_dropout(float p, uint64_t seed, uint32_t site) {
+static inline XfDropout xf_make_dropout(float p, XfSeed sd, uint32_t site) {
   XfDropout d;
+  const uint64_t seed = sd.seed;
   d.on = p > 0.f;
   d.key = xf_hash32((uint32_t)seed ^ xf_hash32((uint32_t)(seed >> 32) + 0x9E3779B9U * (site + 1)));
   double t = (double)p * 4294967296.0;
   d.thresh = p >= 1.f ? 0xFFFFFFFFu : (uint32_t)t;
   d.scale = d.on ? 1.f / (1.f - p) : 1.f;
+  d.dyn = d.on ? sd.dyn : nullptr;
+  return d;
+}
+// Kernel entry: fold the device-side step counter into the key (one scalar load + a scalar hash per wave; forward and
+// backward kernels of a step read the same counter value -- it advances after the optimizer, xfmr_step_advance).
+__host__ __device__ __forceinline__ XfDropout xf_drop_resolve(XfDropout d) {
+  if (d.dyn) {
+    d.key = xf_hash32(d.key ^ (*d.dyn * 0x9E3779B9U + 0x7F4A7C15U));
+    d.dyn = nullptr;
+  }
   return d;
 }
 // Two-index form (attention probabilities: query row, key column; hidden states: token row, feature column): the full hash is

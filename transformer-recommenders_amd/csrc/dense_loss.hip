@@ -369,7 +369,7 @@ int xfmr_dense_loss_grads(const xfmr_loss_cfg* cfg, const float* query, const fl
   XF_LAUNCH_CHECK();
   hipLaunchKernelGGL(dense_loss_kernel, dim3((unsigned)N), dim3(256), smem, st, a);
   XF_LAUNCH_CHECK();
-  return xf_loss_finalize(blockpart, (int)N, 1, counts, XFMR_NEG_SHARED, 0, losses, stats, tot, st);
+  return xf_loss_finalize(blockpart, (int)N, 1, counts, XFMR_NEG_SHARED, 0, (int64_t)C, losses, stats, tot, st);
 }
 
 }  // extern "C"

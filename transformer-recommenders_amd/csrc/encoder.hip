@@ -4,6 +4,7 @@
 // so one training step can be captured into a hipGraph.
 #include <math.h>
 #include <stdlib.h>
+#include <new>
 #include <string.h>
 
 #include "internal.h"
@@ -100,11 +101,14 @@ bool mixed_storage(const xfmr_encoder_cfg* c) {
 // FFN1 -> GELU -> FFN2 -> LayerNorm as one forward kernel (gemm.hip: ffn_fwd_fused_kernel): same conditions as the
 // LayerNorm-fused GEMM epilogues plus I a multiple of its chunk widths. The forward and the backward of one step must
 // agree on it (f1 holds u after the fused kernel, gelu'(u) after the two-kernel form): a pure function of the
-// configuration and the XFMR_FFN_UNFUSED / XFMR_LN_UNFUSED switches.
+// configuration, its XFMR_ENC_*_UNFUSED flag bits included -- both calls of a step get the same cfg.
+bool ln_fused(const xfmr_encoder_cfg* c, int64_t T) {
+  // out-proj / FFN2 GEMM + LayerNorm as one kernel: its 64 x 128 tiles are T / 64 workgroups -- below one per CU
+  // (T < 16 384) the two-kernel form with 64 x 64 tiles is faster (batch 32: -1.5 % fused; batch 128: +0.9 %; 512: +1.8 %)
+  return mixed_storage(c) && c->hidden == 128 && T >= 16384 && !(c->flags & XFMR_ENC_LN_UNFUSED);
+}
 bool ffn_fused(const xfmr_encoder_cfg* c, int64_t T) {
-  auto on = [](const char* name) { const char* e = getenv(name); return e && *e && *e != '0'; };
-  return mixed_storage(c) && c->hidden == 128 && T >= 16384 && (c->inter % 128) == 0 && c->inter <= 1024 && !on("XFMR_LN_UNFUSED") &&
-         !on("XFMR_FFN_UNFUSED");
+  return ln_fused(c, T) && (c->inter % 128) == 0 && c->inter <= 1024 && !(c->flags & XFMR_ENC_FFN_UNFUSED);
 }
 
 // Shapes whose backward runs the weight-gradient GEMMs on the side stream (xfmr_encoder_bwd): those of the LayerNorm-fused
@@ -133,7 +137,8 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   a.dA = take(T * H); a.dB = take(T * H);
   a.dLin = take_bytes(T * H * es); a.dCtx = take_bytes(T * H * es);
   a.dI = take_bytes(T * I * es); a.dQKV = take_bytes(T * 3 * H * es);
-  const bool per_layer = dw_side_shape(c, (int64_t)T);  // (+236 MB per layer at T = 102 400, I = 512)
+  // (+236 MB per layer at T = 102 400, I = 512: only when the backward will use the side stream)
+  const bool per_layer = dw_side_shape(c, (int64_t)T) && c->context && !(c->flags & XFMR_ENC_DW_INLINE);
   for (int i = 0; i < c->layers && i < 64; ++i) {
     a.dLinF[i] = (per_layer && i) ? take_bytes(T * H * es) : a.dLin;
     a.dLinO[i] = per_layer ? take_bytes(T * H * es) : a.dLin;
@@ -196,7 +201,7 @@ int check_cfg(const xfmr_encoder_cfg* c) {
   if (c->seq_len > c->max_pos) return XFMR_EINVAL;
   if (c->hidden != c->heads * 32 || (c->inter & 3)) return XFMR_EUNSUPPORTED;
   if (c->precision != XFMR_PREC_F32 && c->precision != XFMR_PREC_BF16) return XFMR_EINVAL;
-  if (c->flags & ~(uint32_t)XFMR_ENC_BIDIRECTIONAL) return XFMR_EINVAL;  // unknown flag bits
+  if (c->flags & ~(uint32_t)XFMR_ENC_FLAGS_ALL) return XFMR_EINVAL;  // unknown flag bits
   return XFMR_OK;
 }
 
@@ -230,21 +235,6 @@ const char* xfmr_strerror(int code) {
 }
 int xfmr_abi_version(void) { return XFMR_ABI_VERSION; }
 
-int xfmr_low_priority_stream_create(void** stream) {
-  if (!stream) return XFMR_EINVAL;
-  int lo = 0, hi = 0;
-  hipStream_t s = nullptr;
-  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
-      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess)
-    return XFMR_EHIP;
-  *stream = s;
-  return XFMR_OK;
-}
-int xfmr_stream_destroy(void* stream) {
-  if (!stream) return XFMR_EINVAL;
-  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? XFMR_OK : XFMR_EHIP;
-}
-
 int64_t xfmr_param_count(const xfmr_encoder_cfg* cfg) {
   if (!cfg || cfg->layers <= 0) return XFMR_EINVAL;
   ParamLayout pl;
@@ -277,9 +267,33 @@ size_t xfmr_encoder_workspace_bytes(const xfmr_encoder_cfg* cfg) {
   return carve(cfg, nullptr, -1, nullptr).total;
 }
 
-namespace { thread_local hipEvent_t g_embed_event = nullptr; }
-int xfmr_encoder_fwd_mark_embed(void* event) {
-  g_embed_event = (hipEvent_t)event;
+// The caller-owned side stream of xfmr_encoder_bwd's weight-gradient GEMMs + the events of its fork / join.
+struct XfContext {
+  hipStream_t side;
+  hipEvent_t ev_in, ev_done;
+};
+int xfmr_context_create(void** context) {
+  if (!context) return XFMR_EINVAL;
+  XfContext* c = new (std::nothrow) XfContext{};
+  if (!c) return XFMR_EHIP;
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
+    xfmr_context_destroy(c);
+    return XFMR_EHIP;
+  }
+  *context = c;
+  return XFMR_OK;
+}
+int xfmr_context_destroy(void* context) {
+  if (!context) return XFMR_EINVAL;
+  XfContext* c = (XfContext*)context;
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  delete c;
   return XFMR_OK;
 }
 
@@ -298,15 +312,13 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
   const bool mix = mixed_storage(cfg);
   const bool causal = !(cfg->flags & XFMR_ENC_BIDIRECTIONAL);
   hipStream_t st = (hipStream_t)stream;
+  const XfSeed sd(cfg->seed, cfg->step_device);
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
   XF_TRY(xf_embed_ln_fwd_ex(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
                             params + pl.eb, a.x0, mix ? a.x0b : nullptr, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask, B,
-                            L, H, cfg->ln_eps, cfg->hidden_dropout, cfg->seed, SITE_EMB, st));
-  if (hipEvent_t ev = g_embed_event) {  // (one-shot) key_mask is written: see xfmr_encoder_fwd_mark_embed
-    g_embed_event = nullptr;
-    if (hipEventRecord(ev, st) != hipSuccess) return XFMR_EHIP;
-  }
+                            L, H, cfg->ln_eps, cfg->hidden_dropout, sd, SITE_EMB, st));
+  if (cfg->embed_event && hipEventRecord((hipEvent_t)cfg->embed_event, st) != hipSuccess) return XFMR_EHIP;  // key_mask is written
   const float* x = a.x0;
   const void* xg = mix ? a.x0b : (const void*)a.x0;  // the same activations as the GEMM operand
   const uint32_t sA = mix ? XF_S16_A : 0;
@@ -317,10 +329,7 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     XF_LAUNCH_CHECK();
   }
   const uint32_t sB = mix ? XF_S16_B : 0;
-  const bool no_fuse = [] { const char* e = getenv("XFMR_LN_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
-  // out-proj / FFN2 GEMM + LayerNorm as one kernel: its 64 x 128 tiles are T / 64 workgroups -- below one per CU
-  // (T < 16 384) the two-kernel form with 64 x 64 tiles is faster (batch 32: -1.5 % fused; batch 128: +0.9 %; 512: +1.8 %)
-  const bool fuse_ln = mix && H == 128 && T >= 16384 && !no_fuse;
+  const bool fuse_ln = ln_fused(cfg, T);  // LayerNorm in the out-proj / FFN2 GEMM epilogues
   const bool fuse_ffn = ffn_fused(cfg, T);
   auto W = [&](int64_t off) -> const float* {  // weight operand: the bf16 copy under mixed storage
     return mix ? reinterpret_cast<const float*>((const __bf16*)a.wbf + off) : params + off;
@@ -332,22 +341,22 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     float* out = (i == cfg->layers - 1) ? tok : l.x2;
     XF_TRY(xf_linear_fwd_ex(xg, W(p.wqkv), params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
                             0.f, 0, 0, prec, (mix ? XF_S16_C : 0) | sA | sB, st));
-    XF_TRY(xf_attn_fwd_ex(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, cfg->seed, site_attn(i), prec,
+    XF_TRY(xf_attn_fwd_ex(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, sd, site_attn(i), prec,
                           mix, causal, st));
     if (fuse_ln) {  // LayerNorm in the GEMM epilogue (the tile spans whole rows)
-      XF_TRY(xf_linear_ln_fwd_ex(l.ctx, W(p.wo), params + p.bo, l.pre1, T, H, H, x, cfg->hidden_dropout, cfg->seed,
+      XF_TRY(xf_linear_ln_fwd_ex(l.ctx, W(p.wo), params + p.bo, l.pre1, T, H, H, x, cfg->hidden_dropout, sd,
                                  site_out(i), params + p.ln1g, params + p.ln1b, cfg->ln_eps, l.x1, l.x1b, l.mean1,
                                  l.rstd1, prec, XF_S16_A | sB, st));
     } else {
       XF_TRY(xf_linear_fwd_ex(l.ctx, W(p.wo), params + p.bo, l.pre1, T, H, H, XFMR_EPI_BIAS_DROP_RES, x, nullptr,
-                              cfg->hidden_dropout, cfg->seed, site_out(i), prec, (mix ? XF_S16_A : 0) | sB, st));
+                              cfg->hidden_dropout, sd, site_out(i), prec, (mix ? XF_S16_A : 0) | sB, st));
       XF_TRY(xf_layernorm_fwd_ex(l.pre1, params + p.ln1g, params + p.ln1b, l.x1, mix ? l.x1b : nullptr, l.mean1,
                                  l.rstd1, T, H, cfg->ln_eps, st));
     }
     const bool last = i == cfg->layers - 1;
     if (fuse_ffn) {  // FFN1 -> GELU -> FFN2 -> dropout + residual + LayerNorm in one kernel; f1 <- the PRE-activation, g <- gelu
       XF_TRY(xf_ffn_fwd_fused_ex(l.x1b, W(p.w1), params + p.b1, W(p.w2), params + p.b2, l.f1, l.g, l.pre2, T, H, I, l.x1,
-                                 cfg->hidden_dropout, cfg->seed, site_ffn(i), params + p.ln2g, params + p.ln2b,
+                                 cfg->hidden_dropout, sd, site_ffn(i), params + p.ln2g, params + p.ln2b,
                                  cfg->ln_eps, out, last ? nullptr : l.x2b, l.mean2, l.rstd2, st));
       x = out;
       xg = mix ? (const void*)l.x2b : (const void*)out;
@@ -357,12 +366,12 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
                             XFMR_EPI_BIAS_GELU, nullptr, l.f1, 0.f, 0, 0, prec,
                             (mix ? XF_S16_C : 0) | sA | sB | XF_AUX_GELU_GRAD, st));  // f1 <- gelu'(pre)
     if (fuse_ln) {
-      XF_TRY(xf_linear_ln_fwd_ex(l.g, W(p.w2), params + p.b2, l.pre2, T, H, I, l.x1, cfg->hidden_dropout, cfg->seed,
+      XF_TRY(xf_linear_ln_fwd_ex(l.g, W(p.w2), params + p.b2, l.pre2, T, H, I, l.x1, cfg->hidden_dropout, sd,
                                  site_ffn(i), params + p.ln2g, params + p.ln2b, cfg->ln_eps, out,
                                  last ? nullptr : l.x2b, l.mean2, l.rstd2, prec, XF_S16_A | sB, st));
     } else {
       XF_TRY(xf_linear_fwd_ex(l.g, W(p.w2), params + p.b2, l.pre2, T, H, I, XFMR_EPI_BIAS_DROP_RES, l.x1, nullptr,
-                              cfg->hidden_dropout, cfg->seed, site_ffn(i), prec, (mix ? XF_S16_A : 0) | sB, st));
+                              cfg->hidden_dropout, sd, site_ffn(i), prec, (mix ? XF_S16_A : 0) | sB, st));
       XF_TRY(xf_layernorm_fwd_ex(l.pre2, params + p.ln2g, params + p.ln2b, out, (mix && !last) ? l.x2b : nullptr,
                                  l.mean2, l.rstd2, T, H, cfg->ln_eps, st));
     }
@@ -381,6 +390,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   const Acts a = carve(cfg, base, -1, nullptr);
   if (acts_bytes < a.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  const XfSeed sd(cfg->seed, cfg->step_device);
   const int B = cfg->batch, L = cfg->seq_len, H = cfg->hidden, I = cfg->inter, A = cfg->heads;
   const int64_t T = (int64_t)B * L;
   const int prec = cfg->precision;
@@ -403,38 +413,22 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   // LayerNorm backward in the epilogue of the dX GEMM that produces its input gradient (whole-row 64 x 128 tiles: same
   // conditions as the forward fusion): LN1 with the FFN1 dX GEMM of its layer, LN2 of layer i-1 with the QKV dX GEMM of
   // layer i. The top layer's LN2 and the embedding LayerNorm keep their own launches.
-  const bool no_fuse = [] { const char* e = getenv("XFMR_LN_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
-  const bool fuse_lnb = mix && H == 128 && T >= 16384 && !no_fuse;
+  const bool fuse_lnb = ln_fused(cfg, T);
   const bool fuse_ffn = ffn_fused(cfg, T);  // what the forward of this step did
-  const bool no_ffn_bwd = [] { const char* e = getenv("XFMR_FFN_BWD_UNFUSED"); return e && *e && *e != '0'; }();  // (per call)
-  // The weight-gradient GEMMs (16 of the backward's launches, 0.49 ms at batch 512) run on a LOW-PRIORITY side stream: the
-  // dX -> LayerNorm -> attention chain keeps the CUs it wants, and the dW workgroups fill what its 64-row-tile kernels
-  // leave idle in their last rounds (1600 tiles over 768 / 1024 workgroup slots: section 4 of DESIGN.md). Same priority
-  // was measured in round 1 and gained nothing (each side slowed by what the overlap gave). Dependencies: a dW GEMM
-  // starts after an event recorded behind the producers of its operands; the gradient buffers the chain used to reuse layer
-  // after layer (dLin in both roles, dI, dQKV) exist once PER LAYER in this mode, so nothing a dW GEMM reads is rewritten
-  // before the chain joins the side stream in front of the reduction launch (with two sets alternating by layer parity
-  // and write-after-read events the chain kept stalling on the lagging side stream: 0.4 % instead of 2 %).
-  // XFMR_DW_SIDE=0: everything on `st`.
-  static thread_local hipStream_t side = nullptr;
-  static thread_local hipEvent_t ev_in = nullptr, ev_done = nullptr;
-  static thread_local int side_device = -1;
-  const bool dw_side = fuse_lnb && dw_side_shape(cfg, T) && [] { const char* e = getenv("XFMR_DW_SIDE"); return !(e && *e == '0'); }();
-  int cur_device = -1;
-  if (dw_side && hipGetDevice(&cur_device) != hipSuccess) return XFMR_EHIP;
-  if (dw_side && side && side_device != cur_device) {  // this host thread moved to another device: its own stream there
-    (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_in); (void)hipEventDestroy(ev_done);
-    side = nullptr;
-  }
-  if (dw_side && !side) {
-    int lo = 0, hi = 0;
-    side_device = cur_device;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess)
-      return XFMR_EHIP;
-  }
+  const bool no_ffn_bwd = (cfg->flags & XFMR_ENC_FFN_BWD_UNFUSED) != 0;
+  // The weight-gradient GEMMs (16 of the backward's launches, 0.49 ms at batch 512) run on the LOW-PRIORITY side stream of
+  // the caller's xfmr_context: the dX -> LayerNorm -> attention chain keeps the CUs it wants, and the dW workgroups fill
+  // what its 64-row-tile kernels leave idle in their last rounds (section 4 of DESIGN.md). Same priority was measured in
+  // round 1 and gained nothing (each side slowed by what the overlap gave). Dependencies: a dW GEMM starts after an event
+  // recorded behind the producers of its operands; the gradient buffers the chain used to reuse layer after layer (dLin in
+  // both roles, dI, dQKV) exist once PER LAYER in this mode, so nothing a dW GEMM reads is rewritten before the chain
+  // joins the side stream in front of the reduction launch (with two sets alternating by layer parity and
+  // write-after-read events the chain kept stalling on the lagging side stream: 0.4 % instead of 2 %).
+  // No context, or XFMR_ENC_DW_INLINE: everything on `st`.
+  XfContext* const ctx = (XfContext*)cfg->context;
+  const bool dw_side = ctx && fuse_lnb && dw_side_shape(cfg, T) && !(cfg->flags & XFMR_ENC_DW_INLINE);
+  hipStream_t const side = dw_side ? ctx->side : nullptr;
+  hipEvent_t const ev_in = dw_side ? ctx->ev_in : nullptr, ev_done = dw_side ? ctx->ev_done : nullptr;
   bool side_used = false;
   int side_rc = XFMR_OK;
   auto dw_stream = [&]() -> hipStream_t {  // everything enqueued on `st` so far is visible to the side stream
@@ -445,6 +439,8 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   };
   bool ln2_done = false;  // layer i's LN2 backward already ran inside layer i+1's QKV dX GEMM
   bool emb_ln_done = false;  // ... and the embedding LayerNorm's inside layer 0's
+  // (a lambda so that a failing launch still reaches the join below: the side stream's GEMMs read the caller's buffers)
+  const int chain_rc = [&]() -> int {
   for (int i = cfg->layers - 1; i >= 0; --i) {
     LayerActs l;
     RedBufs r;
@@ -466,7 +462,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     if (!ln2_done) {
       XF_TRY(xf_layernorm_bwd_impl(dX, l.pre2, l.mean2, l.rstd2, params + p.ln2g, a.dA, lin_copy ? dLinF : nullptr,
                                    mix, nullptr, nullptr, nullptr, T, H, off,
-                                   xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_ffn(i)), r.ln2, st, &blocks));
+                                   xf_make_dropout(cfg->hidden_dropout, sd, site_ffn(i)), r.ln2, st, &blocks));
       seg(r.ln2, grads + p.ln2g, blocks, H, 3 * H);
       seg(r.ln2 + H, grads + p.ln2b, blocks, H, 3 * H);
       seg(r.ln2 + 2 * H, grads + p.b2, blocks, H, 3 * H);
@@ -477,7 +473,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     const bool fuse_ffn_bwd = fuse_ffn && fuse_lnb && !no_ffn_bwd;
     if (fuse_ffn_bwd) {  // FFN2 dX * gelu'(u) -> dI -> FFN1 dX (+= d(pre2)) -> LayerNorm 1 backward in one kernel
       XF_TRY(xf_ffn_bwd_dx_fused_ex(dlin, W(p.w2), l.f1, W(p.w1), dI, T, H, I, a.dA, l.pre1, l.mean1, l.rstd1,
-                                    params + p.ln1g, cfg->hidden_dropout, cfg->seed, site_out(i), dX, dLinO, r.ln1,
+                                    params + p.ln1g, cfg->hidden_dropout, sd, site_out(i), dX, dLinO, r.ln1,
                                     &blocks, st));
     } else {
       // (after the fused FFN forward f1 holds the pre-activation u, not gelu'(u): the epilogue evaluates gelu'(u))
@@ -490,14 +486,14 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     if (fuse_ffn_bwd) {  // (done above)
     } else if (fuse_lnb) {  // dX of FFN1 (+= d(pre2)) and LayerNorm 1 backward in one kernel -> dX = d(pre1), dLin
       XF_TRY(xf_linear_bwd_dx_lnbwd_ex(dI, W(p.w1), T, I, H, a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g,
-                                       cfg->hidden_dropout, cfg->seed, site_out(i), dX, dLinO, r.ln1, &blocks, prec,
+                                       cfg->hidden_dropout, sd, site_out(i), dX, dLinO, r.ln1, &blocks, prec,
                                        sA | sB, st));
     } else {
       XF_TRY(xf_linear_bwd_dx_ex(dI, W(p.w1), a.dA, T, I, H, a.dA, nullptr, prec, sA | sB, st));  // += d(pre2)
       // LayerNorm 1 -> dX = d(pre1)
       XF_TRY(xf_layernorm_bwd_impl(a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g, dX, lin_copy ? dLinO : nullptr,
                                    mix, nullptr, nullptr, nullptr, T, H, off,
-                                   xf_make_dropout(cfg->hidden_dropout, cfg->seed, site_out(i)), r.ln1, st, &blocks));
+                                   xf_make_dropout(cfg->hidden_dropout, sd, site_out(i)), r.ln1, st, &blocks));
     }
     seg(r.ln1, grads + p.ln1g, blocks, H, 3 * H);
     seg(r.ln1 + H, grads + p.ln1b, blocks, H, 3 * H);
@@ -506,7 +502,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.ctx, T, H, H, prec, sAB, r.wo, nullptr, &splits, dw_stream()));
     seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
-    XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, dQKV, B, L, A, H, cfg->attn_dropout, cfg->seed,
+    XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, dQKV, B, L, A, H, cfg->attn_dropout, sd,
                           site_attn(i), prec, mix, causal, st));
     XF_TRY(xf_linear_bwd_dw_deferred(dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, dw_stream()));
     seg(r.wqkv, grads + p.wqkv, splits, (int64_t)3 * H * H, (int64_t)3 * H * H);
@@ -517,7 +513,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       carve(cfg, base, i - 1, &prev, &rp);
       const LayerParams pp = layer_params(cfg, i - 1);
       XF_TRY(xf_linear_bwd_dx_lnbwd_ex(dQKV, W(p.wqkv), T, 3 * H, H, dX, prev.pre2, prev.mean2, prev.rstd2,
-                                       params + pp.ln2g, cfg->hidden_dropout, cfg->seed, site_ffn(i - 1), a.dA,
+                                       params + pp.ln2g, cfg->hidden_dropout, sd, site_ffn(i - 1), a.dA,
                                        dw_side ? a.dLinF[i - 1] : a.dLin, rp.ln2, &blocks, prec, sA | sB, st));
       seg(rp.ln2, grads + pp.ln2g, blocks, H, 3 * H);
       seg(rp.ln2 + H, grads + pp.ln2b, blocks, H, 3 * H);
@@ -527,7 +523,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       ParamLayout pe;
       layer_base(cfg, 0, &pe);
       XF_TRY(xf_linear_bwd_dx_lnbwd_ex(dQKV, W(p.wqkv), T, 3 * H, H, dX, a.emb_pre, a.emb_mean, a.emb_rstd,
-                                       params + pe.eg, 0.f, cfg->seed, 0, a.dA, nullptr, a.emb_ln, &blocks, prec,
+                                       params + pe.eg, 0.f, sd, 0, a.dA, nullptr, a.emb_ln, &blocks, prec,
                                        sA | sB, st, cfg->hidden_dropout, SITE_EMB));
       seg(a.emb_ln, grads + pe.eg, blocks, H, 3 * H);
       seg(a.emb_ln + H, grads + pe.eb, blocks, H, 3 * H);
@@ -541,7 +537,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   if (!emb_ln_done) {
     int blocks = 0;
     XF_TRY(xf_layernorm_bwd_impl(dX, a.emb_pre, a.emb_mean, a.emb_rstd, params + pl.eg, a.dA, nullptr, false, nullptr,
-                                 nullptr, nullptr, T, H, xf_make_dropout(cfg->hidden_dropout, cfg->seed, SITE_EMB), off,
+                                 nullptr, nullptr, T, H, xf_make_dropout(cfg->hidden_dropout, sd, SITE_EMB), off,
                                  a.emb_ln, st, &blocks));
     seg(a.emb_ln, grads + pl.eg, blocks, H, 3 * H);
     seg(a.emb_ln + H, grads + pl.eb, blocks, H, 3 * H);
@@ -553,9 +549,12 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   // the position / type embedding gradients need only the chain's last output: in front of the join, underneath whatever
   // the side stream still has to do
   XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
+  return XFMR_OK;
+  }();
   if (side_used) {  // the chain joins the side stream: the reduction launch reads every slab
     if (hipEventRecord(ev_done, side) != hipSuccess || hipStreamWaitEvent(st, ev_done, 0) != hipSuccess) side_rc = XFMR_EHIP;
   }
+  if (chain_rc != XFMR_OK) return chain_rc;
   if (side_rc != XFMR_OK) return side_rc;
   XF_TRY(xf_multi_rowsum(segs, nseg, st));  // every weight / bias / LayerNorm gradient of the encoder, one launch
   return XFMR_OK;

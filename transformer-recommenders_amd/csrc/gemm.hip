@@ -535,7 +535,10 @@ template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S
 //  sequences/s with the default bound. Round 1 believed this bound was what made them run-to-run deterministic; the
 //  cause was the packed-fp32 op_sel form described at XF_PIN_SCALAR above, which the default-bound schedule happened
 //  to contain and this one did not. With the scalars pinned, both bounds are bit-reproducible.)
-__global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? XF_LN_EPI_MIN_WAVES : 1) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? XF_LN_EPI_MIN_WAVES : 1) void gemm_kernel(const GemmArgs g_in) {
+  GemmArgs g = g_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  if (EPI != EPI_SPLITK) XF_CHAIN_PRIO();
+  g.drop = xf_drop_resolve(g.drop); g.drop2 = xf_drop_resolve(g.drop2);
   using elem = typename P::elem;
   using TileA = OperandTile<P, BM, BK, TA>;
   using TileB = OperandTile<P, BN, BK, TB>;
@@ -847,7 +850,10 @@ struct WeightChunk {
 };
 
 template <int CH>  // columns of I per chunk: 128 (two workgroups' worth of registers) or 64
-__global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd_fused_kernel(FfnFwdArgs f) {
+__global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd_fused_kernel(const FfnFwdArgs f_in) {
+  FfnFwdArgs f = f_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  f.e.drop = xf_drop_resolve(f.e.drop);
   constexpr int H = 128, LDH = H + 8, LDC = CH + 8, BM = 64;
   constexpr int NJ = CH / 64;           // 32-column blocks of the u chunk per wave (2 x 2 waves over 64 x CH)
   constexpr int W_ELEMS = CH * LDH > H * LDC ? CH * LDH : H * LDC;
@@ -998,7 +1004,10 @@ struct FfnBwdArgs {
   GemmArgs e;         // epi_dx_lnbwd_64x128's arguments
 };
 
-__global__ __launch_bounds__(256, 3) void ffn_bwd_dx_fused_kernel(FfnBwdArgs f) {
+__global__ __launch_bounds__(256, 3) void ffn_bwd_dx_fused_kernel(const FfnBwdArgs f_in) {
+  FfnBwdArgs f = f_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  f.e.drop = xf_drop_resolve(f.e.drop); f.e.drop2 = xf_drop_resolve(f.e.drop2);
   constexpr int H = 128, BM = 64, CH = 64, LDH = H + 8, LDC = CH + 8;
   constexpr int LD1 = CH + 32;  // W2 chunk image [128 k][CH rows]
   constexpr int LD2 = H + 32;   // W1 chunk image [CH k][128 rows]
@@ -1360,7 +1369,7 @@ int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStrea
 }
 
 int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, int64_t M, int32_t N, int32_t K,
-                     int32_t epilogue, const float* residual, void* aux_out, float dropout_p, uint64_t seed,
+                     int32_t epilogue, const float* residual, void* aux_out, float dropout_p, XfSeed seed,
                      uint32_t site, int32_t precision, uint32_t s16, hipStream_t st) {
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return XFMR_EINVAL;
   if ((K & 3) || (N & 3)) return XFMR_EUNSUPPORTED;
@@ -1390,7 +1399,7 @@ int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, 
 }
 
 int xf_linear_ln_fwd_ex(const void* x, const float* w, const float* bias, float* pre, int64_t M, int32_t N, int32_t K,
-                        const float* residual, float dropout_p, uint64_t seed, uint32_t site, const float* gamma,
+                        const float* residual, float dropout_p, XfSeed seed, uint32_t site, const float* gamma,
                         const float* beta, float eps, float* y, void* y16, float* mean, float* rstd, int32_t precision,
                         uint32_t s16, hipStream_t st) {
   if (!x || !w || !pre || !residual || !gamma || !beta || !y || !mean || !rstd || M <= 0 || K <= 0)
@@ -1415,7 +1424,7 @@ int xfmr_linear_fwd(const float* x, const float* w, const float* bias, float* y,
 
 int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, const void* w2_16, const float* b2,
                         void* u16, void* g16, float* pre, int64_t M, int32_t H, int32_t I, const float* residual, float dropout_p,
-                        uint64_t seed, uint32_t site, const float* gamma, const float* beta, float eps, float* y,
+                        XfSeed seed, uint32_t site, const float* gamma, const float* beta, float eps, float* y,
                         void* y16, float* mean, float* rstd, hipStream_t st) {
   if (!x16 || !w1_16 || !b1 || !w2_16 || !pre || !residual || !gamma || !beta || !y || !mean || !rstd || M <= 0)
     return XFMR_EINVAL;
@@ -1437,7 +1446,9 @@ int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, con
   g.nt_n = 1; g.nt_m = (int)((M + 63) / 64); g.nt_z = 1;
   const int64_t groups = (g.nt_m + 7) / 8;
   if (groups * 8 > 0x7fffffffll) return XFMR_EUNSUPPORTED;
-  const char* ce = getenv("XFMR_FFN_CHUNK");  // (per call) 128: the wider chunk, two workgroups per CU -- measured slower
+  // XFMR_FFN_CHUNK=128 (tiling only -- what the kernel stores does not depend on it; read per call so that one test process
+  // can cover both): the wider chunk, two workgroups per CU -- measured slower
+  const char* ce = getenv("XFMR_FFN_CHUNK");
   const int chunk = ce ? atoi(ce) : 64;
   if (chunk == 64) hipLaunchKernelGGL(ffn_fwd_fused_kernel<64>, dim3((unsigned)(groups * 8)), dim3(256), 0, st, f);
   else hipLaunchKernelGGL(ffn_fwd_fused_kernel<128>, dim3((unsigned)(groups * 8)), dim3(256), 0, st, f);
@@ -1447,7 +1458,7 @@ int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, con
 
 int xf_ffn_bwd_dx_fused_ex(const void* dy16, const void* w2_16, const void* u16, const void* w1_16, void* di16, int64_t M,
                            int32_t H, int32_t I, const float* residual_grad, const float* ln_x, const float* ln_mean,
-                           const float* ln_rstd, const float* ln_gamma, float dropout_p, uint64_t seed, uint32_t site,
+                           const float* ln_rstd, const float* ln_gamma, float dropout_p, XfSeed seed, uint32_t site,
                            float* dx, void* d_lin16, float* partials, int* blocks_out, hipStream_t st) {
   if (!dy16 || !w2_16 || !u16 || !w1_16 || !di16 || !ln_x || !ln_mean || !ln_rstd || !ln_gamma || !dx || !partials ||
       !blocks_out || M <= 0)
@@ -1499,7 +1510,7 @@ int xf_linear_bwd_dx_ex(const void* dy, const float* w, void* dx, int64_t M, int
 
 int xf_linear_bwd_dx_lnbwd_ex(const void* dy, const float* w, int64_t M, int32_t N, int32_t K,
                               const float* residual_grad, const float* ln_x, const float* ln_mean, const float* ln_rstd,
-                              const float* ln_gamma, float dropout_p, uint64_t seed, uint32_t site, float* dx,
+                              const float* ln_gamma, float dropout_p, XfSeed seed, uint32_t site, float* dx,
                               void* d_lin16, float* partials, int* blocks_out, int32_t precision, uint32_t s16,
                               hipStream_t st, float out_dropout_p, uint32_t out_site) {
   if (!dy || !w || !dx || !ln_x || !ln_mean || !ln_rstd || !ln_gamma || !partials || !blocks_out || M <= 0 || N <= 0)

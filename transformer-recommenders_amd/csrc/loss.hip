@@ -691,8 +691,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double* blockpar
   if (threadIdx.x == 0) tot[k] = red[0];
 }
 // stage 2: one thread turns the 24 totals into the 14 loss values and the statistics
-__global__ void loss_final_kernel(const double* tot, const int* counts, int mode, int64_t n_rows, float* losses,
-                                  float* stats) {
+__global__ void loss_final_kernel(const double* tot, const int* counts, int mode, int64_t n_rows, int64_t positions,
+                                  float* losses, float* stats) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int Nq = counts[1];
     for (int k = 0; k < XFMR_NUM_LOSSES; ++k) {
@@ -704,6 +704,10 @@ __global__ void loss_final_kernel(const double* tot, const int* counts, int mode
     stats[XFMR_STAT_N_VALID] = (float)((mode == XFMR_NEG_CATALOG) ? (int)n_rows : counts[0]);
     stats[XFMR_STAT_N_QUERY] = (float)Nq;
     stats[XFMR_STAT_NEG_DISTINCT] = (float)((mode == XFMR_NEG_CATALOG) ? (int)n_rows : counts[2]);
+    // batch/positive_density, batch/attention_density (trainer.py:241-249): on the device, so that the step's logged
+    // values need no host arithmetic (and no host sync)
+    stats[XFMR_STAT_POS_DENSITY] = (float)(nq / ((double)counts[0] + 1e-9));
+    stats[XFMR_STAT_ATTN_DENSITY] = (float)((double)counts[0] / ((double)positions + 1e-9));
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     stats[XFMR_STAT_NEG_DENSITY] = (float)(Nq > 0 ? tot[8] / nq : nan);
     stats[XFMR_STAT_POS_MEAN] = (float)(Nq > 0 ? tot[9] / nq : nan);
@@ -737,7 +741,8 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   int64_t ns = (1024 + qblocks / 2) / qblocks;  // ~1024 workgroups: two full rounds at 2 workgroups/CU
   if (ns > 16) ns = 16;
   if (ns < 2) ns = 2;  // measured at 800 query blocks (B = 512): 2 splits 95.5k seq/s, 1 split 94.1k
-  if (const char* e = getenv("XFMR_LOSS_NSPLIT")) ns = atoi(e);  // tuning experiments
+  static const int ns_env = [] { const char* e = getenv("XFMR_LOSS_NSPLIT"); return e ? atoi(e) : 0; }();  // tuning experiments
+  if (ns_env > 0) ns = ns_env;
   if (ns > tiles) ns = tiles;
   if (ns < 1) ns = 1;
   p.nsplit = (int)ns;
@@ -798,33 +803,17 @@ int launch_dma_h(const LossArgs& a, const void* tbf, int H, int head, dim3 grid,
   }
 }
 
-// one-shot, per host thread: events recorded around the NEXT main-kernel launch (measurement only)
-thread_local hipEvent_t g_prof_start = nullptr;
-thread_local hipEvent_t g_prof_stop = nullptr;
-thread_local int g_prof_which = 0;  // XFMR_PROFILE_GRADIENT_PASS / XFMR_PROFILE_LOGGING_PASS
-
 }  // namespace
 
 extern "C" {
 
 int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, const int* counts, int mode,
-                     int64_t n_rows, float* losses, float* stats, double* tot, hipStream_t st) {
+                     int64_t n_rows, int64_t positions, float* losses, float* stats, double* tot, hipStream_t st) {
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(BP), dim3(256), 0, st, blockpart, nblocks, rows_per_block, counts, tot);
   XF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)tot, counts, mode, n_rows, losses,
-                     stats);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)tot, counts, mode, n_rows, positions,
+                     losses, stats);
   XF_LAUNCH_CHECK();
-  return XFMR_OK;
-}
-
-int xfmr_sampled_loss_profile_next(void* start_event, void* stop_event) {
-  return xfmr_sampled_loss_profile_pass(start_event, stop_event, XFMR_PROFILE_GRADIENT_PASS);
-}
-int xfmr_sampled_loss_profile_pass(void* start_event, void* stop_event, int32_t which) {
-  if (which != XFMR_PROFILE_GRADIENT_PASS && which != XFMR_PROFILE_LOGGING_PASS) return XFMR_EINVAL;
-  g_prof_start = (hipEvent_t)start_event;
-  g_prof_stop = (hipEvent_t)stop_event;
-  g_prof_which = which;
   return XFMR_OK;
 }
 
@@ -859,29 +848,17 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   // blocks: the pass itself takes the same time with 1, 2 or 3 splits (387 us). XFMR_LOSS_NSPLIT_GRAD overrides (experiments).
   int ns_grad = p.nsplit;
   if (grid.x >= 512) ns_grad = 1;
-  if (const char* e = getenv("XFMR_LOSS_NSPLIT_GRAD")) ns_grad = atoi(e);
+  static const int ns_grad_env = [] { const char* e = getenv("XFMR_LOSS_NSPLIT_GRAD"); return e ? atoi(e) : 0; }();
+  if (ns_grad_env > 0) ns_grad = ns_grad_env;
   if (ns_grad < 1) ns_grad = 1;
   if (ns_grad > p.nsplit) ns_grad = p.nsplit;  // (the workspace is carved for p.nsplit)
   int ns_part = p.nsplit;  // split count the records in a.part (and partO) are written with
   bool fused_finish = false;
   int rc;
-  // one-shot measurement hook. XFMR_PROFILE_GRADIENT_PASS: events around the main kernel of THIS call (its gradient
-  // pass, or its only pass). XFMR_PROFILE_LOGGING_PASS: events around the values-only logging pass of a call that runs
-  // one beside a gradient pass, or alone with every head (all_heads != 0); other calls leave the request pending.
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, lev0 = nullptr, lev1 = nullptr;
-  if (g_prof_start) {
-    const bool dma = cfg->num_hard_negatives == 0 && cfg->precision == XFMR_PREC_BF16 && table_bf16;
-    const bool gp = d_tok != nullptr && cfg->train_head != XFMR_LOSS_ALIGNMENT;
-    const bool has_log = dma && cfg->all_heads != 0;
-    if (g_prof_which == XFMR_PROFILE_GRADIENT_PASS) {
-      ev0 = g_prof_start; ev1 = g_prof_stop;
-      g_prof_start = g_prof_stop = nullptr;
-    } else if (has_log) {
-      if (gp) { lev0 = g_prof_start; lev1 = g_prof_stop; }
-      else { ev0 = g_prof_start; ev1 = g_prof_stop; }  // the logging pass IS this call's only main kernel
-      g_prof_start = g_prof_stop = nullptr;
-    }
-  }
+  // measurement events (xfmr_loss_cfg): profile_grad around the gradient pass -- or around the call's single main kernel
+  // when it runs the generic kernel --, profile_log around the values-only logging pass of the bf16 production path
+  hipEvent_t ev0 = (hipEvent_t)cfg->profile_grad[0], ev1 = (hipEvent_t)cfg->profile_grad[1];
+  hipEvent_t lev0 = (hipEvent_t)cfg->profile_log[0], lev1 = (hipEvent_t)cfg->profile_log[1];
   const float* part_loss = nullptr;  // records the loss VALUES are read from (null: the same as the gradient's)
   bool lse_from_grad = false;        // InfoNCE value from the gradient pass's records (logging pass ran without it)
   const bool hard = cfg->num_hard_negatives > 0;
@@ -949,7 +926,6 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       b.nsplit = p.nsplit; b.d_tok = nullptr;
       if (grad_pass) b.part = (float*)(ws + p.off_part2);
       b.need_grad = 0;
-      if (!grad_pass && ev0 && hipEventRecord(ev0, st) != hipSuccess) return XFMR_EHIP;
       // all_heads == 2: the train head's value is not wanted from this call (the caller has it from the gradient
       // pass of the same step): for InfoNCE that drops the log-sum-exp from the per-logit work
       // ... and likewise when the gradient pass of THIS call is the InfoNCE one: the combine kernel then takes the
@@ -957,11 +933,10 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       const bool lse_elsewhere = cfg->train_head == XFMR_LOSS_INFONCE && (grad_pass || cfg->all_heads == 2);
       lse_from_grad = lse_elsewhere && grad_pass;
       const int code = lse_elsewhere ? -2 : -1;
-      if (grad_pass && lev0 && hipEventRecord(lev0, st) != hipSuccess) return XFMR_EHIP;
+      if (lev0 && hipEventRecord(lev0, st) != hipSuccess) return XFMR_EHIP;
       rc = launch_dma_h(b, table_bf16, H, code, grid, st);
       if (rc) return rc;
-      if (grad_pass && lev1 && hipEventRecord(lev1, st) != hipSuccess) return XFMR_EHIP;
-      if (!grad_pass && ev1 && hipEventRecord(ev1, st) != hipSuccess) return XFMR_EHIP;
+      if (lev1 && hipEventRecord(lev1, st) != hipSuccess) return XFMR_EHIP;
       if (grad_pass) part_loss = b.part;
     }
     }
@@ -990,12 +965,12 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
     const int nb = (T + kValueRows - 1) / kValueRows;
     hipLaunchKernelGGL(loss_combine_kernel<true>, dim3(nb), dim3(256), 0, st, c);
     XF_LAUNCH_CHECK();
-    return xf_loss_finalize(c.blockpart, nb, kValueRows, counts, cfg->mode, n_rows, losses, stats,
+    return xf_loss_finalize(c.blockpart, nb, kValueRows, counts, cfg->mode, n_rows, T, losses, stats,
                             (double*)(ws + p.off_tot), st);
   }
   hipLaunchKernelGGL(loss_combine_kernel<false>, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
-  return xf_loss_finalize(c.blockpart, p.nblocks, kCombineRows, counts, cfg->mode, n_rows, losses, stats,
+  return xf_loss_finalize(c.blockpart, p.nblocks, kCombineRows, counts, cfg->mode, n_rows, T, losses, stats,
                           (double*)(ws + p.off_tot), st);
 }
 
@@ -1054,7 +1029,6 @@ int xfmr_sampled_loss_prepare(const xfmr_loss_cfg* cfg, const uint8_t* key_mask,
   return XFMR_OK;
 }
 
-static thread_local bool g_dtok_zeroed = false;
 // ... and the rest, on a workspace xfmr_sampled_loss_prepare filled for the SAME cfg / key mask / index tensors / sizes.
 int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,
                                const int64_t* neg_idx, const float* table, const float* table_rnorm, const void* table_bf16,
@@ -1067,17 +1041,11 @@ int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const
   const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0);
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const bool zeroed = g_dtok_zeroed;  // (one-shot) the caller zeroed d_tok itself: xfmr_sampled_loss_dtok_is_zeroed
-  g_dtok_zeroed = false;
+  const bool zeroed = (cfg->flags & XFMR_LOSS_DTOK_ZEROED) != 0;  // the caller zeroed d_tok itself
   if (d_tok && !zeroed && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
   return run_loss(cfg, tok, table, table_rnorm, table_bf16, n_rows, (int)positions, H, losses, stats, d_tok,
                   (unsigned char*)workspace, p, st);
-}
-
-int xfmr_sampled_loss_dtok_is_zeroed(void) {
-  g_dtok_zeroed = true;
-  return XFMR_OK;
 }
 
 int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,

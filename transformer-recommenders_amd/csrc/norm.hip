@@ -26,7 +26,10 @@ struct LnFwdArgs {
 };
 
 template <int NPL, bool GATHER>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_in) {
+  LnFwdArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
@@ -99,7 +102,10 @@ struct LnBwdArgs {
 };
 
 template <int NPL>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_in) {
+  LnBwdArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop_out = xf_drop_resolve(a.drop_out); a.drop_lin = xf_drop_resolve(a.drop_lin);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [4][3][H]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int H = a.H;
@@ -176,7 +182,10 @@ __device__ __forceinline__ float row_sum(float v) {
 }
 
 template <int LPR, bool GATHER>
-__global__ __launch_bounds__(256) void ln_fwd_v4_kernel(LnFwdArgs a) {
+__global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const LnFwdArgs a_in) {
+  LnFwdArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
   constexpr int H = 4 * LPR, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int sub = lane / LPR, li = lane % LPR, c = li * 4;
@@ -222,7 +231,10 @@ __global__ __launch_bounds__(256) void ln_fwd_v4_kernel(LnFwdArgs a) {
 }
 
 template <int LPR>
-__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(LnBwdArgs a) {
+__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const LnBwdArgs a_in) {
+  LnBwdArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop_out = xf_drop_resolve(a.drop_out); a.drop_lin = xf_drop_resolve(a.drop_lin);
   constexpr int H = 4 * LPR, RPW = 64 / LPR;
   __shared__ float red[4][3][H];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -405,10 +417,18 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* dy, const 
   for (int c = lane; c < H; c += 64) dx[row * H + c] = inv * (dy[row * H + c] - y[row * H + c] * d);
 }
 
+// step_dev != nullptr: the step count comes from device memory (a captured step replays with the right bias
+// corrections): step = *step_dev + step_off, corrections evaluated in double as the host does for the by-value form.
 __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
-                             float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                             float eps, float wd, float bc1, float bc2_sqrt, float gscale, const uint32_t* step_dev,
+                             int step_off) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
+  if (step_dev) {
+    const double t = (double)((int64_t)*step_dev + step_off);
+    bc1 = (float)(1.0 - pow((double)b1, t));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  }
   if (i + 3 < n) {
     float4 pp = *reinterpret_cast<float4*>(p + i);
     const float4 gg = *reinterpret_cast<const float4*>(g + i);
@@ -519,7 +539,7 @@ int xfmr_embed_ln_fwd(const int64_t* item_idx, const float* table, int64_t n_row
 int xf_embed_ln_fwd_ex(const int64_t* item_idx, const float* table, int64_t n_rows, const float* pos_emb,
                        const float* type_emb, const float* gamma, const float* beta, float* out, void* out16,
                        float* pre, float* mean, float* rstd, uint8_t* key_mask, int32_t B, int32_t L, int32_t H,
-                       float eps, float dropout_p, uint64_t seed, uint32_t site, hipStream_t stream) {
+                       float eps, float dropout_p, XfSeed seed, uint32_t site, hipStream_t stream) {
   if (!item_idx || !table || !pos_emb || !type_emb || !gamma || !beta || !out || !pre || !mean || !rstd || !key_mask)
     return XFMR_EINVAL;
   if (B <= 0 || L <= 0 || H <= 0 || n_rows <= 0) return XFMR_EINVAL;
@@ -651,7 +671,29 @@ int xfmr_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg
   const int64_t threads = (n + 3) / 4;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-                     (float)sqrt(bc2), grad_scale);
+                     (float)sqrt(bc2), grad_scale, (const uint32_t*)nullptr, 0);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+int xfmr_adamw_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, const uint32_t* step_device,
+                   int32_t step_offset, float grad_scale, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || !step_device) return XFMR_EINVAL;
+  if (!xf_aligned16(params) || !xf_aligned16(grads) || !xf_aligned16(exp_avg) || !xf_aligned16(exp_avg_sq))
+    return XFMR_EALIGN;
+  const int64_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale,
+                     step_device, (int)step_offset);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
+}
+
+__global__ void step_advance_kernel(uint32_t* c) { *c += 1; }
+int xfmr_step_advance(uint32_t* step_device, void* stream) {
+  if (!step_device) return XFMR_EINVAL;
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_device);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }

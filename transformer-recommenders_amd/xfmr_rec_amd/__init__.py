@@ -6,9 +6,9 @@ interfaces over hand-written gfx950 HIP kernels (``libxfmr_hip.so``, C ABI in ``
 
 from .losses import LOSS_CLASSES, EmbedLoss, LossConfig, LossType  # noqa: F401
 from .models import ModelConfig, RecommenderModel  # noqa: F401
-from .trainer import FusedAdamW, LightningConfig, RecommenderLightningModule, Trainer  # noqa: F401
+from .trainer import FusedAdamW, GraphedStep, LightningConfig, RecommenderLightningModule, Trainer  # noqa: F401
 
 __all__ = [
     "LOSS_CLASSES", "EmbedLoss", "LossConfig", "LossType", "ModelConfig", "RecommenderModel",
-    "FusedAdamW", "LightningConfig", "RecommenderLightningModule", "Trainer",
+    "FusedAdamW", "GraphedStep", "LightningConfig", "RecommenderLightningModule", "Trainer",
 ]

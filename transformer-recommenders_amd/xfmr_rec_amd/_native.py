@@ -21,9 +21,11 @@ PREC_F32, PREC_BF16 = 0, 1
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES = 0, 1, 2
 NEG_SHARED, NEG_CATALOG = 0, 1
-PROFILE_GRADIENT_PASS, PROFILE_LOGGING_PASS = 0, 1  # xfmr_sampled_loss_profile_pass
 ATTN_CAUSAL, ATTN_BIDIRECTIONAL = 0, 1  # xfmr_attn_{fwd,bwd}_mode
-ENC_BIDIRECTIONAL = 1  # xfmr_encoder_cfg.flags
+# xfmr_encoder_cfg.flags
+ENC_BIDIRECTIONAL, ENC_LN_UNFUSED, ENC_FFN_UNFUSED, ENC_FFN_BWD_UNFUSED, ENC_DW_INLINE = 1, 2, 4, 8, 16
+LOSS_DTOK_ZEROED = 1  # xfmr_loss_cfg.flags
+ABI_VERSION = 2
 NUM_LOSSES, NUM_STATS = 7, 16
 LOSS_IDS = {
     "AlignmentLoss": 0,
@@ -36,7 +38,7 @@ LOSS_IDS = {
 }
 STAT = dict(
     n_valid=0, n_query=1, neg_density=2, pos_mean=3, pos_std=4, pos_min=5, pos_max=6,
-    neg_mean=7, neg_std=8, neg_min=9, neg_max=10, neg_count=11, neg_distinct=12,
+    neg_mean=7, neg_std=8, neg_min=9, neg_max=10, neg_count=11, neg_distinct=12, pos_density=13, attn_density=14,
 )
 
 
@@ -46,6 +48,7 @@ class EncoderCfg(C.Structure):
         ("inter", C.c_int32), ("layers", C.c_int32), ("max_pos", C.c_int32), ("precision", C.c_int32),
         ("ln_eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float),
         ("flags", C.c_uint32), ("seed", C.c_uint64),
+        ("step_device", C.c_void_p), ("embed_event", C.c_void_p), ("context", C.c_void_p),
     ]
 
 
@@ -53,8 +56,20 @@ class LossCfg(C.Structure):
     _fields_ = [
         ("train_head", C.c_int32), ("all_heads", C.c_int32), ("mask_false_negatives", C.c_int32),
         ("mode", C.c_int32), ("precision", C.c_int32), ("scale", C.c_float), ("margin", C.c_float),
-        ("num_hard_negatives", C.c_int32),
+        ("num_hard_negatives", C.c_int32), ("flags", C.c_uint32),
+        ("profile_grad", C.c_void_p * 2), ("profile_log", C.c_void_p * 2),
     ]
+
+
+class Seed(C.Structure):
+    """csrc/common.h XfSeed, by value: the dropout seed argument of the library's INTERNAL entry points (xf_*_ex; tests and
+    probes call a few of them directly). A plain int converts to (seed, no device-side counter)."""
+
+    _fields_ = [("seed", C.c_uint64), ("dyn", C.c_void_p)]
+
+    @classmethod
+    def from_param(cls, v):
+        return v if isinstance(v, cls) else cls(int(v), None)
 
 
 TARGET_FIRST, TARGET_DIAGONAL, TARGET_EXPLICIT = 0, 1, 2
@@ -65,8 +80,18 @@ _SIGNATURES = {
     "xfmr_strerror": (C.c_char_p, [C.c_int]),
     "xfmr_abi_version": (C.c_int, []),
     "xfmr_low_priority_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
-    "xfmr_encoder_fwd_mark_embed": (C.c_int, [_P]),
+    "xfmr_context_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "xfmr_context_destroy": (C.c_int, [_P]),
     "xfmr_stream_destroy": (C.c_int, [_P]),
+    "xfmr_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "xfmr_event_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
+    "xfmr_event_destroy": (C.c_int, [_P]),
+    "xfmr_event_record": (C.c_int, [_P, _P]),
+    "xfmr_stream_wait_event": (C.c_int, [_P, _P]),
+    "xfmr_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "xfmr_event_synchronize": (C.c_int, [_P]),
+    "xfmr_event_query": (C.c_int, [_P]),
+    "xfmr_batch_upload": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
     "xfmr_param_count": (C.c_int64, [C.POINTER(EncoderCfg)]),
     "xfmr_param_offsets": (C.c_int32, [C.POINTER(EncoderCfg), C.POINTER(C.c_int64), C.c_int32]),
     "xfmr_embed_ln_fwd": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
@@ -102,7 +127,6 @@ _SIGNATURES = {
     "xfmr_sampled_loss_workspace_cfg": (C.c_size_t, [C.POINTER(LossCfg), C.c_int64, C.c_int32, C.c_int64]),
     "xfmr_sampled_loss": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32,
                                     _P, _P, _P, _P, C.c_size_t, _P]),
-    "xfmr_sampled_loss_dtok_is_zeroed": (C.c_int, []),
     "xfmr_sampled_loss_prepare": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P,
                                             C.c_size_t, _P]),
     "xfmr_sampled_loss_prepared": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64,
@@ -117,8 +141,6 @@ _SIGNATURES = {
                                   _P, _P, C.c_size_t, _P]),
     "xfmr_dense_loss_grads": (C.c_int, [C.POINTER(LossCfg), _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P,
                                         _P, _P, _P, _P, C.c_size_t, _P]),
-    "xfmr_sampled_loss_profile_next": (C.c_int, [_P, _P]),
-    "xfmr_sampled_loss_profile_pass": (C.c_int, [_P, _P, C.c_int32]),
     "xfmr_table_rnorm": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "xfmr_table_prepare": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     "xfmr_seq_sample_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
@@ -130,6 +152,9 @@ _SIGNATURES = {
     "xfmr_retrieval_metrics": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "xfmr_adamw": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                              C.c_int64, C.c_float, _P]),
+    "xfmr_adamw_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 _P, C.c_int32, C.c_float, _P]),
+    "xfmr_step_advance": (C.c_int, [_P, _P]),
     "xfmr_scale_by_device_scalar": (C.c_int, [_P, C.c_int64, _P, _P]),
     "xfmr_selftest_mfma": (C.c_int, [_P, _P]),
 }
@@ -157,6 +182,10 @@ def load() -> C.CDLL:
         lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
     except OSError as e:  # pragma: no cover - depends on the host
         raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    got = lib.xfmr_abi_version() if hasattr(lib, "xfmr_abi_version") else None
+    if got != ABI_VERSION:  # checked before binding the symbols: an older build fails here with a version message
+        raise NativeLibraryError(f"{LIB_PATH}: ABI version {got}, this package binds version {ABI_VERSION}: rebuild the "
+                                 "library (python -c 'import __graft_entry__ as g; g.build()')")
     for name, (res, args) in _SIGNATURES.items():
         try:
             fn = getattr(lib, name)
@@ -164,8 +193,6 @@ def load() -> C.CDLL:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.xfmr_abi_version() != 1:
-        raise NativeLibraryError("libxfmr_hip.so ABI version mismatch: rebuild the library")
     _lib = lib
     return lib
 

@@ -87,3 +87,124 @@ class DeviceSeqDataset:
             "xfmr_seq_sample",
         )
         return {"history_item_idx": out[0], "pos_item_idx": out[1], "neg_item_idx": out[2]}
+
+
+SEQ_BATCH_KEYS = ("history_item_idx", "pos_item_idx", "neg_item_idx")  # the index tensors of SeqBatch (data.py:534-540)
+
+
+class PinnedBatchRing:
+    """Host -> HBM hand-over of collated batches: the step-side half of the reference's ``DataLoader(pin_memory=True)``
+    + Lightning batch transfer (``xfmr_rec/data.py:915-927``).
+
+    ``slots`` persistent device blocks of ``(3, batch, width)`` int64 (+ as many page-locked host blocks for batches
+    that arrive in pageable memory), one copy stream, and per slot one "ready" and one "free" event -- all created
+    ONCE. Per batch: one ``hipMemcpyAsync`` on the copy stream, two event records and one stream wait
+    (``xfmr_batch_upload``); no allocation, no new event or stream object. The copy of batch i + 1 runs underneath step
+    i (``stage`` is called right after ``take``). A slot is reused ``slots`` batches later; ``stage`` waits on the host
+    for the step that last read it, i.e. only when the host has run a whole ring ahead of the GPU (bounded run-ahead --
+    a stream-side wait in front of the copy would make the copy call itself block: ``include/xfmr_hip.h``).
+
+        ring = PinnedBatchRing(device, batch=512, width=200)
+        ring.stage(first_batch)
+        for nxt in batches:              # dicts of (B, L) int64 CPU tensors, or one pinned (3, B, L) block
+            dev_batch = ring.take()      # current stream waits for the copy; returns views of the device slot
+            ring.stage(nxt)              # in flight while this step computes
+            step(dev_batch)
+    """
+
+    def __init__(self, device, batch: int, width: int, slots: int = 6):
+        import ctypes
+
+        self.device = torch.device(device)
+        self.slots = int(slots)
+        self.shape = (3, int(batch), int(width))
+        self.lib = N.load()
+        with torch.cuda.device(self.device):
+            self.dev = [torch.zeros(self.shape, dtype=torch.int64, device=self.device) for _ in range(self.slots)]
+            self.host = [torch.zeros(self.shape, dtype=torch.int64).pin_memory() for _ in range(self.slots)]
+            h = ctypes.c_void_p()
+            N.check(self.lib.xfmr_stream_create(ctypes.byref(h)), "xfmr_stream_create")
+            self.copy_stream = h.value
+            self.ready, self.free = [], []
+            for _ in range(self.slots):
+                for lst in (self.ready, self.free):
+                    e = ctypes.c_void_p()
+                    N.check(self.lib.xfmr_event_create(ctypes.byref(e), 0), "xfmr_event_create")
+                    lst.append(e.value)
+        self.used = [False] * self.slots  # slot read by a step at least once (its free event has been recorded)
+        self.shapes = [self.shape] * self.slots
+        self.head = 0  # next slot to stage into
+        self.tail = 0  # next slot to take
+        self.pending = 0
+
+    def stage(self, batch) -> None:
+        """Start the copy of one collated batch into the next slot. ``batch``: a dict with the three ``(B, L)`` int64 CPU
+        index tensors (B <= batch, L <= width of this ring) or one contiguous ``(3, B, L)`` int64 CPU tensor (the collate
+        output kept as one block). Page-locked input is copied from where it lies; pageable input goes through the
+        slot's own page-locked block first (a host memcpy)."""
+        if self.pending >= self.slots:
+            raise RuntimeError("PinnedBatchRing: every slot holds a batch that has not been taken")
+        s = self.head
+        blk = batch if isinstance(batch, torch.Tensor) else None
+        if blk is None:
+            parts = [batch[k] for k in SEQ_BATCH_KEYS]
+            shape = (3, *parts[0].shape)
+        else:
+            shape = tuple(blk.shape)
+        if len(shape) != 3 or shape[0] != 3 or shape[1] > self.shape[1] or shape[2] > self.shape[2]:
+            raise ValueError(f"batch of shape {shape} does not fit the ring's slots {self.shape}")
+        if blk is None or not (blk.is_pinned() and blk.is_contiguous() and blk.dtype == torch.int64):
+            dst = self.host[s].view(-1)[: shape[0] * shape[1] * shape[2]].view(shape)
+            if blk is None:
+                for i, p in enumerate(parts):
+                    dst[i].copy_(p)
+            else:
+                dst.copy_(blk)
+            blk = dst
+        nbytes = 8 * shape[0] * shape[1] * shape[2]
+        N.check(self.lib.xfmr_batch_upload(self.dev[s].data_ptr(), blk.data_ptr(), nbytes, self.copy_stream,
+                                           self.free[s] if self.used[s] else None, self.ready[s]), "xfmr_batch_upload")
+        self._keep = blk  # the source must stay alive until the copy has been issued (it has: the call returned)
+        self.shapes[s] = shape
+        self.head = (s + 1) % self.slots
+        self.pending += 1
+
+    def take(self) -> dict[str, torch.Tensor]:
+        """The oldest staged batch as device tensors (views of its slot); the current stream waits for its copy. The
+        slot is handed back by the NEXT ``take`` / ``release`` (its free event is recorded on the current stream then),
+        i.e. the returned tensors are valid for the step that follows this call."""
+        if self.pending == 0:
+            raise RuntimeError("PinnedBatchRing.take: nothing staged")
+        self.release()
+        s = self.tail
+        N.check(self.lib.xfmr_stream_wait_event(N.stream(), self.ready[s]), "xfmr_stream_wait_event")
+        self.tail = (s + 1) % self.slots
+        self.pending -= 1
+        self._held = s
+        shape = self.shapes[s]
+        v = self.dev[s].view(-1)[: shape[0] * shape[1] * shape[2]].view(shape)
+        return {k: v[i] for i, k in enumerate(SEQ_BATCH_KEYS)}
+
+    def release(self) -> None:
+        """Mark the slot of the last ``take`` as read: everything enqueued on the current stream so far is ahead of the
+        next copy into it."""
+        s = getattr(self, "_held", None)
+        if s is not None:
+            N.check(self.lib.xfmr_event_record(self.free[s], N.stream()), "xfmr_event_record")
+            self.used[s] = True
+            self._held = None
+
+    def close(self) -> None:
+        if getattr(self, "copy_stream", None):
+            torch.cuda.synchronize(self.device)
+            for e in self.ready + self.free:
+                self.lib.xfmr_event_destroy(e)
+            self.lib.xfmr_stream_destroy(self.copy_stream)
+            self.copy_stream = None
+            self.ready, self.free = [], []
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -11,8 +11,11 @@ Differences that are deliberate and visible:
   fp32 ``nn.Parameter`` (``self.flat``); ``encoder_state_dict()`` exposes them under the HF BERT key names
   the reference checkpoints use, and ``load_encoder_state_dict()`` takes the same.
   ``word_embeddings`` / ``pooler`` never receive a gradient in the reference and are not created.
-* Nothing is fetched from the network: ``hidden_size`` etc. must be given (the reference resolves ``None``
-  from a pretrained model download, ``models.py:85-91``).
+* Nothing is fetched from the network. ``None`` fields of ``ModelConfig`` (the reference's own ``config.yaml``
+  leaves ``hidden_size: null``) are resolved offline: from the published config of ``pretrained_model_name`` when it
+  is a known model (``params.KNOWN_PRETRAINED`` -- what the reference's ``AutoModel.from_pretrained`` would return,
+  ``models.py:69-91``), else ``hidden_size = 32 x num_attention_heads`` (the head size of the kernels); the item
+  table's width is checked against it in ``configure_embeddings``.
 * ``compute_embeds`` returns the candidates structured (:class:`~xfmr_rec_amd.losses.SharedNegatives`)
   rather than as the materialised ``(Np, 1+N, H)`` tensor.
 """
@@ -33,6 +36,7 @@ from .params import (
     ATTENTION_PROBS_DROPOUT_PROB,
     HIDDEN_DROPOUT_PROB,
     INITIALIZER_RANGE,
+    KNOWN_PRETRAINED,
     LAYER_NORM_EPS,
     PRETRAINED_MODEL_NAME,
 )
@@ -123,15 +127,32 @@ class RecommenderModel(torch.nn.Module):
             self.load_encoder_state_dict(model)
 
     # ------------------------------------------------------------------ construction
-    def configure_model(self, device=None, seed: int = 0) -> None:
-        c = self.config
+    @staticmethod
+    def resolve_config(config: ModelConfig) -> ModelConfig:
+        """Fill the ``None`` fields of ``config`` in place, offline (``models.py:69-91`` does it by downloading
+        ``pretrained_model_name``): a known model's published config first; otherwise ``hidden_size`` follows from the
+        head count (head size 32). Anything still missing raises."""
+        known = KNOWN_PRETRAINED.get(config.pretrained_model_name, {})
+        for k in ("vocab_size", "max_seq_length", "hidden_size", "num_hidden_layers", "num_attention_heads",
+                  "intermediate_size"):
+            if getattr(config, k) is None and k in known:
+                setattr(config, k, known[k])
+        if config.hidden_size is None and config.num_attention_heads is not None:
+            config.hidden_size = 32 * config.num_attention_heads
+        if config.num_attention_heads is None and config.hidden_size is not None and config.hidden_size % 32 == 0:
+            config.num_attention_heads = config.hidden_size // 32
         missing = [k for k in ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
-                               "max_seq_length") if getattr(c, k) is None]
+                               "max_seq_length") if getattr(config, k) is None]
         if missing:
             raise ValueError(
-                f"ModelConfig fields {missing} are None: the reference resolves them by downloading "
-                f"{c.pretrained_model_name!r} (models.py:69-91); this build is offline -- set them explicitly"
+                f"ModelConfig fields {missing} are None and {config.pretrained_model_name!r} is not in "
+                f"params.KNOWN_PRETRAINED: the reference resolves them by downloading that model (models.py:69-91); "
+                f"this build is offline -- set them explicitly"
             )
+        return config
+
+    def configure_model(self, device=None, seed: int = 0) -> None:
+        c = self.resolve_config(self.config)
         if c.hidden_size != 32 * c.num_attention_heads:
             raise ValueError(
                 f"hidden_size / num_attention_heads must be 32 (got {c.hidden_size}/{c.num_attention_heads}): "
@@ -218,24 +239,95 @@ class RecommenderModel(torch.nn.Module):
 
     def set_table(self, table: torch.Tensor) -> None:
         """Install a ready ``(V+1, H)`` table (row 0 = padding)."""
+        if table.dim() != 2 or table.shape[1] != self.config.hidden_size:
+            raise ValueError(
+                f"item table of shape {tuple(table.shape)} does not match hidden_size {self.config.hidden_size}: "
+                "embeddings enter the encoder as inputs_embeds without projection (models.py:336-345)")
         self.embeddings = table.contiguous()
         # frozen table => per-item inverse norms and the bf16 gather copy are computed once
         self.table_rnorm, self.table_bf16 = ops.table_prepare(self.embeddings) if table.is_cuda else (None, None)
 
+    def load_table(self, path, *, column: str = "embedding", id_column: str = "item_id", has_padding_row=None) -> None:
+        """Install the frozen item table from a FILE (SURVEY section 8f-4: "optionally accept any (V,H) table file";
+        the reference only ever gets it through ``items_dataset``, ``models.py:234-259``).
+
+        ``.npy`` (``allow_pickle=False``), ``.safetensors`` / ``.pt`` (``weights_only=True``): one 2-D float array, or a
+        dict holding it under ``column`` (``"embeddings.weight"`` -- the reference module's own key -- is also looked up);
+        ``.parquet``: the ``items.parquet`` layout of ``data.py:395-411`` -- a list column ``column`` plus ``id_column``,
+        which also builds ``id2idx``. A ``(V, H)`` array gets the zero padding row prepended as ``configure_embeddings``
+        does; ``has_padding_row=True`` (or an all-zero first row when left ``None``) says it is ``(V+1, H)`` already."""
+        import numpy as np
+
+        path = pathlib.Path(path)
+        suffix = path.suffix.lower()
+        ids = None
+        if suffix == ".npy":
+            arr = torch.from_numpy(np.load(path, allow_pickle=False))
+        elif suffix == ".safetensors":
+            from safetensors.torch import load_file
+
+            d = load_file(str(path))
+            arr = d[column] if column in d else d["embeddings.weight"] if "embeddings.weight" in d else next(iter(d.values()))
+        elif suffix in (".pt", ".pth", ".bin"):
+            d = torch.load(path, map_location="cpu", weights_only=True)
+            if isinstance(d, dict):
+                d = d[column] if column in d else d["embeddings.weight"] if "embeddings.weight" in d else next(iter(d.values()))
+            arr = torch.as_tensor(d)
+        elif suffix == ".parquet":
+            import pyarrow.parquet as pq
+
+            tbl = pq.read_table(str(path), columns=[c for c in (column, id_column) if c])
+            arr = torch.from_numpy(np.asarray(tbl.column(column).to_pylist(), dtype=np.float32))
+            if id_column in tbl.column_names:
+                ids = tbl.column(id_column).to_pylist()
+            has_padding_row = False if has_padding_row is None else has_padding_row
+        else:
+            raise ValueError(f"load_table: unsupported file type {suffix!r} (.npy, .safetensors, .pt, .parquet)")
+        arr = arr.to(torch.float32)
+        if arr.dim() != 2:
+            raise ValueError(f"load_table: expected a 2-D (V, H) array, got shape {tuple(arr.shape)}")
+        if has_padding_row is None:
+            has_padding_row = bool((arr[0] == 0).all())
+        if ids is not None:
+            self.embeddings = None
+            self.id2idx = None
+            self.configure_embeddings({"embedding": arr[1:] if has_padding_row else arr, "item_id": ids})
+            return
+        table = arr if has_padding_row else torch.cat([torch.zeros_like(arr[:1]), arr])
+        self.set_table(table.contiguous().to(self.device))
+
     # ------------------------------------------------------------------ compute
-    def _cfg(self, B: int, L: int) -> N.EncoderCfg:
+    def context(self):
+        """This model's ``xfmr_context`` (side stream of the backward's weight-gradient GEMMs), created on first use."""
+        ctx = getattr(self, "_context", None)
+        if ctx is None and self.flat.is_cuda:
+            ctx = self._context = ops.Context(self.device)
+        return ctx
+
+    def use_device_step(self, on: bool = True) -> None:
+        """Dropout streams keyed by a step counter in HBM (``xfmr_encoder_cfg.step_device``) instead of the host-side
+        step count: what a captured hipGraph of the training step needs (every replay a new mask). The counter is
+        advanced by the optimizer (``FusedAdamW(step_device=...)``) as the last launch of a step."""
+        self.step_device = torch.zeros(1, dtype=torch.int32, device=self.device) if on else None
+
+    def _cfg(self, B: int, L: int, embed_event=None) -> N.EncoderCfg:
         c = self.config
         train = self.training
+        step_dev = getattr(self, "step_device", None)
+        ctx = self.context() if train else None
         return ops.make_encoder_cfg(
             batch=B, seq_len=L, hidden=c.hidden_size, heads=c.num_attention_heads, inter=c.intermediate_size,
             layers=c.num_hidden_layers, max_pos=c.max_seq_length, precision=self.precision, ln_eps=LAYER_NORM_EPS,
             hidden_dropout=HIDDEN_DROPOUT_PROB if train else 0.0,
             attn_dropout=ATTENTION_PROBS_DROPOUT_PROB if train else 0.0,
-            seed=(self._seed * 0x9E3779B97F4A7C15 + self._step) & 0xFFFFFFFFFFFFFFFF,
+            # with a device-side counter the host-side part of the seed stays fixed (a captured launch replays it)
+            seed=(self._seed * 0x9E3779B97F4A7C15 + (0 if step_dev is not None else self._step)) & 0xFFFFFFFFFFFFFFFF,
             causal=bool(c.is_decoder),  # BertConfig(is_decoder=...) (models.py:355): False = key-padding mask only
+            step_device=step_dev if train else None, embed_event=embed_event,
+            context=ctx.handle if ctx is not None else None,
         )
 
-    def _encode_tokens(self, item_idx=None, item_embeds=None):
+    def _encode_tokens(self, item_idx=None, item_embeds=None, embed_event=None):
         assert self.embeddings is not None, "call configure_embeddings() first"
         if item_embeds is not None:
             # the gather kernel reads rows by index: use the given embeddings as the table
@@ -252,7 +344,7 @@ class RecommenderModel(torch.nn.Module):
             raise ValueError(msg)
         if self.training:
             self._step += 1
-        tok, key_mask = ops.EncoderFunction.apply(self.flat, idx, table, self._cfg(B, L))
+        tok, key_mask = ops.EncoderFunction.apply(self.flat, idx, table, self._cfg(B, L, embed_event))
         return tok, key_mask
 
     def forward(self, item_idx=None, *, item_embeds=None) -> dict[str, torch.Tensor]:

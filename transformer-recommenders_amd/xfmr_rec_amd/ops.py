@@ -8,6 +8,7 @@ arithmetic is never torch's.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -223,12 +224,24 @@ def l2_normalize(x, eps: float = 1e-12):
 
 
 def adamw_(params, grads, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=1,
-           grad_scale=1.0):
+           grad_scale=1.0, step_device=None):
+    """``step_device`` (int32 device tensor = completed steps): the step count is read on the device (``step`` ignored)."""
+    if step_device is not None:
+        N.check(
+            N.load().xfmr_adamw_dev(N.ptr(params), N.ptr(grads), N.ptr(exp_avg), N.ptr(exp_avg_sq), params.numel(), lr,
+                                    beta1, beta2, eps, weight_decay, N.ptr(step_device), 1, grad_scale, N.stream()),
+            "xfmr_adamw_dev",
+        )
+        return
     N.check(
         N.load().xfmr_adamw(N.ptr(params), N.ptr(grads), N.ptr(exp_avg), N.ptr(exp_avg_sq), params.numel(), lr, beta1,
                             beta2, eps, weight_decay, step, grad_scale, N.stream()),
         "xfmr_adamw",
     )
+
+
+def step_advance_(step_device):
+    N.check(N.load().xfmr_step_advance(N.ptr(step_device), N.stream()), "xfmr_step_advance")
 
 
 def sampled_loss_workspace(like, T, H, n_rows, *, train_head, all_heads=True, mask_false_negatives=True, mode=N.NEG_SHARED,
@@ -254,21 +267,25 @@ def sampled_loss_prepare(ws, key_mask, pos_idx, neg_idx, rnorm, n_rows, H, *, tr
 
 def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, all_heads=True,
                  mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
-                 need_grad=True, table_bf16=None, num_hard_negatives=0, workspace=None, prepared=False, d_tok_zeroed=None):
+                 need_grad=True, table_bf16=None, num_hard_negatives=0, workspace=None, prepared=False, d_tok_zeroed=None,
+                 profile_grad=None, profile_log=None):
     """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H). `workspace` (sampled_loss_workspace) +
     `prepared=True`: sampled_loss_prepare already ran on it; `d_tok_zeroed`: a zero-filled buffer like tok to take the
-    gradient (the call then skips its own memset)."""
+    gradient (the call then skips its own memset); `profile_grad` / `profile_log`: (start, stop) hipEvent_t handles
+    recorded around the gradient-pass / logging-pass kernel (measurement)."""
     H = tok.shape[-1]
     T = tok.numel() // H
     lib = N.load()
-    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives)
+    d_tok = (d_tok_zeroed if d_tok_zeroed is not None else torch.empty_like(tok)) if need_grad else None
+    flags = 0
+    if d_tok_zeroed is not None and need_grad:
+        assert d_tok.shape == tok.shape and d_tok.dtype == tok.dtype
+        flags |= N.LOSS_DTOK_ZEROED
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives,
+                    flags=flags, profile_grad=profile_grad, profile_log=profile_log)
     n_rows = table.shape[0]
     losses = _empty((2 * N.NUM_LOSSES,), tok)
     stats = _empty((N.NUM_STATS,), tok)
-    d_tok = (d_tok_zeroed if d_tok_zeroed is not None else torch.empty_like(tok)) if need_grad else None
-    if d_tok_zeroed is not None and need_grad:
-        assert prepared and d_tok.shape == tok.shape and d_tok.dtype == tok.dtype
-        N.check(lib.xfmr_sampled_loss_dtok_is_zeroed(), "xfmr_sampled_loss_dtok_is_zeroed")
     if workspace is None:
         assert not prepared
         nbytes = lib.xfmr_sampled_loss_workspace_cfg(C.byref(cfg), T, H, n_rows)
@@ -285,13 +302,18 @@ def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, a
 
 
 def _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision,
-              num_hard_negatives=0) -> N.LossCfg:
-    return N.LossCfg(
+              num_hard_negatives=0, *, flags=0, profile_grad=None, profile_log=None) -> N.LossCfg:
+    cfg = N.LossCfg(
         train_head=N.LOSS_IDS[train_head] if isinstance(train_head, str) else int(train_head),
         all_heads=int(all_heads), mask_false_negatives=int(mask_false_negatives), mode=mode,
         precision=N.precision_id(precision), scale=float(scale), margin=float(margin),
-        num_hard_negatives=int(num_hard_negatives),
+        num_hard_negatives=int(num_hard_negatives), flags=int(flags),
     )
+    if profile_grad is not None:  # (start, stop) hipEvent_t handles around the gradient-pass kernel
+        cfg.profile_grad[0], cfg.profile_grad[1] = profile_grad
+    if profile_log is not None:  # ... around the values-only logging pass
+        cfg.profile_log[0], cfg.profile_log[1] = profile_log
+    return cfg
 
 
 def dense_loss(query, cand, target=None, *, target_position="first", train_head, all_heads=False,
@@ -342,13 +364,67 @@ def sampled_loss_lists(query, pos_items, neg_items, table, rnorm, *, train_head,
 
 
 # ------------------------------------------------------------------------------------------------ encoder
+def _env_on(name: str) -> bool:
+    v = os.environ.get(name, "")
+    return bool(v) and v != "0"
+
+
+def encoder_flags_from_env() -> int:
+    """A/B switches -> xfmr_encoder_cfg.flags bits. Read when the cfg of a step is made, so the
+    forward and the backward of that step (which share the cfg) agree whatever happens to the environment in between."""
+    f = 0
+    if _env_on("XFMR_LN_UNFUSED"):
+        f |= N.ENC_LN_UNFUSED
+    if _env_on("XFMR_FFN_UNFUSED"):
+        f |= N.ENC_FFN_UNFUSED
+    if _env_on("XFMR_FFN_BWD_UNFUSED"):
+        f |= N.ENC_FFN_BWD_UNFUSED
+    if os.environ.get("XFMR_DW_SIDE", "") == "0":
+        f |= N.ENC_DW_INLINE
+    return f
+
+
 def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, precision, ln_eps=1e-12,
-                     hidden_dropout=0.0, attn_dropout=0.0, seed=0, causal=True) -> N.EncoderCfg:
+                     hidden_dropout=0.0, attn_dropout=0.0, seed=0, causal=True, flags=None, step_device=None,
+                     embed_event=None, context=None) -> N.EncoderCfg:
+    """``step_device``: a uint32 device tensor (or pointer) mixed into the dropout stream on the device;
+    ``embed_event``: a hipEvent_t handle the forward records once the key mask exists; ``context``: an
+    ``xfmr_context`` handle (side stream of the backward's weight-gradient GEMMs)."""
+    f = encoder_flags_from_env() if flags is None else int(flags)
+    if not causal:
+        f |= N.ENC_BIDIRECTIONAL
+    if isinstance(step_device, torch.Tensor):
+        assert step_device.dtype in (torch.int32, torch.uint32) and step_device.is_cuda
+        step_device = step_device.data_ptr()
     return N.EncoderCfg(
         batch=batch, seq_len=seq_len, hidden=hidden, heads=heads, inter=inter, layers=layers, max_pos=max_pos,
         precision=N.precision_id(precision), ln_eps=ln_eps, hidden_dropout=hidden_dropout,
-        attn_dropout=attn_dropout, flags=0 if causal else N.ENC_BIDIRECTIONAL, seed=seed,
+        attn_dropout=attn_dropout, flags=f, seed=seed, step_device=step_device, embed_event=embed_event,
+        context=context,
     )
+
+
+class Context:
+    """Owner of one ``xfmr_context`` (the lowest-priority side stream + fork / join events that ``xfmr_encoder_bwd`` runs
+    its weight-gradient GEMMs on). Created on the current device; destroyed with the object."""
+
+    def __init__(self, device=None):
+        self.handle = None
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            N.check(N.load().xfmr_context_create(C.byref(h)), "xfmr_context_create")
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            N.load().xfmr_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def encoder_fwd(cfg: N.EncoderCfg, flat_params, item_idx, table):

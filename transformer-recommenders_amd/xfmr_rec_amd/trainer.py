@@ -41,6 +41,10 @@ class LightningConfig(LossConfig, ModelConfig):
     learning_rate: float = 0.001
     weight_decay: float = 0.01
     top_k: int = TOP_K
+    # trainer.py:103-115: the LanceDB index configs. Accepted so that the reference's config files load unchanged; the
+    # exact top-k search of this build (retrieval.py) has no index to configure.
+    items_config: dict = {}
+    users_config: dict = {}
     # build-specific knobs (not in the reference)
     precision: str = "bf16"  # MFMA arithmetic: "bf16" (reference default bf16-mixed) or "fp32"
     log_all_losses: bool = True  # evaluate all 7 heads + statistics every step like trainer.py:250-264
@@ -53,10 +57,15 @@ class LightningConfig(LossConfig, ModelConfig):
 
 class FusedAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` semantics (decoupled decay, bias correction, eps outside sqrt) as one HIP launch
-    over the flat parameter buffer. Parameters without a gradient are skipped, as torch does."""
+    over the flat parameter buffer. Parameters without a gradient are skipped, as torch does.
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    ``step_device``: an int32 device tensor holding the number of completed steps. The launch then reads the step count
+    from it (``xfmr_adamw_dev``) and advances it afterwards (``xfmr_step_advance``) -- no host-computed argument changes
+    from step to step, so the step can be captured into a hipGraph and replayed."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0, step_device=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale))
+        self.step_device = step_device
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -74,7 +83,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["step"] += 1
                 ops.adamw_(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], lr=group["lr"], beta1=b1,
                            beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"], step=st["step"],
-                           grad_scale=group["grad_scale"])
+                           grad_scale=group["grad_scale"], step_device=self.step_device)
+        if self.step_device is not None:
+            ops.step_advance_(self.step_device)
         return loss
 
 
@@ -142,7 +153,8 @@ class RecommenderLightningModule(_Base):
             torch.cuda.current_stream().wait_stream(self._side)
             self._logging_pending = False
 
-    def compute_losses(self, batch, *, sync_metrics: bool = True, defer_logging: bool = False) -> dict:
+    def compute_losses(self, batch, *, sync_metrics: bool = True, defer_logging: bool = False, profile_grad=None,
+                       profile_log=None) -> dict:
         """``trainer.py:213-264``: every head's summed loss and ``...Mean``, batch and logits statistics.
 
         One encoder forward + ONE fused loss launch sequence produce all of it (the reference recomputes the
@@ -150,6 +162,8 @@ class RecommenderLightningModule(_Base):
         ``sync_metrics=False`` keeps the statistics on the device (no host sync in the step).
         ``defer_logging=True`` (implies device-side metrics) runs the logging heads on a side stream; the non-train
         entries of the returned dict must then only be read after ``sync_logging()``.
+        ``profile_grad`` / ``profile_log``: (start, stop) hipEvent_t handles recorded around the gradient-pass /
+        logging-pass kernel of the loss (``bench.py``'s roofline figures).
         """
         assert self.model is not None
         m, c = self.model, self.config
@@ -186,9 +200,9 @@ class RecommenderLightningModule(_Base):
                 self._ev_embed.record()  # (creates the handle)
             ws_log = ops.sampled_loss_workspace(m.flat, T, H, n_rows, **opts)
             ws_grad = ops.sampled_loss_workspace(m.flat, T, H, n_rows, **opts)
-            N.check(N.load().xfmr_encoder_fwd_mark_embed(self._ev_embed.cuda_event), "xfmr_encoder_fwd_mark_embed")
             prep = (ws_log, ws_grad, H, n_rows)
-        tok, key_mask = m._encode_tokens(hist)
+        # (the forward records the event right after the launch that writes the key mask: xfmr_encoder_cfg.embed_event)
+        tok, key_mask = m._encode_tokens(hist, embed_event=self._ev_embed.cuda_event if overlap else None)
         if m.config.is_normalized:  # models.py:393-394: the queries are the L2-normalised token embeddings
             tok = ops.l2_normalize(tok)
         assert tok.shape[1] == L
@@ -212,12 +226,13 @@ class RecommenderLightningModule(_Base):
                 # all_heads=2: every head except the train head (its value comes from the launch below)
                 losses, stats, _ = ops.sampled_loss(
                     tok.detach(), key_mask, pos, neg, m.embeddings, m.table_rnorm, need_grad=False,
-                    **(opts | {"all_heads": 2, "workspace": ws_log, "prepared": True})
+                    **(opts | {"all_heads": 2, "workspace": ws_log, "prepared": True, "profile_log": profile_log})
                 )
             main.wait_event(self._ev_prep)  # (recorded long ago)
-            train_loss, _l, stats_t = ops.SampledLossFunction.apply(
+            train_loss, losses_train, stats_t = ops.SampledLossFunction.apply(
                 tok, key_mask, pos, neg, m.embeddings, m.table_rnorm,
-                opts | {"all_heads": False, "workspace": ws_grad, "prepared": True, "d_tok_zeroed": d_tok0}
+                opts | {"all_heads": False, "workspace": ws_grad, "prepared": True, "d_tok_zeroed": d_tok0,
+                        "profile_grad": profile_grad}
             )
             for tns in (ws_log, ws_grad):
                 tns.record_stream(side)
@@ -228,7 +243,8 @@ class RecommenderLightningModule(_Base):
             self._logging_pending = True
         else:
             train_loss, losses, stats = ops.SampledLossFunction.apply(
-                tok, key_mask, pos, neg, m.embeddings, m.table_rnorm, opts
+                tok, key_mask, pos, neg, m.embeddings, m.table_rnorm,
+                opts | {"profile_grad": profile_grad, "profile_log": profile_log}
             )
         out: dict = {}
         n_query = stats[N.STAT["n_query"]]
@@ -240,8 +256,9 @@ class RecommenderLightningModule(_Base):
             out[f"loss/{name}"] = val
             if not overlap:
                 out[f"loss/{name}Mean"] = losses[N.NUM_LOSSES + i]  # computed by the final kernel
-        if overlap:  # raw device vector of the side-stream pass (train head entry = 0): see logged_values()
+        if overlap:  # raw device vectors: the side-stream pass (train head entries = 0) and the gradient call (train head only)
             out["losses/device"] = losses
+            out["losses_train/device"] = losses_train
         batch_size, seq_len = key_mask.shape
         numel = key_mask.numel()
         if sync_metrics and not overlap:
@@ -345,14 +362,71 @@ class RecommenderLightningModule(_Base):
         return metrics
 
     def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
-        loss_dict = self.compute_losses(batch)
-        self.log_dict(loss_dict)
-        return loss_dict[f"loss/{self.config.train_loss}"]
+        """``trainer.py:288-291``. Runs the step the benchmark measures: metrics stay on the device (no host sync), the
+        six logging heads + statistics go to the lowest-priority side stream underneath the backward. The train loss is
+        logged here; everything else is logged by :meth:`on_train_batch_end` -- after the side stream has been joined --
+        as 0-dim DEVICE tensors (Lightning's ``log_dict`` takes them and converts at its own logging interval)."""
+        prof = getattr(self, "profile_events", None) or (None, None)  # bench.py: hipEvent pairs around the two loss passes
+        defer = getattr(self, "defer_logging", "auto")
+        if defer == "auto":
+            # the side-stream logging pass pays once it is long enough to be worth hiding: B x L >= 102 400 tokens
+            # (+0.6 % at batch 512 x 200, -1.4 % at 256, -2 % at 128: measured in round 1, bench.py --overlap)
+            h = batch["history_item_idx"]
+            defer = h.shape[0] * min(h.shape[1], self.model.max_seq_length) >= 102400
+        out = self.compute_losses(batch, sync_metrics=False, defer_logging=bool(defer),
+                                  profile_grad=prof[0], profile_log=prof[1])
+        key = f"loss/{self.config.train_loss}"
+        self._pending_out = out
+        self.logged = {}
+        self.log_dict({key: out[key].detach()})
+        return out[key]
+
+    def on_train_batch_end(self, outputs=None, batch=None, batch_idx: int = 0) -> None:
+        """Lightning hook (after ``optimizer.step``): join the logging stream and log the step's remaining values."""
+        out = getattr(self, "_pending_out", None)
+        if out is None:
+            return
+        self._pending_out = None
+        self.last_out = out  # the step's raw device outputs (bench.py reads the statistics vector from it)
+        self.sync_logging()
+        self.log_dict(self.device_log_dict(out))
+
+    def device_log_dict(self, out: dict) -> dict[str, torch.Tensor]:
+        """Every key the reference logs (``trainer.py:241-263``, ``losses.py:392-404``) as 0-dim device tensors -- views
+        of the kernels' output vectors, no host sync, no torch arithmetic. Call after :meth:`sync_logging`.
+        (``logits/{pos,neg}/*`` of an empty selection are NaN here where the reference omits the key.)"""
+        c = self.config
+        res: dict[str, torch.Tensor] = {}
+        stats = out.get("stats/device")
+        if stats is None:  # a synchronous compute_losses result: already complete
+            return {k: torch.as_tensor(v) for k, v in out.items() if not k.endswith("/device")}
+        side, own = out.get("losses/device"), out.get("losses_train/device")
+        for i, cls in enumerate(LOSS_CLASSES):
+            k = f"loss/{cls.__name__}"
+            if k not in out:
+                continue
+            is_train = cls.__name__ == c.train_loss
+            res[k] = out[k].detach()
+            if k + "Mean" in out:
+                res[k + "Mean"] = out[k + "Mean"]
+            elif side is not None:
+                res[k + "Mean"] = (own if is_train and own is not None else side)[N.NUM_LOSSES + i]
+        res["batch/attention_non_zero"] = stats[N.STAT["n_valid"]]
+        res["batch/positive_non_zero"] = stats[N.STAT["n_query"]]
+        res["batch/attention_density"] = stats[N.STAT["attn_density"]]
+        res["batch/positive_density"] = stats[N.STAT["pos_density"]]
+        if c.log_all_losses:
+            res["logits/neg/density"] = stats[N.STAT["neg_density"]]
+            for side_ in ("pos", "neg"):
+                for kk in ("mean", "std", "min", "max"):
+                    res[f"logits/{side_}/{kk}"] = stats[N.STAT[f"{side_}_{kk}"]]
+        return res
 
     def log_dict(self, d, *a, **k):  # noqa: D401 - lightning API
         if _lp is not None and getattr(self, "_trainer", None) is not None:  # pragma: no cover
             return super().log_dict(d, *a, **k)
-        self.logged = d
+        # plain-module build: the step's values accumulate in `logged` (training_step starts a fresh dict)
+        self.logged.update(d)
         return None
 
     def configure_optimizers(self) -> torch.optim.Optimizer:
@@ -433,27 +507,106 @@ class Trainer:
                 g["grad_scale"] = 1.0 / world_size  # DDP averages gradients: SUM all-reduce then / W
 
     def fit_step(self, batch) -> torch.Tensor:
+        """One step through the module's Lightning seam, in Lightning's order (``zero_grad -> training_step -> backward
+        -> [all-reduce] -> optimizer.step -> on_train_batch_end``): what ``bench.py`` times."""
         m = self.module
         m.train()
         self.optimizer.zero_grad(set_to_none=True)
-        out = m.compute_losses(batch, sync_metrics=False, defer_logging=True)
-        m.log_dict(out)
-        loss = out[f"loss/{m.config.train_loss}"]
+        loss = m.training_step(batch, 0)
         loss.backward()
         if self.world_size > 1:
             from .distributed import allreduce_flat_grad_
 
             allreduce_flat_grad_(m.model.flat.grad, self.process_group)
         self.optimizer.step()
-        m.sync_logging()  # (leaving the pass to finish underneath the next step's forward measured no gain: 3.411 vs 3.414 ms)
-        return loss.detach()
+        m.on_train_batch_end(loss, batch, 0)  # joins the logging stream (leaving the pass to finish underneath the next
+        return loss.detach()                  # step's forward measured no gain: 3.411 vs 3.414 ms)
 
-    def fit(self, batches, max_steps: int | None = None) -> list[float]:
+    def fit(self, batches, max_steps: int | None = None, *, ring_slots: int = 6) -> list[float]:
+        """Steps over an iterable of collated batches. Batches that arrive in HOST memory (the reference's DataLoader
+        output, ``data.py:915-927``) are handed over through a :class:`~xfmr_rec_amd.data.PinnedBatchRing`: the copy of
+        batch i + 1 runs underneath step i; device-resident batches (``DeviceSeqDataset.sample_batch``) are used as they are."""
+        from .data import SEQ_BATCH_KEYS, PinnedBatchRing
+
         out = []
         t0 = time.time()
-        for i, b in enumerate(batches):
-            if max_steps is not None and i >= max_steps:
-                break
-            out.append(float(self.fit_step(b)))
+        ring = None
+        it = iter(batches)
+        nxt = next(it, None)
+        i = 0
+        while nxt is not None and (max_steps is None or i < max_steps):
+            b = nxt
+            on_host = not b[SEQ_BATCH_KEYS[0]].is_cuda
+            if on_host:
+                if ring is None or b[SEQ_BATCH_KEYS[0]].shape[0] > ring.shape[1] or b[SEQ_BATCH_KEYS[0]].shape[1] > ring.shape[2]:
+                    if ring is not None:
+                        ring.close()
+                    bs, width = b[SEQ_BATCH_KEYS[0]].shape
+                    ring = PinnedBatchRing(self.module.model.device, bs, max(width, self.module.model.max_seq_length),
+                                           slots=ring_slots)
+                if ring.pending == 0:
+                    ring.stage(b)
+                dev_b = ring.take()
+            else:
+                dev_b = b
+            nxt = next(it, None)
+            if nxt is not None and ring is not None and not nxt[SEQ_BATCH_KEYS[0]].is_cuda \
+                    and nxt[SEQ_BATCH_KEYS[0]].shape[0] <= ring.shape[1] and nxt[SEQ_BATCH_KEYS[0]].shape[1] <= ring.shape[2]:
+                ring.stage(nxt)  # in flight while this step computes
+            out.append(self.fit_step(dev_b))
+            i += 1
+        if ring is not None:
+            ring.release()
+            ring.close()
         self.elapsed = time.time() - t0
-        return out
+        return [float(v) for v in out]  # (one host sync at the end, not one per step)
+
+
+class GraphedStep:
+    """One training step of ``trainer`` (``Trainer.fit_step``: zero_grad -> training_step -> backward -> AdamW ->
+    on_train_batch_end) captured ONCE as a hipGraph for a fixed batch shape and replayed per step: the ~80 kernel
+    launches of a step become one graph launch. For small batches the eager step is bound by the host's launch rate,
+    not by the GPU (batch 32 at config 2: 0.84 ms per step against 0.8-0.95 ms of enqueueing).
+
+    What changes from step to step is read from DEVICE memory inside the captured kernels -- the dropout stream
+    (``xfmr_encoder_cfg.step_device``) and AdamW's step count (``xfmr_adamw_dev``), both the model's ``step_device``
+    counter, advanced by the step's last launch (``xfmr_step_advance``) -- so every replay draws new masks and applies the
+    right bias corrections: replay == the eager step with the same counter, bit for bit (tests/test_gpu_graph.py).
+
+        step = GraphedStep(trainer, example_batch)     # device tensors of the shape every batch will have
+        loss = step(batch)                             # copies the indices into the captured buffers, replays
+
+    Single process only (the all-reduce of a data-parallel step is not captured here)."""
+
+    def __init__(self, trainer: Trainer, example_batch: dict, warmup: int = 3):
+        from .data import SEQ_BATCH_KEYS
+
+        m = trainer.module
+        if trainer.world_size != 1:
+            raise ValueError("GraphedStep captures a single-process step")
+        self.trainer, self.keys = trainer, SEQ_BATCH_KEYS
+        dev = m.model.device
+        if getattr(m.model, "step_device", None) is None:
+            m.model.use_device_step(True)
+        trainer.optimizer.step_device = m.model.step_device
+        m.train()
+        self.static = {k: example_batch[k].to(dev, torch.int64).clone() for k in self.keys}
+        # eager warm-up on a side stream (torch's capture protocol): creates every lazily made object -- optimizer state,
+        # the model's xfmr_context, allocator pools -- so that the capture itself creates nothing
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                trainer.fit_step(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        trainer.optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = trainer.fit_step(self.static)
+        self.logged = dict(m.logged)  # 0-dim device tensors inside the graph's pool: refreshed by every replay
+
+    def __call__(self, batch: dict) -> torch.Tensor:
+        for k in self.keys:
+            self.static[k].copy_(batch[k], non_blocking=True)
+        self.graph.replay()
+        return self.loss
