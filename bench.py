@@ -352,6 +352,9 @@ def main():
         mod.defer_logging = bool(overlap)
         gstep = X.GraphedStep(trainer, batches[0])
 
+    lib = N.load()
+    ar_events = HipEvents(max(args.steps, 1)) if world > 1 else None  # around the exchange, on the compute stream
+
     def step(i, from_host=False, in_line=False, profile=None):
         """zero_grad -> training_step -> backward -> [all-reduce] -> optimizer.step -> on_train_batch_end: the module's
         Lightning seam in Lightning's order (= Trainer.fit_step)."""
@@ -373,12 +376,15 @@ def main():
         loss = mod.training_step(batch, i)
         loss.backward()
         if world > 1:
-            D.allreduce_flat_grad_(mod.model.flat.grad)
+            pair = ar_events.pairs[i % len(ar_events.pairs)] if ar_events is not None else None
+            if pair:
+                N.check(lib.xfmr_event_record(pair[0], N.stream()), "xfmr_event_record")
+            trainer.allreduce_(mod.model.flat.grad)  # two halves, the upper layers' underneath the backward (HalvedAllReduce)
+            if pair:
+                N.check(lib.xfmr_event_record(pair[1], N.stream()), "xfmr_event_record")
         opt.step()
         mod.on_train_batch_end(loss, batch, i)
         return loss, mod.last_out
-
-    lib = N.load()
 
     def timed(n_steps, events=None, from_host=False):
         """Exactly n_steps steps between barriers + device synchronisations; MAX over ranks."""
@@ -397,6 +403,9 @@ def main():
         elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if world > 1:
+            per_rank = [torch.zeros_like(t) for _ in range(world)]
+            torch.distributed.all_gather(per_rank, t)
+            timed.per_rank_s = [float(x.item()) for x in per_rank]
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item()), loss, out
 
@@ -415,6 +424,8 @@ def main():
     for i in range(2):
         step(i, True)
     elapsed, loss, out = timed(args.steps, ev, from_host=True)
+    per_rank_ms = [round(s / args.steps * 1e3, 4) for s in getattr(timed, "per_rank_s", [elapsed])]
+    ar_ms = ar_events.elapsed_ms() if ar_events is not None else []
     resident_s, _, _ = timed(args.steps)  # the same steps on batches that already lie in HBM
     inline_s, _, _ = timed(args.steps, None, from_host="inline")
     # The dominant kernel once more with nothing beside it (outside the timed region): in the timed region the logging pass
@@ -535,6 +546,18 @@ def main():
                            "note": f"the first {args.steps} steps after {args.warmup} warm-up steps only, before the spin-up"},
             "roofline": roofline,
         }
+        if world > 1:  # what a scaling record needs to explain itself
+            be = torch.distributed.get_backend()
+            result["exchange"] = {
+                "backend": "rccl (torch.distributed 'nccl')" if be == "nccl" else be, "rccl_world": world,
+                "message_bytes": int(mod.model.flat.numel()) * 4,
+                "form": "two halves: layers >= L/2 under the lower layers' backward, the rest behind it" if trainer.exchange
+                        else "one all-reduce after the backward",
+                "allreduce_ms": round(sum(ar_ms) / len(ar_ms), 4) if ar_ms else None,
+                "allreduce_ms_note": "HIP events on the compute stream around the exchange call of rank 0: what the step waits "
+                                     "for (the overlapped half shows only as far as it is NOT hidden)",
+                "ms_per_step_per_rank": per_rank_ms,
+            }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(result), flush=True)

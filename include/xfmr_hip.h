@@ -162,7 +162,15 @@ typedef struct xfmr_encoder_cfg {
   void* context;      /* an xfmr_context handle (xfmr_context_create): xfmr_encoder_bwd runs its weight-gradient GEMMs on the
                          context's lowest-priority side stream and joins it into `stream` before its last launch;
                          NULL = everything on `stream`.                                                            */
+  void* grads_half_event; /* hipEvent_t: xfmr_encoder_bwd finishes the gradients of layers >= layers / 2 -- the contiguous
+                         tail of the flat buffer from xfmr_param_half_offset(cfg) on -- as soon as that layer's backward is
+                         enqueued and records the event behind them: the data-parallel all-reduce of that half can run
+                         underneath the lower layers' backward (xfmr_rec_amd/distributed.py). The rest of the buffer is
+                         complete when the call's last launch has run, as always. Ignored by xfmr_encoder_fwd.        */
 } xfmr_encoder_cfg;
+/* Element offset at which the early-finished upper half of the flat gradient begins (0 for a one-layer encoder: the
+ * event then marks the whole buffer, recorded behind the last launch). */
+int64_t xfmr_param_half_offset(const xfmr_encoder_cfg* cfg);
 
 /* A caller-owned side stream of the device's LOWEST priority plus the two events of the fork / join (created on the
  * current device). One per host thread / stream that drives xfmr_encoder_bwd concurrently. */

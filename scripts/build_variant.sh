@@ -11,6 +11,6 @@ cp $ROOT/transformer-recommenders_amd/csrc/*.{hip,h,inc,o} $ROOT/transformer-rec
 cp $ROOT/include/*.h $d/include/ && cp $ROOT/scripts/check_isa.py $d/scripts/
 cd $d/transformer-recommenders_amd/csrc
 if [ $# -gt 0 ]; then rm -f "$@"; else rm -f *.o; fi
-make -j8 EXTRA="$extra" > $d/make.log 2>&1 || { tail -20 $d/make.log; exit 1; }
+make -j8 EXTRA="$extra" ISA_AUDIT=${ISA_AUDIT:-1} > $d/make.log 2>&1 || { tail -20 $d/make.log; exit 1; }
 mkdir -p $ROOT/build && cp $d/transformer-recommenders_amd/xfmr_rec_amd/libxfmr_hip.so $ROOT/build/libxfmr_hip_$name.so
 echo "built build/libxfmr_hip_$name.so"

@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, train_loss):
+def _worker(rank, world, port, out_dir, train_loss, single=False):
     for p in (ROOT, ROOT / "transformer-recommenders_amd", ROOT / "tests"):
         sys.path.insert(0, str(p))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -48,19 +48,23 @@ def _worker(rank, world, port, out_dir, train_loss):
     batch, _ = ragged_batch(B, L, V, seed=1)
     rows = list(D.shard_rows(B, rank, world))
     shard = {k: v[rows].to("cuda:0") for k, v in batch.items()}
+    os.environ["XFMR_ALLREDUCE_SINGLE"] = "1" if single else "0"
     trainer = X.Trainer(mod, world_size=world)
     assert trainer.optimizer.param_groups[0]["grad_scale"] == 1.0 / world
     p0 = mod.model.flat.detach().clone()
     seen = {}
-    real = D.allreduce_flat_grad_
+    real = trainer.allreduce_
+    # the exchange in its two forms: two halves, the upper layers' overlapped with the backward (default), or one message
+    assert (trainer.exchange is None) == single
 
-    def spy(flat_grad, group=None):  # Trainer.fit_step looks the function up at call time
+    def spy(flat_grad):  # Trainer.fit_step calls its allreduce_ between backward and optimizer.step
+        torch.cuda.synchronize()
         seen["local"] = flat_grad.detach().clone()
-        out = real(flat_grad, group)
+        real(flat_grad)
+        torch.cuda.synchronize()
         seen["reduced"] = flat_grad.detach().clone()
-        return out
 
-    D.allreduce_flat_grad_ = spy
+    trainer.allreduce_ = spy
     loss = trainer.fit_step(shard)
     torch.cuda.synchronize()
     torch.save({"p0": p0.cpu(), "p1": mod.model.flat.detach().cpu(), "local": seen["local"].cpu(),
@@ -69,10 +73,11 @@ def _worker(rank, world, port, out_dir, train_loss):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss"])
-def test_two_rank_fit_step_equals_averaged_independent_gradients(tmp_path, train_loss):
+@pytest.mark.parametrize("train_loss,single", [("InfoNCELoss", False), ("PairwiseLogisticLoss", False), ("InfoNCELoss", True)])
+def test_two_rank_fit_step_equals_averaged_independent_gradients(tmp_path, train_loss, single):
     world, port = 2, _free_port()
-    mp.start_processes(_worker, args=(world, port, str(tmp_path), train_loss), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), train_loss, single), nprocs=world, join=True,
+                       start_method="spawn")
     r = [torch.load(tmp_path / f"r{i}.pt", weights_only=True) for i in range(world)]
     assert sorted(r[0]["rows"] + r[1]["rows"]) == list(range(8)) and not set(r[0]["rows"]) & set(r[1]["rows"])
     assert torch.equal(r[0]["p0"], r[1]["p0"])  # replicas start equal

@@ -44,11 +44,11 @@ def test_graph_replay_equals_eager_steps_bit_for_bit_with_dropout(X, train_loss)
     tr_e.optimizer.step_device = eager.model.step_device
     graphed, _ = _setup(X, train_loss)
     tr_g = X.Trainer(graphed)
-    step = X.GraphedStep(tr_g, batches[0], warmup=3)  # 3 eager warm-up steps + 1 captured step on batches[0]
-    for _ in range(4):
+    step = X.GraphedStep(tr_g, batches[0], warmup=3)  # 3 eager warm-up steps on batches[0]; the capture itself runs nothing
+    for _ in range(3):
         tr_e.fit_step(batches[0])
     torch.cuda.synchronize()
-    assert int(eager.model.step_device) == int(graphed.model.step_device) == 4
+    assert int(eager.model.step_device) == int(graphed.model.step_device) == 3
     assert torch.equal(eager.model.flat, graphed.model.flat)
     losses_e, losses_g = [], []
     for b in batches[1:4]:  # three more steps: eager vs replay

@@ -127,6 +127,51 @@ def test_encoder_config5_shape_vs_oracle(X, prec, L, lengths):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("H,A,I", [(512, 16, 256), (320, 10, 160)])
+def test_encoder_other_d_model_vs_oracle(X, prec, H, A, I):
+    """d_model outside {64, 128, 256, 384} (any (V, H) table): 512 / 16 heads and 320 / 10 heads
+    through gather, LayerNorms, GEMMs and attention against the CPU oracle, every trainable tensor's gradient."""
+    _encoder_shape_vs_oracle(X, prec, B=3, L=40, H=H, A=A, I=I, nL=2, V=150, lengths=[40, 23, 3])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("H,A", [(512, 16), (320, 10)])
+@pytest.mark.parametrize("train_loss", ["InfoNCELoss", "AlignmentContrastiveLoss"])
+def test_training_step_other_d_model_vs_oracle(X, prec, H, A, train_loss):
+    """The whole step -- encoder, the fused loss of all seven heads, backward -- at a d_model the LDS-DMA loss kernel is not
+    instantiated for: the generic loss kernel (next template width, masked rows) in both precision policies, with and
+    without the bf16 table copy, against the oracle's materialised form."""
+    from oracle import model as OM
+
+    L, V, B, I = 24, 90, 4, 128
+    table = unit_table(V, H)
+    batch, lengths = ragged_batch(B, L, V, lengths=[24, 17, 5, 24], seed=5)
+    conf = X.LightningConfig(hidden_size=H, num_attention_heads=A, intermediate_size=I, num_hidden_layers=1,
+                             max_seq_length=L, precision=prec, train_loss=train_loss)
+    mod = X.RecommenderLightningModule(conf)
+    mod.configure_model()
+    mod.model.set_table(table.to(DEV))
+    mod.eval()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mod.model.encoder_state_dict().items()}
+    want = OM.compute_losses(params, table, batch, num_heads=A, max_seq_length=L, loss_cfg={}, resolve_ties=True)
+    want[f"loss/{train_loss}"].backward()
+    out = mod.compute_losses(batch)
+    out[f"loss/{train_loss}"].backward()
+    tol = TOL[prec]
+    for cls in X.LOSS_CLASSES:
+        k = f"loss/{cls.__name__}"
+        w = float(want[k].detach())
+        lim = tol["loss_rel"] * max(1.0, abs(w)) * (3 if prec == "bf16" else 1)
+        assert abs(float(out[k]) - w) <= lim, (k, float(out[k]), w)
+    got = mod.model.grad_state_dict()
+    for k, p_ in params.items():
+        if k.endswith("key.bias"):
+            continue
+        e = rel_l2(got[k], p_.grad)
+        assert e <= tol["grad_l2"] * (3 if prec == "bf16" else 1), (k, e)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_encoder_reference_default_shape_vs_oracle(X, prec):
     """The reference's own default model (config.yaml:46-52 + models.py:80-91 with the all-MiniLM table): d_model 384,
     12 heads, intermediate 48, 1 layer, max_seq_length 32. K = 48 takes the 32-deep K slices."""
@@ -370,7 +415,11 @@ def test_loss_api_errors_mirror_reference(X):
 # ------------------------------------------------------------------------------------------ fused loss, positions form
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("T_shape,H,V", [((4, 50), 64, 60), ((5, 200), 128, 500), ((2, 96), 256, 100),
-                                         ((6, 32), 384, 150)])  # 384 = the reference's default d_model (all-MiniLM table)
+                                         ((6, 32), 384, 150),  # 384 = the reference's default d_model (all-MiniLM table)
+                                         # any other d_model (models.py:22-48 takes any hidden_size): the generic kernel at
+                                         # the next instantiated width, rows masked beyond their real width
+                                         ((3, 40), 512, 120), ((2, 33), 320, 90), ((2, 40), 96, 70), ((2, 24), 640, 80),
+                                         ((2, 20), 1024, 70)])
 def test_fused_loss_positions_form_vs_oracle(X, prec, T_shape, H, V):
     """All seven heads + statistics + d_tok from ONE launch sequence, on ragged positions, vs the oracle that
     materialises the (Np, 1+N, H) candidates like models.py:408-416. Several tiles and splits are exercised."""
@@ -378,6 +427,8 @@ def test_fused_loss_positions_form_vs_oracle(X, prec, T_shape, H, V):
     from xfmr_rec_amd import _native as N
     from xfmr_rec_amd import ops
 
+    if prec == "fp32" and H > 512:
+        pytest.skip("fp32 parity policy: the fused loss stops at d_model 512 (its fp32 tile image must fit LDS)")
     B, L = T_shape
     table = unit_table(V, H)
     batch, lengths = ragged_batch(B, L, V, seed=3)

@@ -244,7 +244,7 @@ def _ddp_worker(rank, world, port, out_dir):
 
     r, _local, w = D.init_process_group_from_env(backend="gloo")
     assert (r, w) == (rank, world)
-    H, A, I, nL, L, V, B = 64, 2, 64, 1, 12, 40, 6
+    H, A, I, nL, L, V, B = 64, 2, 64, 2, 12, 40, 6
     cfg = X.ModelConfig(hidden_size=H, num_attention_heads=A, intermediate_size=I, num_hidden_layers=nL, max_seq_length=L)
     model = X.RecommenderModel(cfg, seed=3)  # same seed on every rank == replicated weights
     table = unit_table(V, H)
@@ -262,7 +262,11 @@ def _ddp_worker(rank, world, port, out_dir):
         flat_grad[off : off + params[name].numel()] = params[name].grad.flatten()
     local = flat_grad.clone()
     D.allreduce_flat_grad_(flat_grad)
-    torch.save({"local": local, "reduced": flat_grad, "rows": rows}, os.path.join(out_dir, f"r{rank}.pt"))
+    # the same exchange in two halves (upper layers first: on a GPU that half runs underneath the lower layers' backward)
+    halved = D.HalvedAllReduce(model)
+    two = halved.reduce_(local.clone())
+    torch.save({"local": local, "reduced": flat_grad, "rows": rows, "halved": two, "boundary": halved.boundary},
+               os.path.join(out_dir, f"r{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -276,6 +280,13 @@ def test_data_parallel_gloo_world2(tmp_path):
     for i in range(world):
         torch.testing.assert_close(r[i]["reduced"], total, rtol=1e-6, atol=1e-7)
     assert not torch.allclose(r[0]["local"], r[1]["local"])  # shards really differ (negatives stay rank-local)
+    # two halves == one message, bit for bit (a SUM of two ranks is exact either way); the boundary is layer 1's first tensor
+    for i in range(world):
+        assert torch.equal(r[i]["halved"], r[i]["reduced"])
+    import xfmr_rec_amd as X
+
+    names, shapes, offsets, total = X.models.flat_layout(64, 64, 12, 2)
+    assert r[0]["boundary"] == offsets[names.index("encoder.layer.1.attention.self.query.weight")] and 0 < r[0]["boundary"] < total
 
 
 def test_saved_directory_is_a_loadable_hf_bert_with_the_sentence_transformer_layout(tmp_path):

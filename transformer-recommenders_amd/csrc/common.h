@@ -143,6 +143,20 @@ struct RegRows<PrecBF16, K> {
       v[s][4] = (__bf16)b.x; v[s][5] = (__bf16)b.y; v[s][6] = (__bf16)b.z; v[s][7] = (__bf16)b.w;
     }
   }
+  // only the first n columns of the row exist (n a multiple of 16; the rest read as zero): a row narrower than K
+  __device__ __forceinline__ void load_n(const float* row, bool valid, int n) {
+    const int h = xf_lane() >> 5;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      float4 a = make_float4(0, 0, 0, 0), b = a;
+      if (valid && 16 * s < n) {
+        a = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h);
+        b = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h + 4);
+      }
+      v[s][0] = (__bf16)a.x; v[s][1] = (__bf16)a.y; v[s][2] = (__bf16)a.z; v[s][3] = (__bf16)a.w;
+      v[s][4] = (__bf16)b.x; v[s][5] = (__bf16)b.y; v[s][6] = (__bf16)b.z; v[s][7] = (__bf16)b.w;
+    }
+  }
   // `row` must be dereferenceable even when !valid (the result is then zero): every load is issued up front,
   // without the per-piece branches (and the chain of exposed load latencies) of load()
   __device__ __forceinline__ void load_safe(const float* row, bool valid) {
@@ -199,6 +213,11 @@ struct RegRows<PrecF32, K> {
     const int h = xf_lane() >> 5;
 #pragma unroll
     for (int s = 0; s < K / 2; ++s) v[s] = valid ? row[2 * s + h] : 0.f;
+  }
+  __device__ __forceinline__ void load_n(const float* row, bool valid, int n) {  // columns >= n read as zero
+    const int h = xf_lane() >> 5;
+#pragma unroll
+    for (int s = 0; s < K / 2; ++s) v[s] = (valid && 2 * s < n) ? row[2 * s + h] : 0.f;
   }
   __device__ __forceinline__ float dot_partial(const RegRows& o) const {
     float acc = 0.f;
@@ -357,6 +376,23 @@ __device__ __forceinline__ void xf_drop4(const XfDropout& d, uint32_t row, uint3
   const uint32_t rk = xf_drop_rowkey(d, row), cm = col * kDropColMul;
   v.x *= xf_keep_scale_rc(d, rk, cm); v.y *= xf_keep_scale_rc(d, rk, cm + kDropColMul);
   v.z *= xf_keep_scale_rc(d, rk, cm + 2 * kDropColMul); v.w *= xf_keep_scale_rc(d, rk, cm + 3 * kDropColMul);
+}
+
+// Zero-fill as a KERNEL launch (bytes % 4 == 0, p 4-byte aligned): hipMemsetAsync nodes captured into a hipGraph were
+// not re-executed by later replays on this runtime (ROCm 7.x with torch 2.10: the multiplicity histogram of the loss
+// doubled from the second replay on -- scripts/probe/graph_debug.py), and the training step must replay as a graph.
+static __global__ __launch_bounds__(256) void xf_zero_kernel(uint32_t* p, int64_t n16, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) reinterpret_cast<uint4*>(p)[i] = make_uint4(0, 0, 0, 0);
+  else if (i - n16 < n4) p[4 * n16 + (i - n16)] = 0;
+}
+static inline hipError_t xf_zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  if ((bytes & 3) || (reinterpret_cast<uintptr_t>(p) & 3)) return hipMemsetAsync(p, 0, bytes, st);
+  const bool a16 = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  const int64_t n16 = a16 ? (int64_t)(bytes / 16) : 0, n4 = (int64_t)(bytes / 4) - 4 * n16, work = n16 + n4;
+  hipLaunchKernelGGL(xf_zero_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, n16, n4);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -570,6 +606,17 @@ __device__ __forceinline__ void xf_glds16(const void* gsrc, void* lds_base) {
 // from the DMA target (here: every read of per-negative side data, twice per 32 x 32 sub-block), which drains the
 // prefetch. The caller owns the ordering: s_waitcnt vmcnt(N) + barrier before anyone reads the destination.
 // M0 (the LDS destination base) is compiler-reserved: it is saved, set and restored inside the one statement.
+// ... with the address as a wave-uniform 64-bit base (SGPR pair) + a 32-bit unsigned byte offset per lane: half the
+// address registers of the 64-bit per-lane form and no 64-bit vector arithmetic per piece (the source must lie within
+// 4 GiB of the base).
+__device__ __forceinline__ void xf_glds16_raw_so(const void* sbase, uint32_t voff, void* lds_base) {
+  const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_base;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(dst)
+               : "memory");
+}
 __device__ __forceinline__ void xf_glds16_raw(const void* gsrc, void* lds_base) {
   const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_base;
   unsigned keep;

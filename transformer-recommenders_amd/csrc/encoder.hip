@@ -225,8 +225,9 @@ const char* xfmr_strerror(int code) {
     case XFMR_OK: return "ok";
     case XFMR_EINVAL: return "invalid argument";
     case XFMR_EUNSUPPORTED:
-      return "shape not supported by the gfx950 kernels (head size must be 32; H in {64,128,256,384} for the fused loss; "
-             "attention panels must fit LDS: L <= 256 in the fp32 policy, L <= 1024 in bf16)";
+      return "shape not supported by the gfx950 kernels (head size must be 32; the fused loss takes any d_model that is a "
+             "multiple of 32 up to 1024 in the bf16 policy and up to 512 in fp32; attention panels must fit LDS: L <= 256 in "
+             "the fp32 policy, L <= 1024 in bf16)";
     case XFMR_EWORKSPACE: return "workspace too small";
     case XFMR_EHIP: return "HIP launch failed";
     case XFMR_EALIGN: return "pointer or leading dimension not 16-byte aligned";
@@ -404,12 +405,19 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   };
   const XfDropout off = xf_make_dropout(0.f, 0, 0);
   float* dX = d_tok;  // gradient w.r.t. the current layer's output
-  XfReduceSeg segs[12 * 64 + 2];
-  int nseg = 0;
-  auto seg = [&](const float* src, float* dst, int rows, int64_t cols, int64_t ld) {
-    segs[nseg++] = XfReduceSeg{src, dst, rows, (int)cols, (int)ld, 0};
-  };
+  // Two reduction lists when the caller wants the UPPER half of the flat gradient early (cfg->grads_half_event): the
+  // tensors of layers >= layers / 2 are the contiguous tail of the buffer (xfmr_param_half_offset); their slabs and
+  // records are reduced as soon as layer layers / 2 has enqueued its last producer, the event is recorded behind that
+  // launch, and the data-parallel exchange of that half runs underneath the lower layers' backward.
+  XfReduceSeg segs[12 * 64 + 2], segs_hi[12 * 64 + 2];
+  int nseg = 0, nseg_hi = 0;
   if (cfg->layers > 64) return XFMR_EUNSUPPORTED;
+  const int half_layer = (cfg->grads_half_event && cfg->layers >= 2) ? cfg->layers / 2 : -1;
+  const float* const hi_begin = half_layer >= 0 ? grads + layer_params(cfg, half_layer).wqkv : nullptr;
+  auto seg = [&](const float* src, float* dst, int rows, int64_t cols, int64_t ld) {
+    if (hi_begin && dst >= hi_begin) segs_hi[nseg_hi++] = XfReduceSeg{src, dst, rows, (int)cols, (int)ld, 0};
+    else segs[nseg++] = XfReduceSeg{src, dst, rows, (int)cols, (int)ld, 0};
+  };
   // LayerNorm backward in the epilogue of the dX GEMM that produces its input gradient (whole-row 64 x 128 tiles: same
   // conditions as the forward fusion): LN1 with the FFN1 dX GEMM of its layer, LN2 of layer i-1 with the QKV dX GEMM of
   // layer i. The top layer's LN2 and the embedding LayerNorm keep their own launches.
@@ -531,6 +539,11 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     } else {
       XF_TRY(xf_linear_bwd_dx_ex(dQKV, W(p.wqkv), dX, T, 3 * H, H, dX, nullptr, prec, sA | sB, st));  // += d(pre1)
     }
+    if (i == half_layer) {  // every producer of the upper half's slabs / records is enqueued: finish that half now
+      hipStream_t rs = dw_stream();  // (the side stream when the dW GEMMs run there: the chain itself does not wait)
+      XF_TRY(xf_multi_rowsum(segs_hi, nseg_hi, rs));
+      if (hipEventRecord((hipEvent_t)cfg->grads_half_event, rs) != hipSuccess) return XFMR_EHIP;
+    }
   }
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
@@ -557,7 +570,16 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   if (chain_rc != XFMR_OK) return chain_rc;
   if (side_rc != XFMR_OK) return side_rc;
   XF_TRY(xf_multi_rowsum(segs, nseg, st));  // every weight / bias / LayerNorm gradient of the encoder, one launch
+  if (cfg->grads_half_event && half_layer < 0 &&  // (a one-layer encoder has no upper half: the event marks the whole buffer)
+      hipEventRecord((hipEvent_t)cfg->grads_half_event, st) != hipSuccess)
+    return XFMR_EHIP;
   return XFMR_OK;
+}
+
+int64_t xfmr_param_half_offset(const xfmr_encoder_cfg* cfg) {
+  if (!cfg || cfg->layers <= 0) return XFMR_EINVAL;
+  if (cfg->layers < 2) return 0;
+  return layer_params(cfg, cfg->layers / 2).wqkv;
 }
 
 }  // extern "C"

@@ -149,14 +149,20 @@ __global__ __launch_bounds__(PREP) void distinct_write_kernel(const int* hist, i
 // H > 256 (the reference's default d_model 384): the dQ product runs as H / 128 column parts (grid.z) -- the tile image
 // [64][H] for S^T is whole, the transposed image and the gradient accumulators cover 128 columns: 134 KB of LDS and 64
 // accumulator registers in the fp32 policy instead of 203 KB / 192. Scores and weights are recomputed per part.
-template <int H>
-constexpr int loss_main_hparts() { return H > 256 ? H / 128 : 1; }
+// H is the kernel's TEMPLATE width: the rows' real width Hr = a.H (their stride too) may be any multiple of 32 up to it
+// -- columns Hr .. H - 1 are zeros in every image and register operand, which changes no dot product, norm or gradient.
+// That is how every d_model the reference can be configured with (models.py:22-48: any hidden_size) reaches this kernel:
+// the width is rounded up to the next instantiation (64, 128, 256, 384, 512, 768, 1024; the fp32 policy up to 512: its
+// tile image is 4 bytes per element, and at 512 the dQ parts are 64 columns wide so that both images fit 160 KB).
+template <class P, int H>
+constexpr int loss_main_hparts() { return H <= 256 ? 1 : (sizeof(typename P::elem) == 4 && H >= 512) ? H / 64 : H / 128; }
 template <class P, int H, bool ALL>
 __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(LossArgs a) {
   using elem = typename P::elem;
   constexpr int LDE = xf_ld<P>(H);
   constexpr int NPASS = 2 * (H / 64);  // staging passes: 32 rows x 64 columns per pass per workgroup
-  constexpr int HP = loss_main_hparts<H>(), HW = H / HP, NO = HW / 32;
+  constexpr int HP = loss_main_hparts<P, H>(), HW = H / HP, NO = HW / 32;
+  const int Hr = a.H;
   const int hpart = HP > 1 ? (int)blockIdx.z : 0;
   // With every head evaluated the epilogue needs the registers: the wave's query rows then live in LDS
   // (B operand read like the A operand) so the kernel still fits 2 waves/SIMD (<= 256 registers).
@@ -190,17 +196,27 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   const int row = qvalid ? a.qrow[qi] : 0;
   const int pos_item = qvalid ? a.qpos[qi] : -2;
   RegRows<P, H> qreg;
-  qreg.load(a.tok + (int64_t)row * H, qvalid);
+  qreg.load_n(a.tok + (int64_t)row * Hr, qvalid, Hr);
   float pos_dot, qq = 0.f;
   {
-    RegRows<P, H> preg;
-    preg.load(a.table + (int64_t)(qvalid ? pos_item : 0) * H, qvalid);
-    pos_dot = qreg.dot_partial(preg);
+    if (H > 384) {  // (a second H-wide register row beside Q would not fit: the positive's dot product in 128-column pieces)
+      pos_dot = 0.f;
+      for (int c0 = 0; c0 < Hr; c0 += 128) {
+        RegRows<P, 128> qa, pa;
+        qa.load_n(a.tok + (int64_t)row * Hr + c0, qvalid, Hr - c0);
+        pa.load_n(a.table + (int64_t)(qvalid ? pos_item : 0) * Hr + c0, qvalid, Hr - c0);
+        pos_dot += qa.dot_partial(pa);
+      }
+    } else {
+      RegRows<P, H> preg;
+      preg.load_n(a.table + (int64_t)(qvalid ? pos_item : 0) * Hr, qvalid, Hr);
+      pos_dot = qreg.dot_partial(preg);
+    }
     pos_dot += xf_half_swap(pos_dot);
     if (qvalid) {
-      const float* pr = a.tok + (int64_t)row * H + hh * (H / 2);
+      const float* pr = a.tok + (int64_t)row * Hr + hh * (Hr / 2);
 #pragma unroll 4
-      for (int c = 0; c < H / 2; c += 4) {
+      for (int c = 0; c < Hr / 2; c += 4) {
         const float4 v = *reinterpret_cast<const float4*>(pr + c);
         qq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
       }
@@ -254,8 +270,8 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
       for (int u = 0; u < 2; ++u) {
         const int r = (p & 1) * 32 + wid * 8 + 2 * st_rho + u;
         const int it = item_of(j0 + r);
-        pre[p][u] = it >= 0 ? *reinterpret_cast<const float4*>(a.table + (int64_t)it * H + cc)
-                            : make_float4(0, 0, 0, 0);
+        pre[p][u] = (it >= 0 && cc < Hr) ? *reinterpret_cast<const float4*>(a.table + (int64_t)it * Hr + cc)
+                                        : make_float4(0, 0, 0, 0);
       }
     }
     if (tid < BN) {
@@ -287,11 +303,51 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
   // variants); otherwise gather-then-commit back to back and let the second resident workgroup of the CU
   // cover the latency (2 waves/SIMD variants: the 32 staging registers are not live across the math).
   constexpr bool PREFETCH_ACROSS = (H > 128 && H <= 256);  // (H = 384: the 96 staging registers are not kept live)
+  // H > 384: the staging registers of a whole tile (8 per 64 columns: 128 at H = 1024, beside 256 of Q) are too many --
+  // gather and commit four passes at a time
+  constexpr bool STAGE_DIRECT = H > 384;
+  auto stage_direct = [&](int tile) {
+    const int j0 = tile * BN;
+#pragma unroll 1
+    for (int p0 = 0; p0 < NPASS; p0 += 4) {
+      float4 t[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = p0 + q, cc = (p >> 1) * 64 + st_c * 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int it = item_of(j0 + (p & 1) * 32 + wid * 8 + 2 * st_rho + u);
+          t[q][u] = (it >= 0 && cc < Hr) ? *reinterpret_cast<const float4*>(a.table + (int64_t)it * Hr + cc)
+                                         : make_float4(0, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = p0 + q, cc = (p >> 1) * 64 + st_c * 4;
+        const int r0 = (p & 1) * 32 + wid * 8 + 2 * st_rho;
+        xf_store4<P>(sE + r0 * LDE + cc, t[q][0]);
+        xf_store4<P>(sE + (r0 + 1) * LDE + cc, t[q][1]);
+        const int ct = cc - hpart * HW;
+        if (HP > 1 && (ct < 0 || ct >= HW)) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf_store2<P>(sET + (ct + j) * LDT + r0, xf_get(t[q][0], j), xf_get(t[q][1], j));
+      }
+    }
+    if (tid < BN) {
+      const int nid = item_of(j0 + tid);
+      sNid[tid] = nid;
+      sRc[tid] = nid >= 0 ? a.rnorm[nid] : 0.f;
+      sMul[tid] = (nid >= 0 && a.neg_mult && !catalog) ? a.neg_mult[j0 + tid] : 1.f;
+    }
+  };
   if (PREFETCH_ACROSS && t_beg < t_end) prefetch(t_beg);
   for (int tile = t_beg; tile < t_end; ++tile) {
     __syncthreads();
-    if (!PREFETCH_ACROSS) prefetch(tile);
-    commit();
+    if (STAGE_DIRECT) stage_direct(tile);
+    else {
+      if (!PREFETCH_ACROSS) prefetch(tile);
+      commit();
+    }
     __syncthreads();
     if (PREFETCH_ACROSS && tile + 1 < t_end) prefetch(tile + 1);
 
@@ -327,10 +383,11 @@ __global__ __launch_bounds__(256, (H <= 128 ? 2 : 1)) void loss_main_kernel(Loss
                 rq, qq);
   if (do_grad) {
     __syncthreads();  // sScratch aliases the tile images other waves may still be reading
-    float* base = a.partO + (int64_t)split * a.T * H;
+    float* base = a.partO + (int64_t)split * a.T * Hr;
 #pragma unroll
     for (int i = 0; i < NO; ++i)
-      xf_store_tile_T(sScratch + wid * 32 * 33, o[i], 1.f, base + (hpart * NO + i) * 32, H, qb0 + wid * 32, Nq);
+      if ((hpart * NO + i) * 32 < Hr)  // (column blocks past the real width hold zeros)
+        xf_store_tile_T(sScratch + wid * 32 * 33, o[i], 1.f, base + (hpart * NO + i) * 32, Hr, qb0 + wid * 32, Nq);
   }
 }
 
@@ -550,7 +607,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       const bool cosh = head <= XFMR_LOSS_CONTRASTIVE;
       // first pass for cosine heads: q_hat . dq_hat
       float dotp = 0.f;
-      constexpr int NSW = 4;  // 128-column sweeps: H <= 512
+      constexpr int NSW = 8;  // 128-column sweeps: H <= 1024
       float4 gk[NSW];         // the row's gradient pieces of this lane
 #pragma unroll
       for (int sw = 0; sw < NSW; ++sw) {
@@ -776,19 +833,24 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
 
 template <class P, int H>
 void launch_main(const LossArgs& a, bool all, dim3 grid, hipStream_t st) {
-  grid.z = (a.need_grad && !a.dump) ? loss_main_hparts<H>() : 1;  // dQ column parts (values-only launches: one)
+  grid.z = (a.need_grad && !a.dump) ? loss_main_hparts<P, H>() : 1;  // dQ column parts (values-only launches: one)
   if (all) hipLaunchKernelGGL((loss_main_kernel<P, H, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((loss_main_kernel<P, H, false>), grid, dim3(256), 0, st, a);
 }
+// H: the rows' real width (any multiple of 32) -> the next instantiated template width (see loss_main_kernel)
 template <class P>
 int launch_main_h(const LossArgs& a, int H, bool all, dim3 grid, hipStream_t st) {
-  switch (H) {
-    case 64: launch_main<P, 64>(a, all, grid, st); break;
-    case 128: launch_main<P, 128>(a, all, grid, st); break;
-    case 256: launch_main<P, 256>(a, all, grid, st); break;
-    case 384: launch_main<P, 384>(a, all, grid, st); break;
-    default: return XFMR_EUNSUPPORTED;
-  }
+  if (H <= 0 || (H & 31)) return XFMR_EUNSUPPORTED;
+  constexpr bool f32 = sizeof(typename P::elem) == 4;
+  if (H <= 64) launch_main<P, 64>(a, all, grid, st);
+  else if (H <= 128) launch_main<P, 128>(a, all, grid, st);
+  else if (H <= 256) launch_main<P, 256>(a, all, grid, st);
+  else if (H <= 384) launch_main<P, 384>(a, all, grid, st);
+  else if (H <= 512) launch_main<P, 512>(a, all, grid, st);
+  else if (f32) return XFMR_EUNSUPPORTED;  // (the fp32 tile image of 64 x 768 does not fit LDS)
+  else if (H <= 768) launch_main<PrecBF16, 768>(a, all, grid, st);
+  else if (H <= 1024) launch_main<PrecBF16, 1024>(a, all, grid, st);
+  else return XFMR_EUNSUPPORTED;
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
@@ -839,7 +901,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   a.neg_rc = (const float*)(ws + p.off_negrc);
   a.neg_mult = cfg->mode == XFMR_NEG_SHARED ? (const float*)(ws + p.off_negmul) : nullptr;
   a.qrow = qrow; a.qpos = qpos; a.part = (float*)(ws + p.off_part); a.partO = (float*)(ws + p.off_partO);
-  a.T = T; a.nsplit = p.nsplit; a.train_head = cfg->train_head; a.mask_fn = cfg->mask_false_negatives;
+  a.T = T; a.H = H; a.nsplit = p.nsplit; a.train_head = cfg->train_head; a.mask_fn = cfg->mask_false_negatives;
   a.mode = cfg->mode; a.need_grad = d_tok != nullptr; a.scale = cfg->scale; a.margin = cfg->margin;
   dim3 grid((unsigned)((T + QB - 1) / QB), p.nsplit);
   // Gradient pass of the bf16 production path with ONE column split when the query blocks alone fill the chip (>= two
@@ -880,7 +942,9 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
     XF_LAUNCH_CHECK();
     a.tau = (const float4*)(ws + p.off_tau);
   }
-  if (!hard && cfg->precision == XFMR_PREC_BF16 && table_bf16) {
+  // widths the LDS-DMA kernel is instantiated for; its gather addresses rows by a 32-bit byte offset from the table base
+  const bool dma_width = (H == 64 || H == 128 || H == 256 || H == 384) && (uint64_t)n_rows * (uint64_t)H * 2 < (1ull << 32);
+  if (!hard && cfg->precision == XFMR_PREC_BF16 && table_bf16 && dma_width) {
     // bf16 production path: the gradient pass of the train head (skipped for AlignmentLoss, whose gradient has
     // no negative term) and, when every head is wanted or no gradient is, the values-only logging pass.
     const bool all = cfg->all_heads != 0;
@@ -1018,7 +1082,7 @@ int xfmr_sampled_loss_prepare(const xfmr_loss_cfg* cfg, const uint8_t* key_mask,
   XF_LAUNCH_CHECK();
   const bool shared = cfg->mode == XFMR_NEG_SHARED;
   int* hist = (int*)(ws + p.off_hist);
-  if (shared && hipMemsetAsync(hist, 0, (size_t)n_rows * sizeof(int), st) != hipSuccess) return XFMR_EHIP;
+  if (shared && xf_zero_async(hist, (size_t)n_rows * sizeof(int), st) != hipSuccess) return XFMR_EHIP;
   hipLaunchKernelGGL(prepare_write_kernel, dim3(nprep), dim3(PREP), 0, st, key_mask, pos_idx,
                      shared ? neg_idx : (const int64_t*)nullptr, T, n_rows, (const int2*)blockcnt,
                      (int*)(ws + p.off_counts), hist, (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));
@@ -1042,7 +1106,7 @@ int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const bool zeroed = (cfg->flags & XFMR_LOSS_DTOK_ZEROED) != 0;  // the caller zeroed d_tok itself
-  if (d_tok && !zeroed && hipMemsetAsync(d_tok, 0, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
+  if (d_tok && !zeroed && xf_zero_async(d_tok, (size_t)positions * H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   if (table_bf16 && !xf_aligned16(table_bf16)) return XFMR_EALIGN;
   return run_loss(cfg, tok, table, table_rnorm, table_bf16, n_rows, (int)positions, H, losses, stats, d_tok,
                   (unsigned char*)workspace, p, st);
@@ -1089,7 +1153,7 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
   const int T = (int)rows;
   const bool shared = cfg->mode == XFMR_NEG_SHARED;
   int* hist = (int*)(ws + p.off_hist);
-  if (shared && hipMemsetAsync(hist, 0, (size_t)n_rows * sizeof(int), st) != hipSuccess) return XFMR_EHIP;
+  if (shared && xf_zero_async(hist, (size_t)n_rows * sizeof(int), st) != hipSuccess) return XFMR_EHIP;
   hipLaunchKernelGGL(prepare_lists_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, pos_items,
                      shared ? neg_items : (const int64_t*)nullptr, (int)n_query, (int)(shared ? n_neg : 0), n_rows,
                      (int*)(ws + p.off_counts), hist, (int*)(ws + p.off_qrow), (int*)(ws + p.off_qpos));

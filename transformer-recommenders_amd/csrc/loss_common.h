@@ -45,6 +45,7 @@ struct LossArgs {
   // combine kernel. Null: write the partials to partO as before.
   float* d_tok;
   int T; int nsplit;
+  int H;                  // generic kernel: the rows' real width (= their stride); <= the kernel's template width, % 32 == 0
   int train_head, mask_fn, mode, need_grad;
   float scale, margin;
 };

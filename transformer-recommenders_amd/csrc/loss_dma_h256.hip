@@ -1,17 +1,33 @@
 // LDS-DMA bf16 main kernel of the fused sampled loss, H = 256: six gradient-pass instantiations (one per head
 // with a negative term) + the logging pass. One translation unit per hidden size to keep build time down.
+#include <stdlib.h>
+
 #include "loss_common.h"
 #include "loss_dma.inc"
+
+static bool logm256() {
+  static const bool on = [] { const char* e = getenv("XFMR_LOSS_LOGM256"); return !(e && *e == '0'); }();
+  return on;
+}
 
 int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st) {
   const __bf16* tbf = (const __bf16*)table_bf16;
   dim3 block(256);
   if (head == XFMR_LOSS_INFONCE && !a.mask_fn && !a.pin_part) grid.z = 2;  // two dQ column halves (loss_dma.inc)
   switch (head) {
-    // (the masked fast-path epilogue of the logging pass is for H <= 128 only: at one wave per SIMD it measured 26 %
-    //  SLOWER than the general epilogue -- 2.21 against 1.75 ms at BASELINE config 5)
-    case -1: hipLaunchKernelGGL((loss_main_dma_kernel<256, -1>), grid, block, 0, st, a, tbf); break;
-    case -2: hipLaunchKernelGGL((loss_main_dma_kernel<256, -2>), grid, block, 0, st, a, tbf); break;
+    // logging pass: masking on + in-batch negatives take the fast epilogue (loss_epilogue_logging_masked), as at H = 128.
+    // (Round 2 measured it 26 % SLOWER than the general epilogue at ONE wave per SIMD -- 2.21 against 1.75 ms at BASELINE
+    // config 5; the values-only kernels now run two waves per SIMD. XFMR_LOSS_LOGM256=0 keeps the general epilogue: A/B.)
+    case -1:
+      if (a.mask_fn && a.mode == XFMR_NEG_SHARED && logm256())
+        hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_LOG_MASKED_LSE>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<256, -1>), grid, block, 0, st, a, tbf);
+      break;
+    case -2:
+      if (a.mask_fn && a.mode == XFMR_NEG_SHARED && logm256())
+        hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_LOG_MASKED>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<256, -2>), grid, block, 0, st, a, tbf);
+      break;
     case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:
       hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_CONTRASTIVE:

@@ -622,11 +622,11 @@ int xfmr_embed_param_grads(const float* d_pre, float* d_pos, float* d_type, int3
   // d_pos (L*H) = column sums of d_pre viewed as [B][L*H]; rows L..max_pos-1 get no gradient
   if (int rc = xf_rowsum(d_pos, d_pre, B, (int64_t)L * H, st)) return rc;
   if (max_pos > L &&
-      hipMemsetAsync(d_pos + (int64_t)L * H, 0, (size_t)(max_pos - L) * H * sizeof(float), st) != hipSuccess)
+      xf_zero_async(d_pos + (int64_t)L * H, (size_t)(max_pos - L) * H * sizeof(float), st) != hipSuccess)
     return XFMR_EHIP;
   // d_type[0] = column sums of d_pos viewed as [L][H]; d_type[1] = 0 (token type 1 is never used)
   if (int rc = xf_rowsum(d_type, d_pos, L, H, st)) return rc;
-  if (hipMemsetAsync(d_type + H, 0, (size_t)H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
+  if (xf_zero_async(d_type + H, (size_t)H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
   return XFMR_OK;
 }
 

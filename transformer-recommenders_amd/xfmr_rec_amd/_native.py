@@ -49,6 +49,7 @@ class EncoderCfg(C.Structure):
         ("ln_eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float),
         ("flags", C.c_uint32), ("seed", C.c_uint64),
         ("step_device", C.c_void_p), ("embed_event", C.c_void_p), ("context", C.c_void_p),
+        ("grads_half_event", C.c_void_p),
     ]
 
 
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "xfmr_event_query": (C.c_int, [_P]),
     "xfmr_batch_upload": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
     "xfmr_param_count": (C.c_int64, [C.POINTER(EncoderCfg)]),
+    "xfmr_param_half_offset": (C.c_int64, [C.POINTER(EncoderCfg)]),
     "xfmr_param_offsets": (C.c_int32, [C.POINTER(EncoderCfg), C.POINTER(C.c_int64), C.c_int32]),
     "xfmr_embed_ln_fwd": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_uint32, _P]),

@@ -2,10 +2,11 @@
 
 The reference reaches data parallelism implicitly (Lightning ``strategy: auto`` -> torch DDP,
 ``config.yaml:5-6,35``): bucketed gradient all-reduce (SUM, then / world) and a ``DistributedSampler``.
-Here every trainable tensor and its gradient live in one flat buffer, so the exchange is a single
-``all_reduce`` over RCCL/xGMI (3.1 MiB at the MovieLens-1M config: latency-bound, one message beats
-buckets) and the 1/world factor is folded into the fused AdamW launch. The item table is frozen and
-replicated; negatives stay rank-local exactly as under the reference's DDP.
+Here every trainable tensor and its gradient live in one flat buffer, so the exchange is one
+``all_reduce`` over RCCL/xGMI (3.1 MiB at the MovieLens-1M config: latency-bound, buckets would only add
+latencies) -- or two halves, the upper layers' first, underneath the lower layers' backward
+(:class:`HalvedAllReduce`) -- and the 1/world factor is folded into the fused AdamW launch. The item table is
+frozen and replicated; negatives stay rank-local exactly as under the reference's DDP.
 """
 
 from __future__ import annotations
@@ -51,3 +52,66 @@ def allreduce_flat_grad_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return flat_grad
+
+
+class HalvedAllReduce:
+    """The gradient exchange of a step in TWO messages, the first one overlapped with the backward (SURVEY section 8e:
+    "overlapped with the last layers' backward"; the reference gets the same from torch DDP's buckets, ``config.yaml:5-6``).
+
+    ``xfmr_encoder_bwd`` finishes the gradients of layers >= layers / 2 -- the contiguous tail of the flat buffer from
+    ``boundary`` on -- as soon as that layer's backward is enqueued and records ``event`` behind them
+    (``xfmr_encoder_cfg.grads_half_event``). :meth:`reduce_` is called once the backward has been enqueued: the tail's
+    all-reduce goes to a communication stream that waits for the event only -- so on the GPU it runs beside the lower
+    layers' backward --, the head's follows the backward on the caller's stream, which then also waits for the tail. The
+    result equals one SUM all-reduce of the whole buffer (``tests/test_host_logic.py``). On CPU tensors (gloo) the two
+    slices are simply reduced one after the other."""
+
+    def __init__(self, model, group=None):
+        import ctypes
+
+        from . import _native as N
+        from . import ops
+
+        self.group = group
+        self.event = None
+        self.comm = None
+        c = model.config
+        cfg = ops.make_encoder_cfg(batch=1, seq_len=1, hidden=c.hidden_size, heads=c.num_attention_heads,
+                                   inter=c.intermediate_size, layers=c.num_hidden_layers, max_pos=c.max_seq_length,
+                                   precision=model.precision)
+        self.boundary = int(N.load().xfmr_param_half_offset(ctypes.byref(cfg)))
+        if model.flat.is_cuda:
+            e = ctypes.c_void_p()
+            with torch.cuda.device(model.device):
+                N.check(N.load().xfmr_event_create(ctypes.byref(e), 0), "xfmr_event_create")
+                self.comm = torch.cuda.Stream(device=model.device)
+            self.event = e.value
+            self._lib = N.load()
+        model.grads_half_event = self.event  # picked up by RecommenderModel._cfg
+
+    def reduce_(self, flat_grad: torch.Tensor) -> torch.Tensor:
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return flat_grad
+        b = self.boundary
+        head, tail = flat_grad[:b], flat_grad[b:]
+        if self.event is None or not flat_grad.is_cuda:
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+            if b > 0:
+                dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
+            return flat_grad
+        from . import _native as N
+
+        main = torch.cuda.current_stream()
+        N.check(self._lib.xfmr_stream_wait_event(self.comm.cuda_stream, self.event), "xfmr_stream_wait_event")
+        with torch.cuda.stream(self.comm):
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)  # beside the lower layers' backward
+        if b > 0:
+            dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)  # behind the backward's last launch
+        main.wait_stream(self.comm)
+        tail.record_stream(self.comm)
+        return flat_grad
+
+    def close(self):
+        if self.event is not None:
+            self._lib.xfmr_event_destroy(self.event)
+            self.event = None

@@ -325,6 +325,7 @@ class RecommenderModel(torch.nn.Module):
             causal=bool(c.is_decoder),  # BertConfig(is_decoder=...) (models.py:355): False = key-padding mask only
             step_device=step_dev if train else None, embed_event=embed_event,
             context=ctx.handle if ctx is not None else None,
+            grads_half_event=getattr(self, "grads_half_event", None),  # set by distributed.HalvedAllReduce
         )
 
     def _encode_tokens(self, item_idx=None, item_embeds=None, embed_event=None):

@@ -386,7 +386,7 @@ def encoder_flags_from_env() -> int:
 
 def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, precision, ln_eps=1e-12,
                      hidden_dropout=0.0, attn_dropout=0.0, seed=0, causal=True, flags=None, step_device=None,
-                     embed_event=None, context=None) -> N.EncoderCfg:
+                     embed_event=None, context=None, grads_half_event=None) -> N.EncoderCfg:
     """``step_device``: a uint32 device tensor (or pointer) mixed into the dropout stream on the device;
     ``embed_event``: a hipEvent_t handle the forward records once the key mask exists; ``context``: an
     ``xfmr_context`` handle (side stream of the backward's weight-gradient GEMMs)."""
@@ -400,7 +400,7 @@ def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, p
         batch=batch, seq_len=seq_len, hidden=hidden, heads=heads, inter=inter, layers=layers, max_pos=max_pos,
         precision=N.precision_id(precision), ln_eps=ln_eps, hidden_dropout=hidden_dropout,
         attn_dropout=attn_dropout, flags=f, seed=seed, step_device=step_device, embed_event=embed_event,
-        context=context,
+        context=context, grads_half_event=grads_half_event,
     )
 
 

@@ -502,9 +502,28 @@ class Trainer:
         self.optimizer = module.configure_optimizers()
         self.world_size = world_size
         self.process_group = process_group
+        self.exchange = None
         if world_size > 1:
+            import os
+
             for g in self.optimizer.param_groups:
                 g["grad_scale"] = 1.0 / world_size  # DDP averages gradients: SUM all-reduce then / W
+            if os.environ.get("XFMR_ALLREDUCE_SINGLE", "0") != "1":  # (=1: one message after the backward, as in round 2)
+                from .distributed import HalvedAllReduce
+
+                self.exchange = HalvedAllReduce(module.model, process_group)
+
+    def allreduce_(self, flat_grad: torch.Tensor) -> None:
+        """The step's one exchange: SUM of the flat gradient over the ranks (1 / W is folded into AdamW) -- in two
+        halves, the upper layers' underneath the rest of the backward, unless XFMR_ALLREDUCE_SINGLE=1."""
+        if self.world_size <= 1:
+            return
+        if self.exchange is not None:
+            self.exchange.reduce_(flat_grad)
+        else:
+            from .distributed import allreduce_flat_grad_
+
+            allreduce_flat_grad_(flat_grad, self.process_group)
 
     def fit_step(self, batch) -> torch.Tensor:
         """One step through the module's Lightning seam, in Lightning's order (``zero_grad -> training_step -> backward
@@ -514,10 +533,7 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         loss = m.training_step(batch, 0)
         loss.backward()
-        if self.world_size > 1:
-            from .distributed import allreduce_flat_grad_
-
-            allreduce_flat_grad_(m.model.flat.grad, self.process_group)
+        self.allreduce_(m.model.flat.grad)
         self.optimizer.step()
         m.on_train_batch_end(loss, batch, 0)  # joins the logging stream (leaving the pass to finish underneath the next
         return loss.detach()                  # step's forward measured no gain: 3.411 vs 3.414 ms)
