@@ -74,7 +74,12 @@ enum {
   XFMR_ENC_FFN_UNFUSED = 4u,     /* FFN forward as two GEMM launches                                               */
   XFMR_ENC_FFN_BWD_UNFUSED = 8u, /* FFN backward dX chain as two GEMM launches                                     */
   XFMR_ENC_DW_INLINE = 16u,      /* weight-gradient GEMMs on the caller's stream even when cfg.context is given     */
-  XFMR_ENC_FLAGS_ALL = 31u
+  XFMR_ENC_DW_SIDE_ANY = 32u,    /* ... on the context's side stream at ANY size. Without it the side stream is used from
+                                    65 536 tokens at d_model 128 only: below that the fork / join event calls of an eager
+                                    step cost the host more than the overlap gives the GPU. In a captured hipGraph
+                                    (xfmr_rec_amd.trainer.GraphedStep) those calls cost nothing at replay, and a small
+                                    step's weight-gradient GEMMs run beside its latency-bound dX chain.              */
+  XFMR_ENC_FLAGS_ALL = 63u
 };
 
 /* Loss heads, in the order of the reference's LOSS_CLASSES (xfmr_rec/losses.py:546-554). */
@@ -142,7 +147,7 @@ typedef struct xfmr_encoder_cfg {
   int32_t batch;      /* B: sequences in this call                                  */
   int32_t seq_len;    /* L: padded length of every sequence (<= max_pos)            */
   int32_t hidden;     /* H: d_model == item-embedding width (xfmr_rec/models.py:336-345) */
-  int32_t heads;      /* A: attention heads; H/A must be 32                          */
+  int32_t heads;      /* A: attention heads; H/A must be 32 or 64                    */
   int32_t inter;      /* I: FFN width                                                */
   int32_t layers;     /* number of BertLayers                                        */
   int32_t max_pos;    /* rows of the position-embedding table (ModelConfig.max_seq_length) */
@@ -245,7 +250,7 @@ int xfmr_colsum(const float* a, float* out, int64_t M, int32_t N, void* workspac
  * Replaces TF:models/bert/modeling_bert.py:111-136 (eager_attention_forward) / SDPA and the mask built
  * at TF:masking_utils.py:76-80,168-179: key k is visible to query q iff k <= q and key_mask[b,k].
  *   qkv (B*L,3H): [q | k | v] per token, heads along H; ctx (B*L,H); lse (B,A,L) log-sum-exp of the
- *   scaled scores (saved for backward). head size H/A must be 32. A query with no visible key gets ctx = 0.
+ *   scaled scores (saved for backward). head size H/A must be 32 or 64. A query with no visible key gets ctx = 0.
  * bwd: d_qkv (B*L,3H) from d_ctx, recomputing probabilities from qkv and lse.
  * ---------------------------------------------------------------------------------------------- */
 int xfmr_attn_fwd(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,

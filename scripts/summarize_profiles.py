@@ -35,10 +35,18 @@ def pmc_mean(path, counter, needle):
     return sum(v) / len(v) if v else None
 
 
+def steps_in(stats_csv, default):
+    """Training steps in a kernel_stats CSV = launches of the AdamW kernel (one per step)."""
+    for r in csv.DictReader(open(stats_csv)):
+        if "adamw_kernel" in r["Name"]:
+            return int(r["Calls"])
+    return default
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--steps", type=int, default=13)
+    ap.add_argument("--steps", type=int, default=0, help="steps in the traces (default: counted from the AdamW launches)")
     a = ap.parse_args()
     src = ROOT / "gpurun_out" / a.tag
     prof = ROOT / "profiles"
@@ -48,13 +56,25 @@ def main():
         stats = find(src / sub / "**" / "*kernel_stats.csv")
         if not stats:
             continue
+        n_steps = a.steps or steps_in(stats, 48)
         if not suffix:
             shutil.copy(stats, prof / f"{a.tag}_kernel_stats.csv")
-        md = subprocess.run([sys.executable, str(ROOT / "scripts" / "rocpd_stats.py"), stats, "--steps", str(a.steps),
+            main_steps = n_steps
+        md = subprocess.run([sys.executable, str(ROOT / "scripts" / "rocpd_stats.py"), stats, "--steps", str(n_steps),
                              "--top", "40", "--md"], capture_output=True, text=True, check=True).stdout
         head = (f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline"
-                f"{' --overlap on' if suffix else ' --overlap off'}  ({a.tag}; {a.steps} steps profiled)\n")
+                f"{' --overlap on' if suffix else ' --overlap off'}  ({a.tag}; {n_steps} steps profiled)\n")
         (prof / f"{a.tag}_kernel_stats{suffix}.md").write_text(head + md)
+    for v, what in (("config4", "--preset config4"), ("config5", "--preset config5"), ("b32", "--batch 32")):
+        stats = find(src / f"trace_{v}" / "**" / "*kernel_stats.csv")
+        if not stats:
+            continue
+        n_steps = a.steps or steps_in(stats, 48)
+        md = subprocess.run([sys.executable, str(ROOT / "scripts" / "rocpd_stats.py"), stats, "--steps", str(n_steps),
+                             "--top", "30", "--md"], capture_output=True, text=True, check=True).stdout
+        head = (f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline "
+                f"--overlap off --graph off {what}  ({a.tag}; {n_steps} steps profiled)\n")
+        (prof / f"{a.tag}_{v}_kernel_stats.md").write_text(head + md)
     f = find(src / "pmc_FETCH_SIZE" / "**" / "*counter_collection.csv")
     w = find(src / "pmc_WRITE_SIZE" / "**" / "*counter_collection.csv")
     static = {"source": f"profiles/{a.tag}_* (rocprofv3 runs of scripts/collect_profiles.sh {a.tag}; static, not measured in the bench run)",
@@ -77,6 +97,7 @@ def main():
     # GEMM family: compulsory bytes / GPU time of every gemm_kernel launch of one step (scripts/kernel_roofline.py table)
     stats = prof / f"{a.tag}_kernel_stats.csv"
     if stats.exists():
+        a.steps = a.steps or steps_in(stats, 48)
         out = subprocess.run([sys.executable, str(ROOT / "scripts" / "kernel_roofline.py"), str(stats), "--steps", str(a.steps),
                               "--json"], capture_output=True, text=True, check=True).stdout
         fam = json.loads(out)
@@ -84,6 +105,17 @@ def main():
         md = subprocess.run([sys.executable, str(ROOT / "scripts" / "kernel_roofline.py"), str(stats), "--steps", str(a.steps)],
                             capture_output=True, text=True, check=True).stdout
         (prof / f"{a.tag}_kernel_roofline.md").write_text(md)
+    # vector-instruction counts of the dominant kernel (the masked logging pass is bound by VALU issue, not by the matrix core)
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import summarize_pmc
+
+    for k, c in summarize_pmc.load(a.tag).items():
+        if "loss_main_dma_kernel<128, -3>" in k and "SQ_INSTS_VALU" in c:
+            static["dominant_kernel_valu"] = {
+                "kernel": k, "wave_instructions_per_launch": c["SQ_INSTS_VALU"],
+                "active_quad_cycles_per_launch": c.get("SQ_ACTIVE_INST_VALU"),
+                "mfma_wave_instructions_per_launch": c.get("SQ_INSTS_MFMA"),
+                "source": f"profiles/{a.tag}_loss_passes_pmc.md (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ..., scripts/pmc_loss_passes.sh)"}
     (prof / f"{a.tag}_bench_static.json").write_text(json.dumps(static, indent=1) + "\n")
     pm = subprocess.run([sys.executable, str(ROOT / "scripts" / "summarize_pmc.py"), a.tag, "--out",
                          str(prof / f"{a.tag}_loss_passes_pmc.md")], capture_output=True, text=True)

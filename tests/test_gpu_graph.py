@@ -35,8 +35,8 @@ def X():
     return X
 
 
-@pytest.mark.parametrize("train_loss", ["InfoNCELoss", "PairwiseLogisticLoss"])
-def test_graph_replay_equals_eager_steps_bit_for_bit_with_dropout(X, train_loss):
+@pytest.mark.parametrize("train_loss,overlap", [("InfoNCELoss", True), ("PairwiseLogisticLoss", True), ("InfoNCELoss", False)])
+def test_graph_replay_equals_eager_steps_bit_for_bit_with_dropout(X, train_loss, overlap):
     # eager: the same device-side step counter drives dropout and AdamW
     eager, batches = _setup(X, train_loss)
     eager.model.use_device_step(True)
@@ -44,7 +44,9 @@ def test_graph_replay_equals_eager_steps_bit_for_bit_with_dropout(X, train_loss)
     tr_e.optimizer.step_device = eager.model.step_device
     graphed, _ = _setup(X, train_loss)
     tr_g = X.Trainer(graphed)
-    step = X.GraphedStep(tr_g, batches[0], warmup=3)  # 3 eager warm-up steps on batches[0]; the capture itself runs nothing
+    # 3 eager warm-up steps on batches[0]; the capture itself runs nothing. overlap: the captured step forks its weight-gradient
+    # GEMMs and its logging heads onto side streams (graph branches) -- the eager reference runs everything in line
+    step = X.GraphedStep(tr_g, batches[0], warmup=3, overlap=overlap)
     for _ in range(3):
         tr_e.fit_step(batches[0])
     torch.cuda.synchronize()

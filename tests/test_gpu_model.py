@@ -127,15 +127,17 @@ def test_encoder_config5_shape_vs_oracle(X, prec, L, lengths):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("H,A,I", [(512, 16, 256), (320, 10, 160)])
+@pytest.mark.parametrize("H,A,I", [(512, 16, 256), (320, 10, 160), (384, 6, 96), (768, 12, 192), (128, 2, 256)])
 def test_encoder_other_d_model_vs_oracle(X, prec, H, A, I):
-    """d_model outside {64, 128, 256, 384} (any (V, H) table): 512 / 16 heads and 320 / 10 heads
-    through gather, LayerNorms, GEMMs and attention against the CPU oracle, every trainable tensor's gradient."""
+    """d_model outside {64, 128, 256, 384} (any (V, H) table) and head size 64 (models.py:22-48 takes
+    any hidden_size / num_attention_heads pair): 512 / 16 and 320 / 10 heads (head size 32), 384 / 6, 768 / 12 (the
+    all-mpnet shape) and 128 / 2 (head size 64) through gather, LayerNorms, GEMMs and attention against the CPU oracle,
+    every trainable tensor's gradient."""
     _encoder_shape_vs_oracle(X, prec, B=3, L=40, H=H, A=A, I=I, nL=2, V=150, lengths=[40, 23, 3])
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("H,A", [(512, 16), (320, 10)])
+@pytest.mark.parametrize("H,A", [(512, 16), (320, 10), (384, 6)])
 @pytest.mark.parametrize("train_loss", ["InfoNCELoss", "AlignmentContrastiveLoss"])
 def test_training_step_other_d_model_vs_oracle(X, prec, H, A, train_loss):
     """The whole step -- encoder, the fused loss of all seven heads, backward -- at a d_model the LDS-DMA loss kernel is not

@@ -168,10 +168,16 @@ def _attention_reference(qkv, key_mask, A, causal=True):
                                            (2, 200, 4, [200, 150]), (1, 256, 1, [250]),
                                            # L > 256: the two-block forward and the two-kernel backward
                                            (2, 320, 2, [320, 301]), (1, 512, 1, [512])])
-def test_attention_fwd_bwd(ops, prec, B, L, A, lengths, causal):
-    if prec == "fp32" and L > 256:
-        pytest.skip("fp32 parity policy: its kernels keep whole fp32 panels in LDS (L <= 256); see DESIGN.md section 2")
-    H = 32 * A
+@pytest.mark.parametrize("dh", [32, 64])
+def test_attention_fwd_bwd(ops, prec, B, L, A, lengths, causal, dh):
+    """dh = 32: the production kernels (bf16) / the generic ones (fp32); dh = 64 (e.g. 384 / 6, 768 / 12): the generic
+    kernels in both policies."""
+    if prec == "fp32" and L > (256 if dh == 32 else 128):
+        pytest.skip("fp32 parity policy: its kernels keep whole fp32 panels in LDS (L <= 256 at head size 32, <= 128 at "
+                    "64); see DESIGN.md section 2")
+    if dh == 64 and L > 256:
+        pytest.skip("head size 64: the generic kernels keep whole panels in LDS (the dK/dV kernel's four: L <= 256 in bf16)")
+    H = dh * A
     qkv = _rand(B, L, 3 * H, seed=3)
     mask = torch.zeros(B, L, dtype=torch.uint8)
     for b, n in enumerate(lengths):

@@ -64,6 +64,8 @@ def test_unsupported_shapes_are_rejected_on_the_host(native):
     lib = native.load()
     bad = ops.make_encoder_cfg(batch=2, seq_len=8, hidden=48, heads=1, inter=64, layers=1, max_pos=8, precision="bf16")
     assert lib.xfmr_encoder_workspace_bytes(C.byref(bad)) == 0  # head size 48
+    ok64 = ops.make_encoder_cfg(batch=2, seq_len=8, hidden=128, heads=2, inter=64, layers=1, max_pos=8, precision="bf16")
+    assert lib.xfmr_encoder_workspace_bytes(C.byref(ok64)) > 0  # head size 64: the generic attention kernels
     long = ops.make_encoder_cfg(batch=2, seq_len=16, hidden=64, heads=2, inter=64, layers=1, max_pos=8, precision="bf16")
     assert lib.xfmr_encoder_workspace_bytes(C.byref(long)) == 0  # seq_len > max_pos
     assert lib.xfmr_sampled_loss_workspace(1000, 128, 500) > 0
@@ -94,8 +96,9 @@ def test_config_surface_matches_reference_fields():
         "PairwiseHingeLoss", "PairwiseLogisticLoss"]
     with pytest.raises(ValueError, match="offline"):  # an unknown model name and nothing to derive the sizes from
         X.RecommenderModel(X.ModelConfig(pretrained_model_name="someone/unknown-model", num_attention_heads=None))
-    with pytest.raises(ValueError, match="must be 32"):
+    with pytest.raises(ValueError, match="must be 32 or 64"):
         X.RecommenderModel(X.ModelConfig(hidden_size=48, num_attention_heads=1))
+    assert X.RecommenderModel(X.ModelConfig(hidden_size=128, num_attention_heads=2)).config.hidden_size == 128  # head size 64
 
 
 # The `model.config` block of the reference's config.yaml, verbatim (config.yaml:46-79): `hidden_size: null` is what

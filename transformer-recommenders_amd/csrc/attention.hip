@@ -1,4 +1,5 @@
-// Causal self-attention with key-padding mask, head size 32, flash-style (scores never reach HBM).
+// Causal self-attention with key-padding mask, flash-style (scores never reach HBM): head size 32 (production kernels,
+// every BASELINE config and the reference's default 384 / 12) or 64 (generic kernels).
 //
 // Layout trick used by all three kernels (forward, dQ, dK/dV): every score tile is produced with the
 // softmax-reduction axis in the accumulator REGISTERS and the other axis on the LANE
@@ -26,52 +27,68 @@ struct AttnArgs {
   XfDropout drop;
 };
 
-// img[r][0..32) = src[(row0 + r) * stride + 0..32) for r in [0, nrows); rows >= row_end read as zero.
-template <class P>
-__device__ __forceinline__ void stage_rows(typename P::elem* img, int ld, const float* src, int64_t stride, int row0,
-                                           int nrows, int row_end) {
-  for (int c = threadIdx.x; c < nrows * 8; c += blockDim.x) {
-    const int r = c >> 3, dd = (c & 7) * 4;
+// img[r][0..DHT) = src[off + (row0 + r) * stride + 0..DHT) for r in [0, nrows); rows >= row_end read as zero.
+// (generic kernels below: head size DHT = 32 or 64, operands fp32 or -- S16 -- bf16 in HBM)
+template <class P, int DHT, bool S16>
+__device__ __forceinline__ void stage_rows(typename P::elem* img, int ld, const void* src, int64_t off, int64_t stride,
+                                           int row0, int nrows, int row_end) {
+  constexpr int CPR = DHT / 4;  // 4-element pieces per row
+  for (int c = threadIdx.x; c < nrows * CPR; c += blockDim.x) {
+    const int r = c / CPR, dd = (c % CPR) * 4;
     float4 v = make_float4(0, 0, 0, 0);
-    if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * stride + dd);
+    if (row0 + r < row_end) v = xf_ld4<S16>(src, off + (int64_t)(row0 + r) * stride + dd);
     xf_store4<P>(img + r * ld + dd, v);
   }
 }
-// imgT[d][r] = src[(row0 + r) * stride + d]
-template <class P>
-__device__ __forceinline__ void stage_rows_T(typename P::elem* imgT, int ldT, const float* src, int64_t stride,
+// imgT[d][r] = src[off + (row0 + r) * stride + d]
+template <class P, int DHT, bool S16>
+__device__ __forceinline__ void stage_rows_T(typename P::elem* imgT, int ldT, const void* src, int64_t off, int64_t stride,
                                              int row0, int nrows, int row_end) {
-  for (int c = threadIdx.x; c < (nrows / 2) * 8; c += blockDim.x) {
-    const int rp = c >> 3, dd = (c & 7) * 4;
+  constexpr int CPR = DHT / 4;
+  for (int c = threadIdx.x; c < (nrows / 2) * CPR; c += blockDim.x) {
+    const int rp = c / CPR, dd = (c % CPR) * 4;
     float4 v0 = make_float4(0, 0, 0, 0), v1 = v0;
     const int r = 2 * rp;
-    if (row0 + r < row_end) v0 = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * stride + dd);
-    if (row0 + r + 1 < row_end) v1 = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r + 1) * stride + dd);
+    if (row0 + r < row_end) v0 = xf_ld4<S16>(src, off + (int64_t)(row0 + r) * stride + dd);
+    if (row0 + r + 1 < row_end) v1 = xf_ld4<S16>(src, off + (int64_t)(row0 + r + 1) * stride + dd);
 #pragma unroll
     for (int j = 0; j < 4; ++j) xf_store2<P>(imgT + (dd + j) * ldT + r, xf_get(v0, j), xf_get(v1, j));
   }
 }
+// this lane's row of a register-resident operand, from fp32 or bf16 storage
+template <class P, int DHT, bool S16>
+__device__ __forceinline__ void load_reg_rows(RegRows<P, DHT>& reg, const void* base, int64_t idx, bool valid) {
+  if constexpr (S16) reg.load(reinterpret_cast<const __bf16*>(base) + idx, valid);
+  else reg.load(reinterpret_cast<const float*>(base) + idx, valid);
+}
 
-template <class P>
+template <class P, int DHT = DH>
 struct AttnSmem {
   using elem = typename P::elem;
-  static constexpr int LDR = xf_ld<P>(DH);  // row images [row][DH]
-  // transposed images [DH][rows]: rows + 4 keeps 8-byte row alignment and makes the b64 fragment reads
+  static constexpr int LDR = xf_ld<P>(DHT);  // row images [row][DHT]
+  // transposed images [DHT][rows]: rows + 4 keeps 8-byte row alignment and makes the b64 fragment reads
   // of 32 consecutive image rows hit 32 distinct even bank pairs (conflict-free)
   __host__ __device__ static int ldt(int rows) { return rows + 4; }
   __host__ __device__ static size_t row_img(int rows) { return (size_t)rows * LDR * sizeof(elem); }
-  __host__ __device__ static size_t t_img(int rows) { return (size_t)DH * ldt(rows) * sizeof(elem); }
+  __host__ __device__ static size_t t_img(int rows) { return (size_t)DHT * ldt(rows) * sizeof(elem); }
   __host__ __device__ static size_t align(size_t x) { return (x + 15) & ~(size_t)15; }
 };
+template <int DHT>
+__host__ __device__ constexpr float attn_scale() { return DHT == 64 ? 0.125f : 0.17677669529663687f; }  // 1 / sqrt(DHT)
 
 // ------------------------------------------------------------------------------------------------ forward
-template <class P>
+// Generic kernels (both precision policies, head size 32 or 64, fp32 or bf16 operands in HBM). The bf16 policy at head
+// size 32 -- the reference's 384 / 12 and every BASELINE config -- runs the production kernels further down; these
+// serve the fp32 parity policy and head size 64 (e.g. 384 / 6, 768 / 12: models.py:22-48 takes any hidden_size /
+// num_attention_heads pair).
+template <class P, int DHT, bool S16>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_in) {
   AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
   XF_CHAIN_PRIO();
   a.drop = xf_drop_resolve(a.drop);
   using elem = typename P::elem;
-  using SM = AttnSmem<P>;
+  using SM = AttnSmem<P, DHT>;
+  constexpr int ND = DHT / 32;  // 32-wide blocks of the head dimension
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
@@ -85,10 +102,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_in) {
   uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
 
   const int64_t tok0 = (int64_t)b * L;
-  const float* kbase = a.qkv + tok0 * 3 * H + H + h * DH;
-  const float* vbase = a.qkv + tok0 * 3 * H + 2 * H + h * DH;
-  stage_rows<P>(sK, SM::LDR, kbase, 3 * H, 0, nkeys, L);
-  stage_rows_T<P>(sVT, ldt, vbase, 3 * H, 0, nkeys, L);
+  const int64_t koff = tok0 * 3 * H + H + h * DHT, voff = tok0 * 3 * H + 2 * H + h * DHT;
+  stage_rows<P, DHT, S16>(sK, SM::LDR, a.qkv, koff, 3 * H, 0, nkeys, L);
+  stage_rows_T<P, DHT, S16>(sVT, ldt, a.qkv, voff, 3 * H, 0, nkeys, L);
   for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
   __syncthreads();
 
@@ -96,14 +112,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_in) {
   const int q0 = qblk0 + wid * 32;
   if (q0 >= L) return;
   const int q = q0 + (lane & 31);
-  RegRows<P, DH> qreg;
-  qreg.load(a.qkv + (tok0 + q) * 3 * H + h * DH, q < L);
+  RegRows<P, DHT> qreg;
+  load_reg_rows<P, DHT, S16>(qreg, a.qkv, (tok0 + q) * 3 * H + h * DHT, q < L);
 
-  const float sc = 0.17677669529663687f * kLog2e;  // 1/sqrt(32) in base-2 exponent units
+  const float sc = attn_scale<DHT>() * kLog2e;  // 1/sqrt(head size) in base-2 exponent units
   float m = -INFINITY, lsum = 0.f;
-  f32x16 o;
+  f32x16 o[ND];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  for (int j = 0; j < ND; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
   const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blockIdx.y * L + q));
 
   const int kb_end = a.causal ? min((q0 + 31) / 32, nkeys / 32 - 1) : nkeys / 32 - 1;
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_in) {
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    P::tile_nreg(s, sK, SM::LDR, kb * 32, qreg.regs(), DH);
+    P::tile_nreg(s, sK, SM::LDR, kb * 32, qreg.regs(), DHT);
     float bmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -134,25 +152,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a_in) {
     }
     lsum = lsum * alpha + psum;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    for (int j = 0; j < ND; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
     m = mnew;
-    P::tile_xb(o, sVT, ldt, 0, kb * 32, s);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) P::tile_xb(o[j], sVT, ldt, 32 * j, kb * 32, s);
   }
   const float ltot = lsum + xf_half_swap(lsum);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-  xf_store_tile_T(scratch + wid * 32 * 33, o, inv, a.ctx + tok0 * H + h * DH, H, q0, L);
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+    xf_store_tile_T_at<S16>(scratch + wid * 32 * 33, o[j], inv, a.ctx, tok0 * H + h * DHT + 32 * j, H, q0, L);
   if (lane < 32 && q < L)
     a.lse[((int64_t)blockIdx.y) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-template <class P>
+template <class P, int DHT, bool S16>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_in) {
   AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
   XF_CHAIN_PRIO();
   a.drop = xf_drop_resolve(a.drop);
   using elem = typename P::elem;
-  using SM = AttnSmem<P>;
+  using SM = AttnSmem<P, DHT>;
+  constexpr int ND = DHT / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
@@ -166,11 +190,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_in) {
   uint8_t* sMask = reinterpret_cast<uint8_t*>(scratch + 4 * 32 * 33);
 
   const int64_t tok0 = (int64_t)b * L;
-  const float* kbase = a.qkv + tok0 * 3 * H + H + h * DH;
-  const float* vbase = a.qkv + tok0 * 3 * H + 2 * H + h * DH;
-  stage_rows<P>(sK, SM::LDR, kbase, 3 * H, 0, nkeys, L);
-  stage_rows<P>(sV, SM::LDR, vbase, 3 * H, 0, nkeys, L);
-  stage_rows_T<P>(sKT, ldt, kbase, 3 * H, 0, nkeys, L);
+  const int64_t koff = tok0 * 3 * H + H + h * DHT, voff = tok0 * 3 * H + 2 * H + h * DHT;
+  stage_rows<P, DHT, S16>(sK, SM::LDR, a.qkv, koff, 3 * H, 0, nkeys, L);
+  stage_rows<P, DHT, S16>(sV, SM::LDR, a.qkv, voff, 3 * H, 0, nkeys, L);
+  stage_rows_T<P, DHT, S16>(sKT, ldt, a.qkv, koff, 3 * H, 0, nkeys, L);
   for (int t = threadIdx.x; t < nkeys; t += blockDim.x) sMask[t] = (t < L) ? a.key_mask[tok0 + t] : 0;
   __syncthreads();
 
@@ -179,36 +202,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_in) {
   if (q0 >= L) return;
   const int q = q0 + (lane & 31);
   const bool qv = q < L;
-  RegRows<P, DH> qreg, doreg;
-  qreg.load(a.qkv + (tok0 + q) * 3 * H + h * DH, qv);
-  doreg.load(a.d_ctx + (tok0 + q) * H + h * DH, qv);
-  // delta = rowsum(dO * O) in fp32 from the unrounded tensors; each lane half covers 16 of the 32 dims
+  RegRows<P, DHT> qreg, doreg;
+  load_reg_rows<P, DHT, S16>(qreg, a.qkv, (tok0 + q) * 3 * H + h * DHT, qv);
+  load_reg_rows<P, DHT, S16>(doreg, a.d_ctx, (tok0 + q) * H + h * DHT, qv);
+  // delta = rowsum(dO * O) in fp32 from the stored tensors; each lane half covers half of the head's dims
   float delta = 0.f;
   if (qv) {
-    const float* po = a.ctx + (tok0 + q) * H + h * DH + 16 * (lane >> 5);
-    const float* pd = a.d_ctx + (tok0 + q) * H + h * DH + 16 * (lane >> 5);
+    const int64_t o0 = (tok0 + q) * H + h * DHT + (DHT / 2) * (lane >> 5);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float4 x = *reinterpret_cast<const float4*>(po + 4 * u);
-      const float4 y = *reinterpret_cast<const float4*>(pd + 4 * u);
+    for (int u = 0; u < DHT / 8; ++u) {
+      const float4 x = xf_ld4<S16>(a.ctx, o0 + 4 * u);
+      const float4 y = xf_ld4<S16>(a.d_ctx, o0 + 4 * u);
       delta += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
     }
   }
   delta += xf_half_swap(delta);
   const float lse2 = qv ? a.lse[(int64_t)blockIdx.y * L + q] * kLog2e : INFINITY;
-  const float sc = 0.17677669529663687f * kLog2e;
+  const float sc = attn_scale<DHT>() * kLog2e;
   const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blockIdx.y * L + q));
 
-  f32x16 dq;
+  f32x16 dq[ND];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  for (int j = 0; j < ND; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[j][r] = 0.f;
   const int kb_end = a.causal ? min((q0 + 31) / 32, nkeys / 32 - 1) : nkeys / 32 - 1;
   for (int kb = 0; kb <= kb_end; ++kb) {
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-    P::tile_nreg(s, sK, SM::LDR, kb * 32, qreg.regs(), DH);
-    P::tile_nreg(dp, sV, SM::LDR, kb * 32, doreg.regs(), DH);
+    P::tile_nreg(s, sK, SM::LDR, kb * 32, qreg.regs(), DHT);
+    P::tile_nreg(dp, sV, SM::LDR, kb * 32, doreg.regs(), DHT);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kb * 32 + xf_acc_row(r, lane);
@@ -218,19 +242,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a_in) {
       if (a.drop.on) dpv *= xf_keep_scale_rc(a.drop, rowkey, (uint32_t)key * kDropColMul);
       s[r] = p * (dpv - delta);
     }
-    P::tile_xb(dq, sKT, ldt, 0, kb * 32, s);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) P::tile_xb(dq[j], sKT, ldt, 32 * j, kb * 32, s);
   }
-  xf_store_tile_T(scratch + wid * 32 * 33, dq, 0.17677669529663687f, a.d_qkv + tok0 * 3 * H + h * DH, 3 * H, q0, L);
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+    xf_store_tile_T_at<S16>(scratch + wid * 32 * 33, dq[j], attn_scale<DHT>(), a.d_qkv, tok0 * 3 * H + h * DHT + 32 * j, 3 * H,
+                            q0, L);
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <class P>
+template <class P, int DHT, bool S16>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a_in) {
   AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
   XF_CHAIN_PRIO();
   a.drop = xf_drop_resolve(a.drop);
   using elem = typename P::elem;
-  using SM = AttnSmem<P>;
+  using SM = AttnSmem<P, DHT>;
+  constexpr int ND = DHT / 32, CPR = DHT / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, H = a.H;
   const int b = blockIdx.y / a.A, h = blockIdx.y % a.A;
@@ -248,25 +277,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a_in) 
   float* sDelta = sLse + nq;            // [nq]
 
   const int64_t tok0 = (int64_t)b * L;
-  const float* qbase = a.qkv + tok0 * 3 * H + h * DH;
-  const float* dobase = a.d_ctx + tok0 * H + h * DH;
-  const float* obase = a.ctx + tok0 * H + h * DH;
-  stage_rows<P>(sQ, SM::LDR, qbase, 3 * H, qs, nq, L);
-  stage_rows<P>(sDO, SM::LDR, dobase, H, qs, nq, L);
-  stage_rows_T<P>(sQT, ldt, qbase, 3 * H, qs, nq, L);
-  stage_rows_T<P>(sDOT, ldt, dobase, H, qs, nq, L);
-  for (int c = threadIdx.x; c < nq * 8; c += blockDim.x) {  // delta: 8 consecutive lanes share a row
-    const int r = c >> 3, dd = (c & 7) * 4;
+  const int64_t qoff = tok0 * 3 * H + h * DHT, dooff = tok0 * H + h * DHT;
+  stage_rows<P, DHT, S16>(sQ, SM::LDR, a.qkv, qoff, 3 * H, qs, nq, L);
+  stage_rows<P, DHT, S16>(sDO, SM::LDR, a.d_ctx, dooff, H, qs, nq, L);
+  stage_rows_T<P, DHT, S16>(sQT, ldt, a.qkv, qoff, 3 * H, qs, nq, L);
+  stage_rows_T<P, DHT, S16>(sDOT, ldt, a.d_ctx, dooff, H, qs, nq, L);
+  for (int c = threadIdx.x; c < nq * CPR; c += blockDim.x) {  // delta: CPR consecutive lanes share a row
+    const int r = c / CPR, dd = (c % CPR) * 4;
     float part = 0.f;
     if (qs + r < L) {
-      const float4 x = *reinterpret_cast<const float4*>(obase + (int64_t)(qs + r) * H + dd);
-      const float4 y = *reinterpret_cast<const float4*>(dobase + (int64_t)(qs + r) * H + dd);
+      const float4 x = xf_ld4<S16>(a.ctx, dooff + (int64_t)(qs + r) * H + dd);
+      const float4 y = xf_ld4<S16>(a.d_ctx, dooff + (int64_t)(qs + r) * H + dd);
       part = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
     }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    if ((c & 7) == 0) {
+#pragma unroll
+    for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o, 64);
+    if ((c % CPR) == 0) {
       sDelta[r] = part;
       sLse[r] = (qs + r < L) ? a.lse[(int64_t)blockIdx.y * L + qs + r] * kLog2e : INFINITY;
     }
@@ -278,21 +304,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a_in) 
   if (k0 >= L) return;
   const int key = k0 + (lane & 31);
   const bool kvis = key < L && a.key_mask[tok0 + (key < L ? key : 0)];
-  RegRows<P, DH> kreg, vreg;
-  kreg.load(a.qkv + (tok0 + key) * 3 * H + H + h * DH, key < L);
-  vreg.load(a.qkv + (tok0 + key) * 3 * H + 2 * H + h * DH, key < L);
-  const float sc = 0.17677669529663687f * kLog2e;
+  RegRows<P, DHT> kreg, vreg;
+  load_reg_rows<P, DHT, S16>(kreg, a.qkv, (tok0 + key) * 3 * H + H + h * DHT, key < L);
+  load_reg_rows<P, DHT, S16>(vreg, a.qkv, (tok0 + key) * 3 * H + 2 * H + h * DHT, key < L);
+  const float sc = attn_scale<DHT>() * kLog2e;
 
-  f32x16 dk, dv;
+  f32x16 dk[ND], dv[ND];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+  for (int j = 0; j < ND; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
   for (int qb = a.causal ? k0 / 32 : 0; qb < Lp / 32; ++qb) {
     const int row0 = qb * 32 - qs;
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-    P::tile_nreg(s, sQ, SM::LDR, row0, kreg.regs(), DH);
-    P::tile_nreg(dp, sDO, SM::LDR, row0, vreg.regs(), DH);
+    P::tile_nreg(s, sQ, SM::LDR, row0, kreg.regs(), DHT);
+    P::tile_nreg(dp, sDO, SM::LDR, row0, vreg.regs(), DHT);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = row0 + xf_acc_row(r, lane);
@@ -304,12 +332,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a_in) 
       s[r] = p * (dp[r] * keep - sDelta[qi]);  // dS
       dp[r] = p * keep;                        // P.D
     }
-    P::tile_xb(dv, sDOT, ldt, 0, row0, dp);
-    P::tile_xb(dk, sQT, ldt, 0, row0, s);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      P::tile_xb(dv[j], sDOT, ldt, 32 * j, row0, dp);
+      P::tile_xb(dk[j], sQT, ldt, 32 * j, row0, s);
+    }
   }
   float* sc_w = scratch + wid * 32 * 33;
-  xf_store_tile_T(sc_w, dk, 0.17677669529663687f, a.d_qkv + tok0 * 3 * H + H + h * DH, 3 * H, k0, L);
-  xf_store_tile_T(sc_w, dv, 1.f, a.d_qkv + tok0 * 3 * H + 2 * H + h * DH, 3 * H, k0, L);
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    xf_store_tile_T_at<S16>(sc_w, dk[j], attn_scale<DHT>(), a.d_qkv, tok0 * 3 * H + H + h * DHT + 32 * j, 3 * H, k0, L);
+    xf_store_tile_T_at<S16>(sc_w, dv[j], 1.f, a.d_qkv, tok0 * 3 * H + 2 * H + h * DHT + 32 * j, 3 * H, k0, L);
+  }
 }
 
 // ================================================================================================================
@@ -1101,21 +1135,21 @@ size_t bf16_smem_dkv(int L) {  // Q + dO images (aliased by the scratch), lse + 
   return bf16_panel_bytes(L) + 3 * (size_t)Lp * sizeof(float);
 }
 
-template <class P>
+template <class P, int DHT = DH>
 size_t fwd_smem(int L) {
-  using SM = AttnSmem<P>;
+  using SM = AttnSmem<P, DHT>;
   const int Lp = ((L + 31) / 32) * 32;
   return SM::align(SM::row_img(Lp)) + SM::align(SM::t_img(Lp)) + 4 * 32 * 33 * sizeof(float) + Lp;
 }
-template <class P>
+template <class P, int DHT = DH>
 size_t dq_smem(int L) {
-  using SM = AttnSmem<P>;
+  using SM = AttnSmem<P, DHT>;
   const int Lp = ((L + 31) / 32) * 32;
   return 2 * SM::align(SM::row_img(Lp)) + SM::align(SM::t_img(Lp)) + 4 * 32 * 33 * sizeof(float) + Lp;
 }
-template <class P>
+template <class P, int DHT = DH>
 size_t dkv_smem(int L) {
-  using SM = AttnSmem<P>;
+  using SM = AttnSmem<P, DHT>;
   const int Lp = ((L + 31) / 32) * 32;
   return 2 * SM::align(SM::row_img(Lp)) + 2 * SM::align(SM::t_img(Lp)) + 4 * 32 * 33 * sizeof(float) +
          2 * (size_t)Lp * sizeof(float);
@@ -1173,46 +1207,60 @@ int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
   return XFMR_OK;
 }
 
-template <class P>
-int launch_fwd(const AttnArgs& a, hipStream_t st) {
+// The generic kernels: fp32 policy at head size 32, and both policies at head size 64 (operands fp32, or bf16 when S16).
+template <class P, int DHT, bool S16>
+int launch_fwd_generic(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.L + 127) / 128, a.B * a.A);
-  if constexpr (P::kId == XFMR_PREC_BF16) {
-    return launch_fwd_bf16<false>(a, st);
-  } else {
-    const size_t sm = fwd_smem<P>(a.L);
-    if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
-    if (hipFuncSetAttribute((const void*)attn_fwd_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
-        hipSuccess)
-      return XFMR_EHIP;
-    hipLaunchKernelGGL((attn_fwd_kernel<P>), grid, dim3(256), sm, st, a);
-  }
+  const size_t sm = fwd_smem<P, DHT>(a.L);
+  if (sm > kLdsLimit) return XFMR_EUNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)attn_fwd_kernel<P, DHT, S16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
+      hipSuccess)
+    return XFMR_EHIP;
+  hipLaunchKernelGGL((attn_fwd_kernel<P, DHT, S16>), grid, dim3(256), sm, st, a);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
-template <class P>
-int launch_bwd(const AttnArgs& a, hipStream_t st) {
+template <class P, int DHT, bool S16>
+int launch_bwd_generic(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.L + 127) / 128, a.B * a.A);
-  if constexpr (P::kId == XFMR_PREC_BF16) {
-    return launch_bwd_bf16<false>(a, st);
-  } else {
-    const size_t s1 = dq_smem<P>(a.L), s2 = dkv_smem<P>(a.L);
-    if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
-    if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)s1) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)s2) != hipSuccess)
-      return XFMR_EHIP;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<P>), grid, dim3(256), s1, st, a);
-    XF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P>), grid, dim3(256), s2, st, a);
-  }
+  const size_t s1 = dq_smem<P, DHT>(a.L), s2 = dkv_smem<P, DHT>(a.L);
+  if (s1 > kLdsLimit || s2 > kLdsLimit) return XFMR_EUNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<P, DHT, S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)s1) != hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<P, DHT, S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)s2) != hipSuccess)
+    return XFMR_EHIP;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<P, DHT, S16>), grid, dim3(256), s1, st, a);
+  XF_LAUNCH_CHECK();
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, DHT, S16>), grid, dim3(256), s2, st, a);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
+}
+// precision x storage x head size -> kernel family
+int dispatch_fwd(const AttnArgs& a, int precision, bool s16, hipStream_t st) {
+  const int dh = a.H / a.A;
+  if (precision == XFMR_PREC_BF16) {
+    if (dh == 32) return s16 ? launch_fwd_bf16<true>(a, st) : launch_fwd_bf16<false>(a, st);
+    return s16 ? launch_fwd_generic<PrecBF16, 64, true>(a, st) : launch_fwd_generic<PrecBF16, 64, false>(a, st);
+  }
+  if (precision == XFMR_PREC_F32 && !s16)
+    return dh == 32 ? launch_fwd_generic<PrecF32, 32, false>(a, st) : launch_fwd_generic<PrecF32, 64, false>(a, st);
+  return XFMR_EINVAL;
+}
+int dispatch_bwd(const AttnArgs& a, int precision, bool s16, hipStream_t st) {
+  const int dh = a.H / a.A;
+  if (precision == XFMR_PREC_BF16) {
+    if (dh == 32) return s16 ? launch_bwd_bf16<true>(a, st) : launch_bwd_bf16<false>(a, st);
+    return s16 ? launch_bwd_generic<PrecBF16, 64, true>(a, st) : launch_bwd_generic<PrecBF16, 64, false>(a, st);
+  }
+  if (precision == XFMR_PREC_F32 && !s16)
+    return dh == 32 ? launch_bwd_generic<PrecF32, 32, false>(a, st) : launch_bwd_generic<PrecF32, 64, false>(a, st);
+  return XFMR_EINVAL;
 }
 
 int check_shape(int B, int L, int A, int H) {
   if (B <= 0 || L <= 0 || A <= 0 || H <= 0) return XFMR_EINVAL;
-  if (H != A * DH) return XFMR_EUNSUPPORTED;  // head size must be 32
+  if (H != A * 32 && H != A * 64) return XFMR_EUNSUPPORTED;  // head size 32 (the production kernels) or 64 (generic kernels)
   return XFMR_OK;
 }
 
@@ -1230,9 +1278,7 @@ int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* l
   a.qkv = (const float*)qkv; a.key_mask = key_mask; a.ctx = (float*)ctx; a.lse = lse; a.B = B; a.L = L; a.A = A;
   a.H = H; a.causal = causal;
   a.drop = xf_make_dropout(dropout_p, seed, site);
-  if (precision == XFMR_PREC_BF16) return s16 ? launch_fwd_bf16<true>(a, st) : launch_fwd<PrecBF16>(a, st);
-  if (precision == XFMR_PREC_F32 && !s16) return launch_fwd<PrecF32>(a, st);
-  return XFMR_EINVAL;
+  return dispatch_fwd(a, precision, s16, st);
 }
 
 int xfmr_attn_fwd(const float* qkv, const uint8_t* key_mask, float* ctx, float* lse, int32_t B, int32_t L,
@@ -1260,9 +1306,7 @@ int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, co
   a.lse = const_cast<float*>(lse); a.d_ctx = (const float*)d_ctx; a.d_qkv = (float*)d_qkv;
   a.B = B; a.L = L; a.A = A; a.H = H; a.causal = causal;
   a.drop = xf_make_dropout(dropout_p, seed, site);
-  if (precision == XFMR_PREC_BF16) return s16 ? launch_bwd_bf16<true>(a, st) : launch_bwd<PrecBF16>(a, st);
-  if (precision == XFMR_PREC_F32 && !s16) return launch_bwd<PrecF32>(a, st);
-  return XFMR_EINVAL;
+  return dispatch_bwd(a, precision, s16, st);
 }
 
 int xfmr_attn_bwd(const float* qkv, const uint8_t* key_mask, const float* ctx, const float* lse,

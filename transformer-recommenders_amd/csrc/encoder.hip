@@ -116,7 +116,8 @@ bool ffn_fused(const xfmr_encoder_cfg* c, int64_t T) {
 bool dw_side_shape(const xfmr_encoder_cfg* c, int64_t T) {
   // (T >= 65 536: at batch 128 x 200 tokens the step is 1.36 ms of ~70 launches from one host thread and the 32 extra event
   //  calls cost more than the overlap gives -- 1.40 vs 1.355 ms; batch 256: even; batch 512: -2.4 %)
-  return mixed_storage(c) && c->hidden == 128 && T >= 65536 && c->layers <= 64;
+  if (!mixed_storage(c) || c->layers > 64) return false;
+  return (c->flags & XFMR_ENC_DW_SIDE_ANY) || (c->hidden == 128 && T >= 65536);
 }
 
 // Carves `base` (may be null: size query). Layer i's activations are returned in *la when i >= 0.
@@ -199,7 +200,7 @@ int check_cfg(const xfmr_encoder_cfg* c) {
   if (c->batch <= 0 || c->seq_len <= 0 || c->hidden <= 0 || c->heads <= 0 || c->inter <= 0 || c->layers <= 0)
     return XFMR_EINVAL;
   if (c->seq_len > c->max_pos) return XFMR_EINVAL;
-  if (c->hidden != c->heads * 32 || (c->inter & 3)) return XFMR_EUNSUPPORTED;
+  if ((c->hidden != c->heads * 32 && c->hidden != c->heads * 64) || (c->inter & 3)) return XFMR_EUNSUPPORTED;
   if (c->precision != XFMR_PREC_F32 && c->precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   if (c->flags & ~(uint32_t)XFMR_ENC_FLAGS_ALL) return XFMR_EINVAL;  // unknown flag bits
   return XFMR_OK;
@@ -225,9 +226,9 @@ const char* xfmr_strerror(int code) {
     case XFMR_OK: return "ok";
     case XFMR_EINVAL: return "invalid argument";
     case XFMR_EUNSUPPORTED:
-      return "shape not supported by the gfx950 kernels (head size must be 32; the fused loss takes any d_model that is a "
-             "multiple of 32 up to 1024 in the bf16 policy and up to 512 in fp32; attention panels must fit LDS: L <= 256 in "
-             "the fp32 policy, L <= 1024 in bf16)";
+      return "shape not supported by the gfx950 kernels (head size must be 32 or 64; the fused loss takes any d_model that is a "
+             "multiple of 32 up to 1024 in the bf16 policy and up to 512 in fp32; attention panels must fit LDS: head size 32 -- "
+             "L <= 256 in the fp32 policy, L <= 1024 in bf16; head size 64 -- L <= 128 in fp32, L <= 256 in bf16)";
     case XFMR_EWORKSPACE: return "workspace too small";
     case XFMR_EHIP: return "HIP launch failed";
     case XFMR_EALIGN: return "pointer or leading dimension not 16-byte aligned";
@@ -434,7 +435,9 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   // write-after-read events the chain kept stalling on the lagging side stream: 0.4 % instead of 2 %).
   // No context, or XFMR_ENC_DW_INLINE: everything on `st`.
   XfContext* const ctx = (XfContext*)cfg->context;
-  const bool dw_side = ctx && fuse_lnb && dw_side_shape(cfg, T) && !(cfg->flags & XFMR_ENC_DW_INLINE);
+  // (the per-layer gradient buffers make this independent of the LayerNorm-fused forms: a dW GEMM only ever reads dLinF /
+  //  dLinO / dI / dQKV of ITS layer and activations of the forward)
+  const bool dw_side = ctx && dw_side_shape(cfg, T) && !(cfg->flags & XFMR_ENC_DW_INLINE);
   hipStream_t const side = dw_side ? ctx->side : nullptr;
   hipEvent_t const ev_in = dw_side ? ctx->ev_in : nullptr, ev_done = dw_side ? ctx->ev_done : nullptr;
   bool side_used = false;

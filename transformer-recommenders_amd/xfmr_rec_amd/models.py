@@ -153,10 +153,11 @@ class RecommenderModel(torch.nn.Module):
 
     def configure_model(self, device=None, seed: int = 0) -> None:
         c = self.resolve_config(self.config)
-        if c.hidden_size != 32 * c.num_attention_heads:
+        if c.hidden_size not in (32 * c.num_attention_heads, 64 * c.num_attention_heads):
             raise ValueError(
-                f"hidden_size / num_attention_heads must be 32 (got {c.hidden_size}/{c.num_attention_heads}): "
-                "the gfx950 attention kernels are built for head size 32 (the reference's 384/12)"
+                f"hidden_size / num_attention_heads must be 32 or 64 (got {c.hidden_size}/{c.num_attention_heads}): the "
+                "gfx950 attention kernels are built for head size 32 (the reference's 384/12; the production kernels) "
+                "and 64 (e.g. 384/6, 768/12; generic kernels)"
             )
         H, I, Lm, nL = c.hidden_size, c.intermediate_size, c.max_seq_length, c.num_hidden_layers
         names, shapes, offsets, total = flat_layout(H, I, Lm, nL)
@@ -326,6 +327,7 @@ class RecommenderModel(torch.nn.Module):
             step_device=step_dev if train else None, embed_event=embed_event,
             context=ctx.handle if ctx is not None else None,
             grads_half_event=getattr(self, "grads_half_event", None),  # set by distributed.HalvedAllReduce
+            extra_flags=getattr(self, "enc_flags", 0),  # e.g. ENC_DW_SIDE_ANY inside a captured step (GraphedStep)
         )
 
     def _encode_tokens(self, item_idx=None, item_embeds=None, embed_event=None):

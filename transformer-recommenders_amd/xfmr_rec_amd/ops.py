@@ -386,11 +386,12 @@ def encoder_flags_from_env() -> int:
 
 def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, precision, ln_eps=1e-12,
                      hidden_dropout=0.0, attn_dropout=0.0, seed=0, causal=True, flags=None, step_device=None,
-                     embed_event=None, context=None, grads_half_event=None) -> N.EncoderCfg:
+                     embed_event=None, context=None, grads_half_event=None, extra_flags=0) -> N.EncoderCfg:
     """``step_device``: a uint32 device tensor (or pointer) mixed into the dropout stream on the device;
     ``embed_event``: a hipEvent_t handle the forward records once the key mask exists; ``context``: an
     ``xfmr_context`` handle (side stream of the backward's weight-gradient GEMMs)."""
     f = encoder_flags_from_env() if flags is None else int(flags)
+    f |= int(extra_flags)
     if not causal:
         f |= N.ENC_BIDIRECTIONAL
     if isinstance(step_device, torch.Tensor):

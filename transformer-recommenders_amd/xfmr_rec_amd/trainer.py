@@ -594,7 +594,12 @@ class GraphedStep:
 
     Single process only (the all-reduce of a data-parallel step is not captured here)."""
 
-    def __init__(self, trainer: Trainer, example_batch: dict, warmup: int = 3):
+    def __init__(self, trainer: Trainer, example_batch: dict, warmup: int = 3, overlap: bool = False):
+        """``overlap=True`` captures the step with its two forks at ANY size -- the weight-gradient GEMMs on the context's
+        side stream (``XFMR_ENC_DW_SIDE_ANY``) and the logging heads on the logging stream (``defer_logging``) -- as
+        branches of the graph. Same bits (tests/test_gpu_graph.py), but on this runtime (ROCm 7.2 / torch 2.10) a graph
+        with cross-stream branches replays 2-3x SLOWER than the single-stream capture (config 2 at batch 32: 2.07 ms
+        against 0.85; H 64 / L 50 / batch 64: 1.39 against 0.31), so the default is the single-stream step."""
         from .data import SEQ_BATCH_KEYS
 
         m = trainer.module
@@ -602,6 +607,11 @@ class GraphedStep:
             raise ValueError("GraphedStep captures a single-process step")
         self.trainer, self.keys = trainer, SEQ_BATCH_KEYS
         dev = m.model.device
+        if overlap:
+            m.model.enc_flags = getattr(m.model, "enc_flags", 0) | N.ENC_DW_SIDE_ANY
+            m.defer_logging = True
+        elif getattr(m, "defer_logging", "auto") == "auto":
+            m.defer_logging = False  # one stream inside the capture
         if getattr(m.model, "step_device", None) is None:
             m.model.use_device_step(True)
         trainer.optimizer.step_device = m.model.step_device
