@@ -47,10 +47,14 @@ if hasattr(lib, "xf_diag_set_buffer"):  # a build with XF_LN_DIAG & 4: per (row,
     lib.xf_diag_set_buffer(N.ptr(DBG))
 
 
+lib.xf_ln_row_tiles.restype, lib.xf_ln_row_tiles.argtypes = C.c_int, [C.c_int64]
+N_TILES = max(lib.xf_ln_row_tiles(M), PROD.xf_ln_row_tiles(M)) if hasattr(lib, "xf_ln_row_tiles") else (M + 63) // 64
+
+
 def run_bwd(p_drop, fn=fn):
     dx = torch.empty(M, K, device=DEV)
     d16 = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
-    parts = torch.zeros((M + 63) // 64, 3, K, device=DEV)
+    parts = torch.zeros(N_TILES, 3, K, device=DEV)
     blocks = C.c_int(0)
     rc = fn(N.ptr(dy), N.ptr(w), M, Nn, K, N.ptr(rg), N.ptr(lnx), N.ptr(mean), N.ptr(rstd), N.ptr(gamma), p_drop, 5, 9,
             N.ptr(dx), N.ptr(d16), N.ptr(parts), C.byref(blocks), N.precision_id("bf16"), 3, N.stream(), 0.0, 0)

@@ -565,14 +565,19 @@ def test_dx_gemm_with_layernorm_backward_epilogue_vs_separate_kernels_and_bit_re
         C.c_float, N.Seed, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int32,
         C.c_uint32, C.c_void_p, C.c_float, C.c_uint32]
 
+    # row tiles = LayerNorm partial records: (M + 63) / 64, or more when the last round is dealt as short tiles
+    lib.xf_ln_row_tiles.restype, lib.xf_ln_row_tiles.argtypes = C.c_int, [C.c_int64]
+    n_tiles = lib.xf_ln_row_tiles(M)
+    assert n_tiles >= (M + 63) // 64
+
     def run():
         dx = torch.empty(M, K, device=DEV)
         d16 = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
-        parts = torch.zeros((M + 63) // 64, 3, K, device=DEV)
+        parts = torch.zeros(n_tiles, 3, K, device=DEV)
         blocks = C.c_int(0)
         rc = fn(N.ptr(dy), N.ptr(w), M, Nn, K, N.ptr(rg), N.ptr(lnx), N.ptr(mean), N.ptr(rstd), N.ptr(gamma), p_drop, 5,
                 9, N.ptr(dx), N.ptr(d16), N.ptr(parts), C.byref(blocks), N.precision_id("bf16"), 3, N.stream(), 0.0, 0)
-        assert rc == 0 and blocks.value == (M + 63) // 64
+        assert rc == 0 and blocks.value == n_tiles
         return dx, d16, parts
 
     dx, d16, parts = run()

@@ -448,3 +448,41 @@ def test_configure_embeddings_builds_the_padded_table_and_id2idx():
     m = X.RecommenderModel(cfg, device="cpu")
     with pytest.raises(ValueError, match="width 32 != hidden_size 64"):
         m.configure_embeddings({"item_id": ids, "embedding": np.zeros((7, 32), np.float32)})
+
+
+def test_structured_candidates_behave_like_the_dense_tensor_they_stand_for():
+    """compute_embeds returns the (Np, 1+N, H) candidates structured (models.py:408-416 would materialise O(N^2 H) bytes);
+    a caller of the reference that looks at the tensor -- shape, size, dim, dtype, indexing rows / columns -- gets what
+    the dense tensor would give."""
+    from xfmr_rec_amd.losses import CatalogCandidates, SharedNegatives
+
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(20, 8, generator=g)
+    pos, neg = torch.tensor([3, 7, 7, 1, 19]), torch.tensor([2, 5, 7, 11])
+    c = SharedNegatives(table, torch.ones(20), pos, neg)
+    dense = torch.cat([table[pos][:, None], table[neg][None].expand(5, -1, -1)], 1)
+    assert c.shape == dense.shape and c.size(1) == 5 and c.dim() == 3 and len(c) == 5 and c.dtype == dense.dtype
+    assert torch.equal(c.materialize(), dense)
+    assert torch.equal(c[2], dense[2]) and torch.equal(c[-1], dense[-1]) and torch.equal(c[1:4], dense[1:4])
+    assert torch.equal(c[:, 0], dense[:, 0]) and torch.equal(c[2, 1:], dense[2, 1:]) and torch.equal(c[[0, 4], 2], dense[[0, 4], 2])
+    k = CatalogCandidates(table, torch.ones(20), 3)
+    assert k.shape == (3, 20, 8) and torch.equal(k[1], table) and torch.equal(k[:, 4], table[4][None].expand(3, -1))
+
+
+def test_row_tile_plan_of_the_whole_row_kernels(native):
+    """gemm.hip xf_plan_row_tiles: the plain map by default ((M + 63) / 64 tiles); with XFMR_ROW_TILES_SHORT=1 (an experiment
+    switch read once per process: measured, not kept -- DESIGN.md section 7) the rows left over after whole 64-row tiles
+    per CU, when few (<= 32 per CU), become one short tile per CU: 102 400 rows on 256 CUs = 6 x 256 full tiles + 256 tiles
+    of 16 rows instead of 1600 tiles with a seventh on 64 CUs."""
+    import subprocess
+
+    code = ("import ctypes as C, sys; lib = C.CDLL(sys.argv[1]); lib.xf_ln_row_tiles.restype = C.c_int; "
+            "lib.xf_ln_row_tiles.argtypes = [C.c_int64]; "
+            "print([lib.xf_ln_row_tiles(m) for m in (102400, 25600, 300, 64 * 256 * 3, 64 * 256 * 2 + 1)])")
+    env = {k: v for k, v in os.environ.items() if k != "XFMR_ROW_TILES_SHORT"}
+    plain = subprocess.run([sys.executable, "-c", code, str(native.LIB_PATH)], env=env, capture_output=True, text=True, check=True)
+    assert eval(plain.stdout) == [1600, 400, 5, 768, 513]
+    short = subprocess.run([sys.executable, "-c", code, str(native.LIB_PATH)], env=env | {"XFMR_ROW_TILES_SHORT": "1"},
+                           capture_output=True, text=True, check=True)
+    # 16 rows left per CU -> 256 short tiles; 36 per CU -> plain; < 1 tile per CU -> plain; nothing left -> plain; 1 row left
+    assert eval(short.stdout) == [6 * 256 + 256, 400, 5, 768, 512 + 1]

@@ -175,6 +175,28 @@ struct RegRows<PrecBF16, K> {
       v[s][6] = (__bf16)(b[s].z * z); v[s][7] = (__bf16)(b[s].w * z);
     }
   }
+  // load_safe + the sum of squares of THIS lane's fp32 pieces (before the bf16 rounding): the row is read once for the
+  // operand and for its norm (the lane pair l, l ^ 32 covers the whole row between them)
+  __device__ __forceinline__ float load_safe_sq(const float* row, bool valid) {
+    const int h = xf_lane() >> 5;
+    float4 a[K / 16], b[K / 16];
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      a[s] = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h);
+      b[s] = *reinterpret_cast<const float4*>(row + 16 * s + 8 * h + 4);
+    }
+    const float z = valid ? 1.f : 0.f;
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      sq += a[s].x * a[s].x + a[s].y * a[s].y + a[s].z * a[s].z + a[s].w * a[s].w;
+      sq += b[s].x * b[s].x + b[s].y * b[s].y + b[s].z * b[s].z + b[s].w * b[s].w;
+      v[s][0] = (__bf16)(a[s].x * z); v[s][1] = (__bf16)(a[s].y * z); v[s][2] = (__bf16)(a[s].z * z);
+      v[s][3] = (__bf16)(a[s].w * z); v[s][4] = (__bf16)(b[s].x * z); v[s][5] = (__bf16)(b[s].y * z);
+      v[s][6] = (__bf16)(b[s].z * z); v[s][7] = (__bf16)(b[s].w * z);
+    }
+    return sq * z;
+  }
   __device__ __forceinline__ void load(const __bf16* row, bool valid) {  // bf16 storage: no conversion
     const int h = xf_lane() >> 5;
 #pragma unroll

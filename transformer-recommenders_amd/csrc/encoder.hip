@@ -161,7 +161,7 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   o += up256(sc);
   {
     size_t rec = xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float);
-    const size_t rec_fused = ((T + 63) / 64) * 3 * H;  // one record per 64-row tile of the fused dX GEMM
+    const size_t rec_fused = (size_t)xf_ln_row_tiles((int64_t)T) * 3 * H;  // one record per row tile of the fused dX GEMM
     a.emb_ln = take(rec_fused > rec ? rec_fused : rec);
   }
   for (int i = 0; i < c->layers; ++i) {
@@ -175,7 +175,7 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
     // LayerNorm partial records [blocks][3][H]: from the LayerNorm backward kernel, or one per 64-row tile from
     // the dX GEMM that applies the LayerNorm backward in its epilogue
     size_t lnrec = xfmr_layernorm_bwd_workspace((int64_t)T, (int32_t)H) / sizeof(float);
-    const size_t lnrec_fused = ((T + 63) / 64) * 3 * H;
+    const size_t lnrec_fused = (size_t)xf_ln_row_tiles((int64_t)T) * 3 * H;
     if (lnrec_fused > lnrec) lnrec = lnrec_fused;
     r.ln2 = take(lnrec);
     r.ln1 = take(lnrec);

@@ -78,6 +78,9 @@ struct GemmArgs {
   int64_t M; int N; int K;
   int k_chunk;            // split-K: split z handles [z*k_chunk, min(K,(z+1)*k_chunk)); 0 = whole K
   int nt_n, nt_m, nt_z;   // tiles along N, M and the number of K splits (the launch is one-dimensional: see tile_of)
+  // Two-region row map of the whole-row (N == 128) kernels: M-tiles [0, nt_full) are BM rows tall, tiles [nt_full, nt_m)
+  // `short_rows` (< BM) -- see xf_plan_row_tiles. nt_full == 0: every tile BM rows (the plain map).
+  int nt_full, short_rows;
   const float* bias;      // [N] or null
   const float* R;         // residual / residual-grad [M,ldc] or null
   const void* P;          // pre-activation for gelu' [M,ldc]
@@ -304,6 +307,46 @@ __device__ __forceinline__ TileIdx tile_of(const int nt_n, const int nt_m, const
     t.valid = t.m < nt_m;
   }
   return t;
+}
+
+// Rows of M-tile m under the two-region map: first row, and the tile's row limit written into g.M (every row test of the
+// kernels and their epilogues is `m < g.M` on the workgroup's own copy of the arguments, so a short tile is a tile whose
+// rows past the limit are masked exactly like the rows past the end of the matrix).
+__device__ __forceinline__ int64_t xf_tile_rows(GemmArgs& g, const int m, const int BM) {
+  if (g.nt_full <= 0 || m < g.nt_full) return (int64_t)m * BM;
+  const int64_t m0 = (int64_t)g.nt_full * BM + (int64_t)(m - g.nt_full) * g.short_rows;
+  g.M = min(g.M, m0 + g.short_rows);
+  return m0;
+}
+// The per-CU tile count of a whole-row kernel: M / BM tiles over the chip's CUs is rarely whole (1600 tiles over 256 CUs =
+// 6.25: 64 CUs run a seventh tile while 192 idle -- 101 -> 119 us on the fused FFN forward). When the
+// rows left over after `per_cu` full tiles per CU are few (<= 32 per CU), they are dealt as ONE short tile per CU instead
+// of a few full ones on a few CUs: the short tiles are dispatched last and land where slots free up. Rows are
+// independent in these kernels (GEMM rows, LayerNorm rows): outputs are bit-identical under any row map.
+static int xf_num_cus() {
+  static const int n = [] {
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return cu > 0 ? cu : 256;
+  }();
+  return n;
+}
+static void xf_plan_row_tiles(GemmArgs& g, int BM) {
+  g.nt_full = 0; g.short_rows = 0;
+  g.nt_m = (int)((g.M + BM - 1) / BM);
+  // MEASURED AND NOT KEPT AS THE DEFAULT (round 3, batch 512, alternating runs on one box): 3.297 / 3.312 / 3.290 ms per step
+  // with the short tiles against 3.278 / 3.288 / 3.279 with the plain map; per kernel 103.3 vs 101.0 us (fused FFN forward),
+  // 126.4 vs 127.0 (backward), 62.6 vs 61.1, 43.6 vs 43.5 (the two LayerNorm-fused GEMMs). A lone short tile costs about what
+  // a lone full tile costs -- its time is the latency chain of staging, K loop and epilogue, not its rows -- so dealing the
+  // tail over all CUs moves it around without shortening it. XFMR_ROW_TILES_SHORT=1 turns the map on (experiments).
+  static const bool on = [] { const char* e = getenv("XFMR_ROW_TILES_SHORT"); return e && *e && *e != '0'; }();
+  const int64_t cus = xf_num_cus();
+  const int64_t per_cu = g.M / (BM * cus), rem = g.M - per_cu * BM * cus;
+  if (!on || per_cu < 1 || rem <= 0 || rem > 32 * cus) return;
+  const int64_t each = (((rem + cus - 1) / cus) + 15) / 16 * 16;  // rows per short tile: a multiple of 16
+  g.nt_full = (int)(per_cu * cus);
+  g.short_rows = (int)each;
+  g.nt_m = g.nt_full + (int)((rem + each - 1) / each);
 }
 
 // Epilogue of a 64 x 128 tile that spans whole output rows (N == 128), computed by 2 x 2 waves (wave = 32 rows x 64
@@ -565,7 +608,7 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   const TileIdx tix = tile_of(g.nt_n, g.nt_m, g.nt_z);
   if (!tix.valid) return;  // (whole workgroup: the grid is padded to a multiple of 8 M-tiles / K splits)
-  const int64_t m0 = (int64_t)tix.m * BM;
+  const int64_t m0 = (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? xf_tile_rows(g, tix.m, BM) : (int64_t)tix.m * BM;
   const int n0 = tix.n * BN;
   int kbeg = 0, kend = g.K;
   if (g.k_chunk > 0) {
@@ -867,7 +910,7 @@ __global__ __launch_bounds__(256, CH == 128 ? XF_FFN_MIN_WAVES : 3) void ffn_fwd
   const int wr = wid >> 1, wc = wid & 1;
   const TileIdx tix = tile_of(1, f.e.nt_m, 1);
   if (!tix.valid) return;
-  const int64_t m0 = (int64_t)tix.m * BM;
+  const int64_t m0 = xf_tile_rows(f.e, tix.m, BM);
   const int64_t M = f.e.M;
   const int I = f.I, nchunk = I / CH;
 #ifdef XF_FFN_STAMP
@@ -1024,7 +1067,7 @@ __global__ __launch_bounds__(256, 3) void ffn_bwd_dx_fused_kernel(const FfnBwdAr
   const int wr = wid >> 1, wc = wid & 1;
   const TileIdx tix = tile_of(1, f.e.nt_m, 1);
   if (!tix.valid) return;
-  const int64_t m0 = (int64_t)tix.m * BM;
+  const int64_t m0 = xf_tile_rows(f.e, tix.m, BM);
   const int64_t M = f.e.M;
   const int I = f.I, nchunk = I / CH;
 
@@ -1297,6 +1340,7 @@ int launch_gemm_bk(const GemmArgs& g, int splits, hipStream_t st) {
   GemmArgs ga = g;
   ga.nt_n = (int)((g.N + bn - 1) / bn);
   ga.nt_m = (int)((g.M + bm - 1) / bm);
+  if (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) xf_plan_row_tiles(ga, bm);  // (whole-row tiles: bm = 64, one N-tile)
   ga.nt_z = splits;
   // one-dimensional launch, padded so that every XCD gets whole groups (see tile_of)
   const int64_t groups = splits > 1 ? (splits + 7) / 8 : (ga.nt_m + 7) / 8;
@@ -1366,6 +1410,14 @@ extern "C" {
 // internal (norm.hip): dst[c] = sum over all rows
 int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st) {
   return launch_rowsum(dst, src, rows, cols, rows, st);
+}
+
+// M-tiles (= LayerNorm partial records) of the whole-row kernels for M rows: the two-region row map's count
+int xf_ln_row_tiles(int64_t M) {
+  GemmArgs g{};
+  g.M = M;
+  xf_plan_row_tiles(g, 64);
+  return g.nt_m;
 }
 
 int xf_linear_fwd_ex(const void* x, const float* w, const float* bias, void* y, int64_t M, int32_t N, int32_t K,
@@ -1443,7 +1495,8 @@ int xf_ffn_fwd_fused_ex(const void* x16, const void* w1_16, const float* b1, con
   g.C = pre; g.ldc = H; g.M = M; g.N = H; g.K = I; g.bias = b2; g.R = residual;
   g.drop = xf_make_dropout(dropout_p, seed, site);
   g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps; g.Y = y; g.Y16 = y16; g.ln_mean = mean; g.ln_rstd = rstd;
-  g.nt_n = 1; g.nt_m = (int)((M + 63) / 64); g.nt_z = 1;
+  g.nt_n = 1; g.nt_z = 1;
+  xf_plan_row_tiles(g, 64);
   const int64_t groups = (g.nt_m + 7) / 8;
   if (groups * 8 > 0x7fffffffll) return XFMR_EUNSUPPORTED;
   // XFMR_FFN_CHUNK=128 (tiling only -- what the kernel stores does not depend on it; read per call so that one test process
@@ -1477,7 +1530,8 @@ int xf_ffn_bwd_dx_fused_ex(const void* dy16, const void* w2_16, const void* u16,
   g.drop2 = xf_make_dropout(0.f, 0, 0);
   g.ln_gamma = ln_gamma; g.lnb_x = ln_x; g.lnb_mean = ln_mean; g.lnb_rstd = ln_rstd; g.D16 = d_lin16;
   g.lnb_partials = partials;
-  g.nt_n = 1; g.nt_m = (int)((M + 63) / 64); g.nt_z = 1;
+  g.nt_n = 1; g.nt_z = 1;
+  xf_plan_row_tiles(g, 64);
   *blocks_out = g.nt_m;
   const int64_t groups = (g.nt_m + 7) / 8;
   if (groups * 8 > 0x7fffffffll) return XFMR_EUNSUPPORTED;
@@ -1525,7 +1579,7 @@ int xf_linear_bwd_dx_lnbwd_ex(const void* dy, const float* w, int64_t M, int32_t
   g.ln_gamma = ln_gamma; g.lnb_x = ln_x; g.lnb_mean = ln_mean; g.lnb_rstd = ln_rstd; g.D16 = d_lin16;
   g.lnb_partials = partials;
   g.drop2 = xf_make_dropout(out_dropout_p, seed, out_site);
-  *blocks_out = (int)((M + 63) / 64);
+  *blocks_out = xf_ln_row_tiles(M);  // (the launch plans the same row map: launch_gemm_bk)
   return dispatch_gemm<false, true, EPI_DX_LNBWD, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, 1, precision, st);
 }
 

@@ -71,6 +71,9 @@ int xf_linear_ln_fwd_ex(const void* x, const float* w, const float* bias, float*
 // output is the gradient of a LayerNorm output applies that LayerNorm's backward in its epilogue. d_lin16 (bf16,
 // optional) = the dropout-scaled copy; partials[*blocks_out][3][128] = d gamma / d beta / d bias partial records.
 // out_dropout_p / out_site: dropout that was applied to the LayerNorm OUTPUT (the embedding LayerNorm).
+// number of 64-row M-tiles (one LayerNorm partial record each) the whole-row kernels run for M rows: >= (M + 63) / 64
+// (short last-round tiles: gemm.hip xf_plan_row_tiles)
+int xf_ln_row_tiles(int64_t M);
 int xf_linear_bwd_dx_lnbwd_ex(const void* dy, const float* w, int64_t M, int32_t N, int32_t K,
                               const float* residual_grad, const float* ln_x, const float* ln_mean, const float* ln_rstd,
                               const float* ln_gamma, float dropout_p, XfSeed seed, uint32_t site, float* dx,

@@ -798,6 +798,11 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   int64_t ns = (1024 + qblocks / 2) / qblocks;  // ~1024 workgroups: two full rounds at 2 workgroups/CU
   if (ns > 16) ns = 16;
   if (ns < 2) ns = 2;  // measured at 800 query blocks (B = 512): 2 splits 95.5k seq/s, 1 split 94.1k
+  // >= 512 query blocks: the gradient pass runs ONE split there (run_loss), so this count is the logging pass's alone. At
+  // three workgroups per CU (768 slots) 800 blocks x 2 splits are 2.08 rounds -- the third round nearly empty; finer
+  // pieces fill it: isolated 456 us (2 splits), 427 (3), 422 (4), 414 (5), 425 (6), 428 (8); 525 with one. In the step the
+  // pass is hidden underneath the backward either way (3.32-3.36 ms for 2 ... 6 splits).
+  if (ns < 4 && qblocks >= 512) ns = 4;
   static const int ns_env = [] { const char* e = getenv("XFMR_LOSS_NSPLIT"); return e ? atoi(e) : 0; }();  // tuning experiments
   if (ns_env > 0) ns = ns_env;
   if (ns > tiles) ns = tiles;

@@ -41,6 +41,11 @@ class LossConfig(pydantic.BaseModel):
 
 
 class _StructuredCandidates:
+    """Stands for the reference's dense ``(Np, C, H)`` candidate tensor (``models.py:408-416``) without holding it. What a
+    caller of the reference's ``compute_embeds`` does with that tensor works here too: ``shape`` / ``size()`` / ``dim()`` /
+    ``dtype`` / ``device``, indexing -- ``cand[i]``, ``cand[a:b]``, ``cand[rows, cols]`` build only the rows asked for --
+    and ``materialize()`` / ``torch.as_tensor(cand.materialize())`` for the whole thing (O(Np * C * H): small inputs)."""
+
     table: torch.Tensor
     table_rnorm: torch.Tensor
 
@@ -54,6 +59,28 @@ class _StructuredCandidates:
     def device(self):
         return self.table.device
 
+    @property
+    def dtype(self):
+        return self.table.dtype
+
+    def __len__(self) -> int:
+        return int(self.shape[0])
+
+    def _rows(self, rows: torch.Tensor) -> torch.Tensor:  # (len(rows), C, H) dense
+        raise NotImplementedError
+
+    def __getitem__(self, idx):
+        first, rest = (idx[0], idx[1:]) if isinstance(idx, tuple) else (idx, ())
+        n = int(self.shape[0])
+        if isinstance(first, int):
+            out = self._rows(torch.as_tensor([first % n], device=self.device))[0]
+        elif first is Ellipsis:
+            return self.materialize()[idx]
+        else:
+            out = self._rows(torch.arange(n, device=self.device)[first])
+            rest = (slice(None),) + tuple(rest)
+        return out[tuple(rest)] if rest else out
+
 
 class SharedNegatives(_StructuredCandidates):
     """``cat([E[pos_items][:, None], E[neg_items][None].expand(Np, -1, -1)], 1)`` without the copy."""
@@ -66,11 +93,14 @@ class SharedNegatives(_StructuredCandidates):
     def shape(self):
         return torch.Size((self.pos_items.numel(), 1 + self.neg_items.numel(), self.table.shape[1]))
 
-    def materialize(self) -> torch.Tensor:
-        """The dense tensor of ``models.py:408-416`` (debug / small inputs only: O(Np*N*H))."""
-        pos = self.table[self.pos_items][:, None, :]
+    def _rows(self, rows):
+        pos = self.table[self.pos_items[rows]][:, None, :]
         neg = self.table[self.neg_items][None, :, :].expand(pos.size(0), -1, -1)
         return torch.cat([pos, neg], dim=1)
+
+    def materialize(self) -> torch.Tensor:
+        """The dense tensor of ``models.py:408-416`` (debug / small inputs only: O(Np*N*H))."""
+        return self._rows(torch.arange(self.pos_items.numel(), device=self.pos_items.device))
 
 
 class CatalogCandidates(_StructuredCandidates):
@@ -82,6 +112,9 @@ class CatalogCandidates(_StructuredCandidates):
     @property
     def shape(self):
         return torch.Size((self.n_query, self.table.shape[0], self.table.shape[1]))
+
+    def _rows(self, rows):
+        return self.table[None].expand(int(rows.numel()), -1, -1)
 
     def materialize(self) -> torch.Tensor:
         return self.table[None].expand(self.n_query, -1, -1)
