@@ -327,7 +327,8 @@ int xfmr_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm
  * Outputs (all device memory):
  *   losses[14]       [0..6] summed loss per head (accumulated in fp64), order XFMR_LOSS_*;
  *                    [7..13] the same divided by (Np + 1e-9): the `loss/<Class>Mean` values of trainer.py:263
- *   stats[16]        see XFMR_STAT_*; fp32
+ *   stats[16]        see XFMR_STAT_*; fp32. With all_heads == 0 only the counts (N_VALID, N_QUERY, NEG_DISTINCT and the
+ *                    two batch densities) are defined; the logits/{pos,neg} statistics belong to the logging pass
  *   d_tok (B*L,H)    dL(train_head)/d tok, rows that are not queries are zero; may be NULL (eval)
  * workspace: xfmr_sampled_loss_workspace(B*L, H, n_rows) bytes. table_bf16: see xfmr_table_prepare (may be NULL).
  * ---------------------------------------------------------------------------------------------- */

@@ -322,6 +322,8 @@ def test_loss_in_two_halves_equals_the_single_call(ops, head, heads):
         ev.record(side)
     torch.cuda.current_stream().wait_event(ev)
     l1, s1, d1 = ops.sampled_loss(tok, mask, pos, neg, table, rn, need_grad=need, workspace=ws, prepared=True, **kw)
-    assert torch.equal(l0, l1) and torch.equal(s0, s1)
+    # (statistics of a train-head-only call are defined for the counts only: a lean gradient epilogue that does not count the
+    #  dot-product negatives -- the cosine heads' -- leaves logits/neg/* as NaN, identically in both forms)
+    assert torch.equal(l0, l1) and torch.allclose(s0, s1, rtol=0, atol=0, equal_nan=True)
     assert (d0 is None and d1 is None) or torch.equal(d0, d1)
 

@@ -20,6 +20,13 @@ constexpr int HEAD_INFONCE_MASKED = XFMR_NUM_LOSSES;
 // run: the row maximum of the counted logits is in its records (R_SMAX), so the running maximum is pinned at
 // max(scale * pos, scale * smax) and the lean epilogue applies -- no online rescaling of the dQ accumulators.
 constexpr int HEAD_INFONCE_PINNED = XFMR_NUM_LOSSES + 1;
+// PairwiseLogisticLoss (BPR, BASELINE config 3) with false-negative masking over in-batch negatives, stripped like the
+// InfoNCE case above (loss_epilogue_bpr_masked): the general epilogue spends ~24 issue slots per logit on it (it also
+// feeds the hinge sum, resolves ties by substitution, tests validity), this one ~16.
+constexpr int HEAD_BPR_MASKED = XFMR_NUM_LOSSES + 2;
+// AlignmentContrastiveLoss (CCL, BASELINE config 5) / ContrastiveLoss with masking over in-batch negatives: the cosine
+// heads in the query-norm-free form of the masked logging epilogue (loss_epilogue_cos_masked), ~9 issue slots per logit.
+constexpr int HEAD_CCL_MASKED = XFMR_NUM_LOSSES + 3, HEAD_CONTR_MASKED = XFMR_NUM_LOSSES + 4;
 
 struct LossArgs {
   const float* tok; const float* table; const float* rnorm; int64_t n_rows;
@@ -211,6 +218,66 @@ __device__ __forceinline__ void loss_epilogue_infonce_masked(f32x16& s, float& l
   }
 }
 
+// PairwiseLogisticLoss, masking on, shared negatives (HEAD_BPR_MASKED): per counted logit d = s - (1 - margin) pos,
+// term softplus(d) = ln 2 log2(1 + 2^y), y = d log2 e, weight sigmoid(d) = 2^y / (1 + 2^y) -- one exponential, one
+// logarithm, one reciprocal; `logi2` holds the log2 sum (ln 2 applied once per row by the caller), a tie by item id is not
+// counted (no logit substitution: with masking on the substituted value is never < pos), past-the-end columns are
+// multiplicity-0 duplicates (no validity test: the staging loop of loss_dma.inc).
+__device__ __forceinline__ void loss_epilogue_bpr_masked(f32x16& s, float& logi2, float& cnt, float& sw, float pos_dot,
+                                                         float chinge, int pos_item, const int* nid_sb, const float* mu_sb,
+                                                         int hh) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[8 * g + 4 * hh]);
+    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+    const float4 m4 = *reinterpret_cast<const float4*>(&mu_sb[8 * g + 4 * hh]);
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * g + u;
+      const bool counted = (s[r] < pos_dot) & (nn[u] != pos_item);
+      const float md = counted ? mu[u] : 0.f;
+      cnt += md;
+      const float e = xf_exp2(fminf((s[r] - chinge) * kLog2e, 100.f));
+      const float one_e = 1.f + e;
+      logi2 = fmaf(xf_log2(one_e), md, logi2);
+      const float w = md * (e * xf_rcp(one_e));
+      sw += w;
+      s[r] = w;
+    }
+  }
+}
+
+// Cosine heads, masking on, shared negatives (HEAD_CCL_MASKED / HEAD_CONTR_MASKED). With sc = s / |e| (rc = 1 / |e|):
+// counted <=> cos < cos_pos <=> sc < pos / |e_pos| (kpos_c); the hinge max(cos - 1 + margin, 0) = (1 / |q|) max(sc - kappa_c, 0)
+// with kappa_c = (1 - margin) |q| -- `contr_q` holds the sum WITHOUT the 1 / |q| (applied once per row by the caller); the
+// gradient weight of a column inside the margin is mult / |e| (dL / d q_hat = sum w e; the Jacobian of q_hat follows per
+// row). A tie by item id is not counted; past-the-end columns are multiplicity-0 duplicates.
+__device__ __forceinline__ void loss_epilogue_cos_masked(f32x16& s, float& contr_q, float& cnt_c, float kpos_c,
+                                                         float kappa_c, int pos_item, const int* nid_sb,
+                                                         const float* rc_sb, const float* mu_sb, int hh) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl0 = 8 * g + 4 * hh;
+    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[jl0]);
+    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+    const float4 c4 = *reinterpret_cast<const float4*>(&rc_sb[jl0]);
+    const float rc[4] = {c4.x, c4.y, c4.z, c4.w};
+    const float4 m4 = *reinterpret_cast<const float4*>(&mu_sb[jl0]);
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * g + u;
+      const float sc = s[r] * rc[u];
+      const float mc = ((sc < kpos_c) & (nn[u] != pos_item)) ? mu[u] : 0.f;
+      cnt_c += mc;
+      const float dd = sc - kappa_c;
+      contr_q = fmaf(fmaxf(dd, 0.f), mc, contr_q);
+      s[r] = dd > 0.f ? mc * rc[u] : 0.f;
+    }
+  }
+}
+
 // The unmasked counterpart (HEAD_INFONCE_PINNED): every valid column counts (the positive's own item only in the
 // in-batch form, with the positive's logit, as losses.py has it); m >= every counted logit by construction.
 template <bool CHECK_VALID>
@@ -256,12 +323,16 @@ __device__ __forceinline__ void loss_epilogue_infonce_pinned(f32x16& s, float& l
 //     [2^-64, 2^64] (|logit of the positive| > 44) make their wave take the two-exponential form.
 // HEAD code -3: without the InfoNCE log-sum-exp (its value comes from the gradient pass), -4: with it.
 constexpr int HEAD_LOG_MASKED = -3, HEAD_LOG_MASKED_LSE = -4;
+// -5: the same fast epilogue WITHOUT false-negative masking over the full catalogue (BASELINE config 4: every table row a
+// column, mask_false_negatives = False, the positive's own column the only one excluded), without the log-sum-exp (the
+// pinned gradient pass of the same call produces InfoNCE's value): MASK = false drops the two `< positive` compares.
+constexpr int HEAD_LOG_UNMASKED_CATALOG = -5;
 struct LogConst {
   float pos_dot, sc2, m, chinge, clog2e /* chinge * log2e */, kpos_c /* pos / |e_pos| */, kappa_c /* (1 - margin) |q| */;
   int pos_item;
   float kexp /* 2^-clog2e */, k2m /* 2^-m */;  // SHARE
 };
-template <bool CHECK_VALID, bool LSE, bool SHARE>
+template <bool CHECK_VALID, bool LSE, bool SHARE, bool MASK = true>
 __device__ __forceinline__ void loss_epilogue_logging_masked(const f32x16& s, RowState& st, const LogConst& k,
                                                              const int* nid_sb, const float* rc_sb, const float* mu_sb,
                                                              int hh) {
@@ -280,7 +351,7 @@ __device__ __forceinline__ void loss_epilogue_logging_masked(const f32x16& s, Ro
       const float sv = s[4 * g + u];
       bool other = nn[u] != k.pos_item;              // not the positive's own item (past-the-end columns carry -1)
       if (CHECK_VALID) other &= nn[u] >= 0;
-      const bool cd = (sv < k.pos_dot) & other;
+      const bool cd = MASK ? ((sv < k.pos_dot) & other) : other;
       const float md = cd ? mu[u] : 0.f;
       st.cnt_d += md;
       const float y = sv * kLog2e;
@@ -295,7 +366,7 @@ __device__ __forceinline__ void loss_epilogue_logging_masked(const f32x16& s, Ro
       if (SHARE) st.logi = fmaf(xf_log2(1.f + fminf(e * k.kexp, 0x1p100f)), md, st.logi);
       else st.logi = fmaf(xf_log2(1.f + xf_exp2(fminf(y - k.clog2e, 100.f))), md, st.logi);
       const float sc = sv * rc[u];
-      const float mc = ((sc < k.kpos_c) & other) ? mu[u] : 0.f;
+      const float mc = (MASK ? ((sc < k.kpos_c) & other) : other) ? mu[u] : 0.f;
       st.cnt_c += mc;
       st.contr = fmaf(fmaxf(sc - k.kappa_c, 0.f), mc, st.contr);
       const float t1 = sv * md;

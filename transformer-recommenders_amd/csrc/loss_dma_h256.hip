@@ -26,12 +26,20 @@ int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, 
     case -2:
       if (a.mask_fn && a.mode == XFMR_NEG_SHARED && logm256())
         hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_LOG_MASKED>), grid, block, 0, st, a, tbf);
+      else if (!a.mask_fn && a.mode == XFMR_NEG_CATALOG && logm256())  // full-catalogue softmax (config 4)
+        hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_LOG_UNMASKED_CATALOG>), grid, block, 0, st, a, tbf);
       else hipLaunchKernelGGL((loss_main_dma_kernel<256, -2>), grid, block, 0, st, a, tbf);
       break;
-    case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:
-      hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
-    case XFMR_LOSS_CONTRASTIVE:
-      hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
+    case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:  // masking on + in-batch negatives: the lean cosine epilogue
+      if (a.mask_fn && a.mode == XFMR_NEG_SHARED)
+        hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_CCL_MASKED>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>), grid, block, 0, st, a, tbf);
+      break;
+    case XFMR_LOSS_CONTRASTIVE:  // masking on + in-batch negatives: the lean cosine epilogue
+      if (a.mask_fn && a.mode == XFMR_NEG_SHARED)
+        hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_CONTR_MASKED>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_CONTRASTIVE>), grid, block, 0, st, a, tbf);
+      break;
     case XFMR_LOSS_INFONCE:
       if (a.mask_fn) hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_INFONCE_MASKED>), grid, block, 0, st, a, tbf);
       else if (a.pin_part) hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_INFONCE_PINNED>), grid, block, 0, st, a, tbf);
@@ -41,8 +49,11 @@ int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, 
       hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_NCE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_PAIRWISE_HINGE:
       hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_PAIRWISE_HINGE>), grid, block, 0, st, a, tbf); break;
-    case XFMR_LOSS_PAIRWISE_LOGISTIC:
-      hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_PAIRWISE_LOGISTIC>), grid, block, 0, st, a, tbf); break;
+    case XFMR_LOSS_PAIRWISE_LOGISTIC:  // BPR: masking on + in-batch negatives (the reference's training form) take the lean epilogue
+      if (a.mask_fn && a.mode == XFMR_NEG_SHARED && !a.tau)
+        hipLaunchKernelGGL((loss_main_dma_kernel<256, HEAD_BPR_MASKED>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<256, XFMR_LOSS_PAIRWISE_LOGISTIC>), grid, block, 0, st, a, tbf);
+      break;
     default: return XFMR_EINVAL;
   }
   XF_LAUNCH_CHECK();

@@ -12,10 +12,16 @@ int xf_launch_loss_dma_384(const LossArgs& a, const void* table_bf16, int head, 
     //  SLOWER than the general epilogue -- 2.21 against 1.75 ms at BASELINE config 5)
     case -1: hipLaunchKernelGGL((loss_main_dma_kernel<384, -1>), grid, block, 0, st, a, tbf); break;
     case -2: hipLaunchKernelGGL((loss_main_dma_kernel<384, -2>), grid, block, 0, st, a, tbf); break;
-    case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:
-      hipLaunchKernelGGL((loss_main_dma_kernel<384, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
-    case XFMR_LOSS_CONTRASTIVE:
-      hipLaunchKernelGGL((loss_main_dma_kernel<384, XFMR_LOSS_CONTRASTIVE>), grid, block, 0, st, a, tbf); break;
+    case XFMR_LOSS_ALIGNMENT_CONTRASTIVE:  // masking on + in-batch negatives: the lean cosine epilogue
+      if (a.mask_fn && a.mode == XFMR_NEG_SHARED)
+        hipLaunchKernelGGL((loss_main_dma_kernel<384, HEAD_CCL_MASKED>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<384, XFMR_LOSS_ALIGNMENT_CONTRASTIVE>), grid, block, 0, st, a, tbf);
+      break;
+    case XFMR_LOSS_CONTRASTIVE:  // masking on + in-batch negatives: the lean cosine epilogue
+      if (a.mask_fn && a.mode == XFMR_NEG_SHARED)
+        hipLaunchKernelGGL((loss_main_dma_kernel<384, HEAD_CONTR_MASKED>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<384, XFMR_LOSS_CONTRASTIVE>), grid, block, 0, st, a, tbf);
+      break;
     case XFMR_LOSS_INFONCE:
       if (a.mask_fn) hipLaunchKernelGGL((loss_main_dma_kernel<384, HEAD_INFONCE_MASKED>), grid, block, 0, st, a, tbf);
       else if (a.pin_part) hipLaunchKernelGGL((loss_main_dma_kernel<384, HEAD_INFONCE_PINNED>), grid, block, 0, st, a, tbf);
@@ -25,8 +31,11 @@ int xf_launch_loss_dma_384(const LossArgs& a, const void* table_bf16, int head, 
       hipLaunchKernelGGL((loss_main_dma_kernel<384, XFMR_LOSS_NCE>), grid, block, 0, st, a, tbf); break;
     case XFMR_LOSS_PAIRWISE_HINGE:
       hipLaunchKernelGGL((loss_main_dma_kernel<384, XFMR_LOSS_PAIRWISE_HINGE>), grid, block, 0, st, a, tbf); break;
-    case XFMR_LOSS_PAIRWISE_LOGISTIC:
-      hipLaunchKernelGGL((loss_main_dma_kernel<384, XFMR_LOSS_PAIRWISE_LOGISTIC>), grid, block, 0, st, a, tbf); break;
+    case XFMR_LOSS_PAIRWISE_LOGISTIC:  // BPR: masking on + in-batch negatives (the reference's training form) take the lean epilogue
+      if (a.mask_fn && a.mode == XFMR_NEG_SHARED && !a.tau)
+        hipLaunchKernelGGL((loss_main_dma_kernel<384, HEAD_BPR_MASKED>), grid, block, 0, st, a, tbf);
+      else hipLaunchKernelGGL((loss_main_dma_kernel<384, XFMR_LOSS_PAIRWISE_LOGISTIC>), grid, block, 0, st, a, tbf);
+      break;
     default: return XFMR_EINVAL;
   }
   XF_LAUNCH_CHECK();
