@@ -379,6 +379,108 @@ __device__ __forceinline__ void loss_epilogue_logging_masked(const f32x16& s, Ro
     __builtin_amdgcn_sched_barrier(0);  // (as in loss_epilogue_t: one run of four elements at a time)
   }
 }
+// The same epilogue on PAIRS of neighbouring logits (round 3). What the probe says of gfx950's vector pipe
+// (scripts/probe/valu_rates.hip, profiles/r03_valu_rates.log): a plain fp32 instruction holds a SIMD 4 cycles per wave64 --
+// not the guide's 2 --, a transcendental 8, and v_pk_{mul,add,fma}_f32 4.3-5.0 for TWO results. 16 of this epilogue's 30
+// instructions per logit are mul / add / fma: written on float2 values they pack (-8 per logit); the sums become two
+// partial sums each (even / odd columns), folded once per row. Scalars enter the packed operations as the LOW half of
+// a broadcast (op_sel_hi), never the form scripts/check_isa.py rejects. In the SHARE form the argument of the one
+// exponential is capped at min(100, clog2e + 100) instead of 100: then e * kexp <= 2^100 without its own clamp, and with
+// masking on no counted logit can reach the cap (it is below the positive's, |m| <= 64: log_share).
+#ifndef XFL_LOG_PK
+#define XFL_LOG_PK 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct LogAcc {
+  f32x2 cnt_d, l, nce, hinge, logi, cnt_c, contr, ssum, ssq;
+};
+__device__ __forceinline__ LogAcc log_acc_zero() {
+  const f32x2 z = {0.f, 0.f};
+  return LogAcc{z, z, z, z, z, z, z, z, z};
+}
+// (once per row. The odd half goes through an opaque move: left to itself the vectoriser writes x + y as one packed add
+//  of the pair with ITSELF, halves swapped by op_sel -- the form check_isa.py rejects)
+__device__ __forceinline__ float log_acc_sum2(f32x2 v) {
+  float hi = v.y;
+  asm volatile("" : "+v"(hi));
+  return v.x + hi;
+}
+__device__ __forceinline__ void log_acc_fold(const LogAcc& a, RowState& st) {
+  st.cnt_d += log_acc_sum2(a.cnt_d); st.l += log_acc_sum2(a.l); st.nce += log_acc_sum2(a.nce);
+  st.hinge += log_acc_sum2(a.hinge); st.logi += log_acc_sum2(a.logi); st.cnt_c += log_acc_sum2(a.cnt_c);
+  st.contr += log_acc_sum2(a.contr); st.ssum += log_acc_sum2(a.ssum); st.ssq += log_acc_sum2(a.ssq);
+}
+template <bool LSE, bool SHARE, bool MASK = true>
+__device__ __forceinline__ void loss_epilogue_logging_masked_pk(const f32x16& s, RowState& st, LogAcc& la,
+                                                                const LogConst& k, float ycap, const int* nid_sb,
+                                                                const float* rc_sb, const float* mu_sb, int hh) {
+  const float qnan = __builtin_nanf("");
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl0 = 8 * g + 4 * hh;
+    const int4 n4 = *reinterpret_cast<const int4*>(&nid_sb[jl0]);
+    const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+    const float4 c4 = *reinterpret_cast<const float4*>(&rc_sb[jl0]);
+    const float rc[4] = {c4.x, c4.y, c4.z, c4.w};
+    const float4 m4 = *reinterpret_cast<const float4*>(&mu_sb[jl0]);
+    const float mu[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int u0 = 2 * p, u1 = 2 * p + 1;
+      const f32x2 sv = {s[4 * g + u0], s[4 * g + u1]};
+      const bool o0 = nn[u0] != k.pos_item, o1 = nn[u1] != k.pos_item;  // not the positive's own item
+      const bool cd0 = MASK ? ((sv.x < k.pos_dot) & o0) : o0, cd1 = MASK ? ((sv.y < k.pos_dot) & o1) : o1;
+      const f32x2 md = {cd0 ? mu[u0] : 0.f, cd1 ? mu[u1] : 0.f};
+      la.cnt_d += md;
+      const f32x2 y = sv * kLog2e;
+      const float cap = (SHARE && MASK) ? ycap : 100.f;
+      const f32x2 e = {xf_exp2(fminf(y.x, cap)), xf_exp2(fminf(y.y, cap))};
+      if (LSE) {
+        if (SHARE) {  // (temperature 1: sc2 == log2 e)
+          const f32x2 t = e * k.k2m;
+          const f32x2 tc = {fminf(t.x, 1.f), fminf(t.y, 1.f)};
+          la.l = tc * md + la.l;
+        } else {
+          const f32x2 z = sv * k.sc2 - k.m;
+          const f32x2 t = {xf_exp2(fminf(z.x, 0.f)), xf_exp2(fminf(z.y, 0.f))};
+          la.l = t * md + la.l;
+        }
+      }
+      const f32x2 e1 = e + 1.f;
+      const f32x2 ln = {xf_log2(e1.x), xf_log2(e1.y)};
+      la.nce = ln * md + la.nce;
+      const f32x2 d = sv - k.chinge;
+      const f32x2 dr = {fmaxf(d.x, 0.f), fmaxf(d.y, 0.f)};
+      la.hinge = dr * md + la.hinge;
+      f32x2 w;
+      if (SHARE) {
+        const f32x2 t = e * k.kexp;
+        if (MASK) w = t + 1.f;
+        else w = f32x2{fminf(t.x, 0x1p100f), fminf(t.y, 0x1p100f)} + 1.f;
+      } else {
+        const f32x2 z = y - k.clog2e;
+        w = f32x2{xf_exp2(fminf(z.x, 100.f)), xf_exp2(fminf(z.y, 100.f))} + 1.f;
+      }
+      const f32x2 lw = {xf_log2(w.x), xf_log2(w.y)};
+      la.logi = lw * md + la.logi;
+      const f32x2 rc2 = {rc[u0], rc[u1]};
+      const f32x2 sc = sv * rc2;
+      const bool cc0 = MASK ? ((sc.x < k.kpos_c) & o0) : o0, cc1 = MASK ? ((sc.y < k.kpos_c) & o1) : o1;
+      const f32x2 mc = {cc0 ? mu[u0] : 0.f, cc1 ? mu[u1] : 0.f};
+      la.cnt_c += mc;
+      const f32x2 dc = sc - k.kappa_c;
+      const f32x2 dcr = {fmaxf(dc.x, 0.f), fmaxf(dc.y, 0.f)};
+      la.contr = dcr * mc + la.contr;
+      const f32x2 t1 = sv * md;
+      la.ssum += t1;
+      la.ssq = t1 * sv + la.ssq;
+      const float s0 = cd0 ? sv.x : qnan, s1 = cd1 ? sv.y : qnan;
+      st.smin = fminf(st.smin, fminf(s0, s1));
+      st.smax = fmaxf(st.smax, fmaxf(s0, s1));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (as in loss_epilogue_t: one run of four elements at a time)
+  }
+}
 // per row, once: back to natural-log sums and the 1 / |q| of the contrastive term
 __device__ __forceinline__ void loss_logging_masked_finish(RowState& st, float rq) {
   st.nce *= kLn2;
