@@ -79,7 +79,9 @@ enum {
                                     step cost the host more than the overlap gives the GPU. In a captured hipGraph
                                     (xfmr_rec_amd.trainer.GraphedStep) those calls cost nothing at replay, and a small
                                     step's weight-gradient GEMMs run beside its latency-bound dX chain.              */
-  XFMR_ENC_FLAGS_ALL = 63u
+  XFMR_ENC_DW_UNPAIRED = 64u,    /* every weight-gradient GEMM a launch of its own. Without it the in-line form (no side
+                                    stream) launches them in pairs -- FFN2 + FFN1, out-proj + QKV: identical slabs.      */
+  XFMR_ENC_FLAGS_ALL = 127u
 };
 
 /* Loss heads, in the order of the reference's LOSS_CLASSES (xfmr_rec/losses.py:546-554). */

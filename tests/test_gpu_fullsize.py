@@ -303,6 +303,38 @@ def test_weight_gradient_gemms_on_the_side_stream_give_the_same_bits(ops, B, nL)
     ctx.close()
 
 
+@pytest.mark.parametrize("B,L,H,A,I", [(32, 200, 128, 4, 512), (8, 50, 64, 2, 256), (16, 64, 256, 8, 1024)])
+def test_paired_weight_gradient_launches_give_the_same_bits(ops, B, L, H, A, I):
+    """In line (no side stream) the backward launches the weight-gradient GEMMs of a layer in PAIRS -- FFN2 + FFN1,
+    out-proj + QKV: one gemm_pair_kernel launch each -- unless XFMR_ENC_DW_UNPAIRED asks for one launch per GEMM. Same tiles,
+    same splits, same slabs: every gradient equal bit for bit, at the reference's default batch (32 x 200) and at widths
+    other than 128."""
+    from xfmr_rec_amd import _native as N
+
+    V, nL = 500, 2
+    g = torch.Generator().manual_seed(31)
+    table = _unit_table(V, H, 77).to(DEV)
+    kw = dict(batch=B, seq_len=L, hidden=H, heads=A, inter=I, layers=nL, max_pos=L, precision="bf16",
+              hidden_dropout=0.1, attn_dropout=0.1, seed=5)
+    cfg = ops.make_encoder_cfg(**kw)
+    cfg_unpaired = ops.make_encoder_cfg(**kw, flags=N.ENC_DW_UNPAIRED)
+    n_params = N.load().xfmr_param_count(__import__("ctypes").byref(cfg))
+    flat = (0.05 * torch.randn(n_params, generator=g)).to(DEV)
+    idx = torch.randint(1, V + 1, (B, L), generator=g)
+    idx[:, -5:] = 0
+    idx = idx.to(DEV)
+    d_out = torch.randn(B, L, H, generator=g).to(DEV)
+
+    def run(c):
+        tok, key_mask, acts = ops.encoder_fwd(c, flat, idx, table)
+        return ops.encoder_bwd(c, flat, d_out.clone(), key_mask, acts)
+
+    one_each = run(cfg_unpaired)
+    assert torch.isfinite(one_each).all() and float(one_each.abs().max()) > 0
+    for _ in range(3):
+        assert torch.equal(run(cfg), one_each)
+
+
 @pytest.mark.parametrize("head,heads", [("InfoNCELoss", True), ("PairwiseLogisticLoss", 2), ("AlignmentContrastiveLoss", False)])
 def test_loss_in_two_halves_equals_the_single_call(ops, head, heads):
     """xfmr_sampled_loss_prepare (query compaction, multiplicities, distinct negatives: needs the key mask and the index

@@ -448,6 +448,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     side_used = true;
     return side;
   };
+  const bool pair_dw = !(cfg->flags & XFMR_ENC_DW_UNPAIRED);
   bool ln2_done = false;  // layer i's LN2 backward already ran inside layer i+1's QKV dX GEMM
   bool emb_ln_done = false;  // ... and the embedding LayerNorm's inside layer 0's
   // (a lambda so that a failing launch still reaches the join below: the side stream's GEMMs read the caller's buffers)
@@ -479,9 +480,19 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       seg(r.ln2 + 2 * H, grads + p.b2, blocks, H, 3 * H);
     }
     const void* dlin = lin_copy ? dLinF : (const void*)a.dA;
-    XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, dw_stream()));
-    seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
     const bool fuse_ffn_bwd = fuse_ffn && fuse_lnb && !no_ffn_bwd;
+    // The weight-gradient GEMMs go out in pairs whose operands are ready together -- FFN2 + FFN1 once dI exists, out-proj +
+    // QKV once dQKV does -- one launch each (xf_linear_bwd_dw_pair; same slabs bit for bit). In line (small batches) that
+    // halves 16 launches of ~8 us; on the side stream the FFN2 GEMM would lose its head start underneath the FFN dX
+    // kernel, so the pairs are for the in-line form only (and need dLinF intact after the FFN dX step: not with the
+    // fused FFN backward writing dLinO over it).
+    const bool pair_ffn = pair_dw && !dw_side && !(fuse_ffn_bwd && dLinF == dLinO);
+    const bool pair_att = pair_dw && !dw_side;
+    int splits2 = 0;
+    if (!pair_ffn) {
+      XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, dw_stream()));
+      seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
+    }
     if (fuse_ffn_bwd) {  // FFN2 dX * gelu'(u) -> dI -> FFN1 dX (+= d(pre2)) -> LayerNorm 1 backward in one kernel
       XF_TRY(xf_ffn_bwd_dx_fused_ex(dlin, W(p.w2), l.f1, W(p.w1), dI, T, H, I, a.dA, l.pre1, l.mean1, l.rstd1,
                                     params + p.ln1g, cfg->hidden_dropout, sd, site_out(i), dX, dLinO, r.ln1,
@@ -491,7 +502,14 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), dI, T, H, I, nullptr, l.f1, prec,
                                  sA | sC | sP | sB | (fuse_ffn ? 0 : XF_AUX_GELU_GRAD), st));
     }
-    XF_TRY(xf_linear_bwd_dw_deferred(dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, dw_stream()));  // + b1 partial rows
+    if (pair_ffn) {
+      XF_TRY(xf_linear_bwd_dw_pair(dlin, l.g, H, I, r.w2, nullptr, &splits2, dI,
+                                   mix ? (const void*)l.x1b : (const void*)l.x1, I, H, r.w1, r.b1, &splits, T, prec, sAB,
+                                   dw_stream()));
+      seg(r.w2, grads + p.w2, splits2, (int64_t)H * I, (int64_t)H * I);
+    } else {
+      XF_TRY(xf_linear_bwd_dw_deferred(dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, dw_stream()));  // + b1 partial rows
+    }
     seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
     seg(r.b1, grads + p.b1, splits, I, I);
     if (fuse_ffn_bwd) {  // (done above)
@@ -510,12 +528,20 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     seg(r.ln1 + H, grads + p.ln1b, blocks, H, 3 * H);
     seg(r.ln1 + 2 * H, grads + p.bo, blocks, H, 3 * H);
     dlin = lin_copy ? dLinO : (const void*)dX;
-    XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.ctx, T, H, H, prec, sAB, r.wo, nullptr, &splits, dw_stream()));
-    seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
+    if (!pair_att) {
+      XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.ctx, T, H, H, prec, sAB, r.wo, nullptr, &splits, dw_stream()));
+      seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
+    }
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
     XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, dQKV, B, L, A, H, cfg->attn_dropout, sd,
                           site_attn(i), prec, mix, causal, st));
-    XF_TRY(xf_linear_bwd_dw_deferred(dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, dw_stream()));
+    if (pair_att) {
+      XF_TRY(xf_linear_bwd_dw_pair(dlin, l.ctx, H, H, r.wo, nullptr, &splits2, dQKV, x_in_g, 3 * H, H, r.wqkv, r.bqkv,
+                                   &splits, T, prec, sAB, dw_stream()));
+      seg(r.wo, grads + p.wo, splits2, (int64_t)H * H, (int64_t)H * H);
+    } else {
+      XF_TRY(xf_linear_bwd_dw_deferred(dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, dw_stream()));
+    }
     seg(r.wqkv, grads + p.wqkv, splits, (int64_t)3 * H * H, (int64_t)3 * H * H);
     seg(r.bqkv, grads + p.bqkv, splits, 3 * H, 3 * H);
     ln2_done = false;

@@ -290,8 +290,8 @@ __device__ __forceinline__ f32x16 xf_mma(float a, float b, f32x16 c) {
 // Here the workgroups of one XCD (d % 8) walk the N-tiles of one M-tile (one K split for the dW GEMMs) back to back,
 // so the re-reads hit that XCD's L2.
 struct TileIdx { int n, m, z; bool valid; };
-__device__ __forceinline__ TileIdx tile_of(const int nt_n, const int nt_m, const int nt_z) {
-  const int d = blockIdx.x, xcd = d & 7, slot = d >> 3;
+__device__ __forceinline__ TileIdx tile_of(const int nt_n, const int nt_m, const int nt_z, const int d = blockIdx.x) {
+  const int xcd = d & 7, slot = d >> 3;
   TileIdx t;
   if (nt_z > 1) {  // split-K: the (m, n) tiles of one split share its A and B slices
     const int per = nt_n * nt_m;
@@ -578,7 +578,7 @@ template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S
 //  sequences/s with the default bound. Round 1 believed this bound was what made them run-to-run deterministic; the
 //  cause was the packed-fp32 op_sel form described at XF_PIN_SCALAR above, which the default-bound schedule happened
 //  to contain and this one did not. With the scalars pinned, both bounds are bit-reproducible.)
-__global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? XF_LN_EPI_MIN_WAVES : 1) void gemm_kernel(const GemmArgs g_in) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g_in, const int bid) {  // bid: workgroup index within THIS GEMM
   GemmArgs g = g_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
   if (EPI != EPI_SPLITK) XF_CHAIN_PRIO();
   g.drop = xf_drop_resolve(g.drop); g.drop2 = xf_drop_resolve(g.drop2);
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
-  const TileIdx tix = tile_of(g.nt_n, g.nt_m, g.nt_z);
+  const TileIdx tix = tile_of(g.nt_n, g.nt_m, g.nt_z, bid);
   if (!tix.valid) return;  // (whole workgroup: the grid is padded to a multiple of 8 M-tiles / K splits)
   const int64_t m0 = (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? xf_tile_rows(g, tix.m, BM) : (int64_t)tix.m * BM;
   const int n0 = tix.n * BN;
@@ -817,6 +817,20 @@ __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD
     }
   }
 }
+template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S>
+__global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? XF_LN_EPI_MIN_WAVES : 1) void gemm_kernel(const GemmArgs g_in) {
+  gemm_body<P, BM, BN, BK, TA, TB, EPI, S>(g_in, (int)blockIdx.x);
+}
+// Two GEMMs of one tile configuration in one launch: workgroups [0, n0) are the first's, the rest the second's. The
+// weight-gradient GEMMs of a layer come in pairs whose operands are ready together (FFN2 + FFN1, out-proj + QKV): at
+// small batches every launch costs its ramp and its tail -- 16 launches of 7.8 us at batch 32 (round 3).
+struct GemmPair { GemmArgs g[2]; int n0; };
+template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S>
+__global__ __launch_bounds__(256, 1) void gemm_pair_kernel(const GemmPair p) {
+  const bool second = (int)blockIdx.x >= p.n0;
+  gemm_body<P, BM, BN, BK, TA, TB, EPI, S>(second ? p.g[1] : p.g[0], second ? (int)blockIdx.x - p.n0 : (int)blockIdx.x);
+}
+
 
 // ---- fused FFN forward (bf16 storage, H = 128) -----------------------------------------------------------------------
 //   u = x W1^T + b1 (T x I)  ->  g = gelu(u)  ->  y = g W2^T + b2  ->  dropout, + residual, LayerNorm
@@ -1397,6 +1411,10 @@ int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
   if (want < 1) want = 1;
   int64_t chunk = (M + want - 1) / want;
   chunk = ((chunk + 127) / 128) * 128;  // multiple of the deep K slice
+  // at least two deep slices per slab once there are tokens for it: at batch 32 (6400 tokens) 50 one-slice slabs per
+  // weight made the slab traffic (write + reduction) the larger part of the weight gradients -- 25 slabs: 0.760 against
+  // 0.847 ms/step; batch 128 and up already have >= 256 tokens per slab (round 3, one box)
+  if (M >= 4096 && chunk < 256) chunk = 256;
   if (chunk < 64) chunk = 64;
   *k_chunk = (int)chunk;
   return (int)((M + chunk - 1) / chunk);
@@ -1634,6 +1652,53 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
   g.drop = xf_make_dropout(0.f, 0, 0);
   *splits_out = splits;
   return dispatch_gemm<true, true, EPI_SPLITK, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, splits, precision, st);
+}
+
+// internal (encoder.hip): the split-K weight-gradient GEMMs of TWO Linears over the same M tokens in ONE launch
+// (gemm_pair_kernel); anything but the bf16 production form falls back to two launches. Results are those of
+// xf_linear_bwd_dw_deferred bit for bit (same tiles, same splits, same order inside each).
+int xf_linear_bwd_dw_pair(const void* dy0, const void* x0, int32_t N0, int32_t K0, float* slabs0, float* bias0,
+                          int* splits0, const void* dy1, const void* x1, int32_t N1, int32_t K1, float* slabs1,
+                          float* bias1, int* splits1, int64_t M, int32_t precision, uint32_t s16, hipStream_t st) {
+  constexpr uint32_t SAB = XF_S16_A | XF_S16_B;
+  static const bool env_tiles = getenv("XFMR_DW_TILE") || getenv("XFMR_GEMM_TILE");
+  const bool pairable = precision == XFMR_PREC_BF16 && (s16 & SAB) == SAB && !env_tiles && dy0 && x0 && slabs0 &&
+                        splits0 && dy1 && x1 && slabs1 && splits1 && M > 0 && N0 > 64 && K0 > 64 && N1 > 64 && K1 > 64 &&
+                        !((N0 | K0 | N1 | K1) & 7) && xf_aligned16(dy0) && xf_aligned16(x0) && xf_aligned16(slabs0) &&
+                        xf_aligned16(dy1) && xf_aligned16(x1) && xf_aligned16(slabs1);
+  if (!pairable) {
+    const int rc = xf_linear_bwd_dw_deferred(dy0, x0, M, N0, K0, precision, s16, slabs0, bias0, splits0, st);
+    if (rc != XFMR_OK) return rc;
+    return xf_linear_bwd_dw_deferred(dy1, x1, M, N1, K1, precision, s16, slabs1, bias1, splits1, st);
+  }
+  GemmPair p{};
+  int64_t blocks[2];
+  const void* dy[2] = {dy0, dy1}; const void* x[2] = {x0, x1};
+  const int32_t N[2] = {N0, N1}, K[2] = {K0, K1};
+  float* slabs[2] = {slabs0, slabs1}; float* bias[2] = {bias0, bias1};
+  int* so[2] = {splits0, splits1};
+  for (int i = 0; i < 2; ++i) {
+    int k_chunk;
+    const int splits = dw_split_plan(M, N[i], K[i], &k_chunk);
+    GemmArgs& g = p.g[i];
+    g.A = dy[i]; g.B = x[i]; g.C = slabs[i]; g.lda = N[i]; g.ldb = K[i]; g.ldc = K[i];
+    g.M = N[i]; g.N = K[i]; g.K = (int)M; g.k_chunk = k_chunk;
+    g.s16 = SAB; g.bias_part = bias[i];
+    g.drop = xf_make_dropout(0.f, 0, 0);
+    g.nt_n = (K[i] + 63) / 64;    // 128 x 64 tiles (launch_gemm_bk)
+    g.nt_m = (N[i] + 127) / 128;
+    g.nt_z = splits;
+    const int64_t groups = splits > 1 ? (splits + 7) / 8 : (g.nt_m + 7) / 8;
+    const int64_t per = splits > 1 ? (int64_t)g.nt_n * g.nt_m : g.nt_n;
+    blocks[i] = groups * per * 8;
+    *so[i] = splits;
+  }
+  if (blocks[0] + blocks[1] > 0x7fffffffll) return XFMR_EUNSUPPORTED;
+  p.n0 = (int)blocks[0];
+  hipLaunchKernelGGL((gemm_pair_kernel<PrecBF16, 128, 64, 128, true, true, EPI_SPLITK, SAB>),
+                     dim3((unsigned)(blocks[0] + blocks[1])), dim3(256), 0, st, p);
+  XF_LAUNCH_CHECK();
+  return XFMR_OK;
 }
 
 int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st) {

@@ -797,6 +797,11 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   const int64_t tiles = (cols + BN - 1) / BN;
   int64_t ns = (1024 + qblocks / 2) / qblocks;  // ~1024 workgroups: two full rounds at 2 workgroups/CU
   if (ns > 16) ns = 16;
+  // 32 ... 63 query blocks (batch 32 at L = 200 is 50): 16 splits leave each workgroup 4 of the 61 column tiles behind a
+  // query prologue worth ~10, and the combine kernel 16 partial records per query: 8 splits 0.790 ms/step, 16 0.830, 4
+  // 0.794 (round 3, one box). At 100 blocks (batch 64) the formula's 10 measured better than 8 (1.000 against 1.013);
+  // fewer than 32 blocks (the reference's default model: 8) keep the finer split.
+  if (qblocks >= 32 && qblocks < 64 && ns > 8) ns = 8;
   if (ns < 2) ns = 2;  // measured at 800 query blocks (B = 512): 2 splits 95.5k seq/s, 1 split 94.1k
   // >= 512 query blocks: the gradient pass runs ONE split there (run_loss), so this count is the logging pass's alone. At
   // three workgroups per CU (768 slots) 800 blocks x 2 splits are 2.08 rounds -- the third round nearly empty; finer

@@ -24,6 +24,7 @@ NEG_SHARED, NEG_CATALOG = 0, 1
 ATTN_CAUSAL, ATTN_BIDIRECTIONAL = 0, 1  # xfmr_attn_{fwd,bwd}_mode
 # xfmr_encoder_cfg.flags
 ENC_BIDIRECTIONAL, ENC_LN_UNFUSED, ENC_FFN_UNFUSED, ENC_FFN_BWD_UNFUSED, ENC_DW_INLINE, ENC_DW_SIDE_ANY = 1, 2, 4, 8, 16, 32
+ENC_DW_UNPAIRED = 64
 LOSS_DTOK_ZEROED = 1  # xfmr_loss_cfg.flags
 ABI_VERSION = 2
 NUM_LOSSES, NUM_STATS = 7, 16

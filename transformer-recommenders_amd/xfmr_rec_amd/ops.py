@@ -381,6 +381,8 @@ def encoder_flags_from_env() -> int:
         f |= N.ENC_FFN_BWD_UNFUSED
     if os.environ.get("XFMR_DW_SIDE", "") == "0":
         f |= N.ENC_DW_INLINE
+    if os.environ.get("XFMR_DW_PAIR", "") == "0":
+        f |= N.ENC_DW_UNPAIRED
     return f
 
 
