@@ -80,7 +80,7 @@ enum {
                                     (xfmr_rec_amd.trainer.GraphedStep) those calls cost nothing at replay, and a small
                                     step's weight-gradient GEMMs run beside its latency-bound dX chain.              */
   XFMR_ENC_DW_UNPAIRED = 64u,    /* every weight-gradient GEMM a launch of its own. Without it the in-line form (no side
-                                    stream) launches them in pairs -- FFN2 + FFN1, out-proj + QKV: identical slabs.      */
+                                    stream, bf16 storage) launches the four of a layer together: identical slabs.       */
   XFMR_ENC_FLAGS_ALL = 127u
 };
 

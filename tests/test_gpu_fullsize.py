@@ -303,10 +303,10 @@ def test_weight_gradient_gemms_on_the_side_stream_give_the_same_bits(ops, B, nL)
     ctx.close()
 
 
-@pytest.mark.parametrize("B,L,H,A,I", [(32, 200, 128, 4, 512), (8, 50, 64, 2, 256), (16, 64, 256, 8, 1024)])
-def test_paired_weight_gradient_launches_give_the_same_bits(ops, B, L, H, A, I):
-    """In line (no side stream) the backward launches the weight-gradient GEMMs of a layer in PAIRS -- FFN2 + FFN1,
-    out-proj + QKV: one gemm_pair_kernel launch each -- unless XFMR_ENC_DW_UNPAIRED asks for one launch per GEMM. Same tiles,
+@pytest.mark.parametrize("B,L,H,A,I", [(32, 200, 128, 4, 512), (128, 200, 128, 4, 512), (8, 50, 64, 2, 256), (16, 64, 256, 8, 1024)])
+def test_grouped_weight_gradient_launches_give_the_same_bits(ops, B, L, H, A, I):
+    """In line (no side stream) the backward launches the four weight-gradient GEMMs of a layer TOGETHER -- FFN2, FFN1,
+    out-proj, QKV: one gemm_group_kernel launch -- unless XFMR_ENC_DW_UNPAIRED asks for one launch per GEMM. Same tiles,
     same splits, same slabs: every gradient equal bit for bit, at the reference's default batch (32 x 200) and at widths
     other than 128."""
     from xfmr_rec_amd import _native as N

@@ -73,6 +73,8 @@ struct Acts {
   float* emb_ln;  // embedding LayerNorm partial records
   float *dA, *dB;
   void *dLin, *dCtx, *dI, *dQKV;  // bf16 when mixed
+  void* dLin2;  // in-line form: the out-proj Linear's output gradient (dLin keeps the FFN2 Linear's until the layer's
+                // weight-gradient GEMMs have gone out together: xf_linear_bwd_dw_group)
   // one set PER LAYER for the side-stream dW GEMMs (xfmr_encoder_bwd): dLin in its two roles (gradient of the FFN2 / of
   // the out-proj Linear's output), dI and dQKV -- no buffer is rewritten while a weight-gradient GEMM may still read it
   void *dLinF[64], *dLinO[64], *dI2[64], *dQKV2[64];
@@ -137,6 +139,7 @@ Acts carve(const xfmr_encoder_cfg* c, unsigned char* base, int layer, LayerActs*
   a.x0b = take_bytes(xb);
   a.dA = take(T * H); a.dB = take(T * H);
   a.dLin = take_bytes(T * H * es); a.dCtx = take_bytes(T * H * es);
+  a.dLin2 = take_bytes(T * H * es);
   a.dI = take_bytes(T * I * es); a.dQKV = take_bytes(T * 3 * H * es);
   // (+236 MB per layer at T = 102 400, I = 512: only when the backward will use the side stream)
   const bool per_layer = dw_side_shape(c, (int64_t)T) && c->context && !(c->flags & XFMR_ENC_DW_INLINE);
@@ -466,7 +469,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     }
     int blocks = 0, splits = 0;
     void* const dLinF = dw_side ? a.dLinF[i] : a.dLin;   // gradient of the FFN2 Linear's output (dropout-scaled d(pre2))
-    void* const dLinO = dw_side ? a.dLinO[i] : a.dLin;   // gradient of the out-proj Linear's output
+    void* const dLinO = dw_side ? a.dLinO[i] : a.dLin2;  // gradient of the out-proj Linear's output
     void* const dI = dw_side ? a.dI2[i] : a.dI;
     void* const dQKV = dw_side ? a.dQKV2[i] : a.dQKV;
     // LayerNorm 2 -> dA = d(pre2); d_lin = gradient of the FFN output Linear (dropout-scaled copy of it)
@@ -481,18 +484,19 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     }
     const void* dlin = lin_copy ? dLinF : (const void*)a.dA;
     const bool fuse_ffn_bwd = fuse_ffn && fuse_lnb && !no_ffn_bwd;
-    // The weight-gradient GEMMs go out in pairs whose operands are ready together -- FFN2 + FFN1 once dI exists, out-proj +
-    // QKV once dQKV does -- one launch each (xf_linear_bwd_dw_pair; same slabs bit for bit). In line (small batches) that
-    // halves 16 launches of ~8 us; on the side stream the FFN2 GEMM would lose its head start underneath the FFN dX
-    // kernel, so the pairs are for the in-line form only (and need dLinF intact after the FFN dX step: not with the
-    // fused FFN backward writing dLinO over it).
-    const bool pair_ffn = pair_dw && !dw_side && !(fuse_ffn_bwd && dLinF == dLinO);
-    const bool pair_att = pair_dw && !dw_side;
-    int splits2 = 0;
-    if (!pair_ffn) {
+    // In line (no side stream) the four weight-gradient GEMMs of the layer go out in ONE launch once its last operand
+    // (dQKV) exists (xf_linear_bwd_dw_group; same slabs bit for bit): 16 launches of ~8 us become 4 at batch 32. Their
+    // operands all live to the end of the layer: dLinF (dLin), dI, dLinO (dLin2), dQKV are four different buffers and the
+    // next writer of any of them is the next layer. On the side stream each GEMM keeps its own launch: there the FFN2 one
+    // starts underneath the FFN dX kernel, long before dQKV exists.
+    // (grouped on the side stream too: 3.245-3.265 against 3.244-3.269 ms/step at batch 512, 6.09-6.16 against 6.07-6.10 at 1024)
+    const bool group_dw = pair_dw && !dw_side && mix;  // (bf16 storage: the dLin copies exist; fp32 keeps one launch each)
+    int splits_w2 = 0, splits_w1 = 0, splits_wo = 0;
+    if (!group_dw) {
       XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.g, T, H, I, prec, sAB, r.w2, nullptr, &splits, dw_stream()));
       seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
     }
+    const void* const dlin_ffn = dlin;
     if (fuse_ffn_bwd) {  // FFN2 dX * gelu'(u) -> dI -> FFN1 dX (+= d(pre2)) -> LayerNorm 1 backward in one kernel
       XF_TRY(xf_ffn_bwd_dx_fused_ex(dlin, W(p.w2), l.f1, W(p.w1), dI, T, H, I, a.dA, l.pre1, l.mean1, l.rstd1,
                                     params + p.ln1g, cfg->hidden_dropout, sd, site_out(i), dX, dLinO, r.ln1,
@@ -502,16 +506,11 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.w2), dI, T, H, I, nullptr, l.f1, prec,
                                  sA | sC | sP | sB | (fuse_ffn ? 0 : XF_AUX_GELU_GRAD), st));
     }
-    if (pair_ffn) {
-      XF_TRY(xf_linear_bwd_dw_pair(dlin, l.g, H, I, r.w2, nullptr, &splits2, dI,
-                                   mix ? (const void*)l.x1b : (const void*)l.x1, I, H, r.w1, r.b1, &splits, T, prec, sAB,
-                                   dw_stream()));
-      seg(r.w2, grads + p.w2, splits2, (int64_t)H * I, (int64_t)H * I);
-    } else {
+    if (!group_dw) {
       XF_TRY(xf_linear_bwd_dw_deferred(dI, mix ? (const void*)l.x1b : (const void*)l.x1, T, I, H, prec, sAB, r.w1, r.b1, &splits, dw_stream()));  // + b1 partial rows
+      seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
+      seg(r.b1, grads + p.b1, splits, I, I);
     }
-    seg(r.w1, grads + p.w1, splits, (int64_t)I * H, (int64_t)I * H);
-    seg(r.b1, grads + p.b1, splits, I, I);
     if (fuse_ffn_bwd) {  // (done above)
     } else if (fuse_lnb) {  // dX of FFN1 (+= d(pre2)) and LayerNorm 1 backward in one kernel -> dX = d(pre1), dLin
       XF_TRY(xf_linear_bwd_dx_lnbwd_ex(dI, W(p.w1), T, I, H, a.dA, l.pre1, l.mean1, l.rstd1, params + p.ln1g,
@@ -528,17 +527,24 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     seg(r.ln1 + H, grads + p.ln1b, blocks, H, 3 * H);
     seg(r.ln1 + 2 * H, grads + p.bo, blocks, H, 3 * H);
     dlin = lin_copy ? dLinO : (const void*)dX;
-    if (!pair_att) {
+    if (!group_dw) {
       XF_TRY(xf_linear_bwd_dw_deferred(dlin, l.ctx, T, H, H, prec, sAB, r.wo, nullptr, &splits, dw_stream()));
       seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
     }
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
     XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, dQKV, B, L, A, H, cfg->attn_dropout, sd,
                           site_attn(i), prec, mix, causal, st));
-    if (pair_att) {
-      XF_TRY(xf_linear_bwd_dw_pair(dlin, l.ctx, H, H, r.wo, nullptr, &splits2, dQKV, x_in_g, 3 * H, H, r.wqkv, r.bqkv,
-                                   &splits, T, prec, sAB, dw_stream()));
-      seg(r.wo, grads + p.wo, splits2, (int64_t)H * H, (int64_t)H * H);
+    if (group_dw) {
+      const XfDwItem items[4] = {
+          {dlin_ffn, l.g, (int32_t)H, (int32_t)I, r.w2, nullptr, &splits_w2},
+          {dI, mix ? (const void*)l.x1b : (const void*)l.x1, (int32_t)I, (int32_t)H, r.w1, r.b1, &splits_w1},
+          {dlin, l.ctx, (int32_t)H, (int32_t)H, r.wo, nullptr, &splits_wo},
+          {dQKV, x_in_g, (int32_t)(3 * H), (int32_t)H, r.wqkv, r.bqkv, &splits}};
+      XF_TRY(xf_linear_bwd_dw_group(items, 4, T, prec, sAB, st));
+      seg(r.w2, grads + p.w2, splits_w2, (int64_t)H * I, (int64_t)H * I);
+      seg(r.w1, grads + p.w1, splits_w1, (int64_t)I * H, (int64_t)I * H);
+      seg(r.b1, grads + p.b1, splits_w1, I, I);
+      seg(r.wo, grads + p.wo, splits_wo, (int64_t)H * H, (int64_t)H * H);
     } else {
       XF_TRY(xf_linear_bwd_dw_deferred(dQKV, x_in_g, T, 3 * H, H, prec, sAB, r.wqkv, r.bqkv, &splits, dw_stream()));
     }

@@ -821,35 +821,17 @@ template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S
 __global__ __launch_bounds__(256, (EPI == EPI_DROP_RES_LN || EPI == EPI_DX_LNBWD) ? XF_LN_EPI_MIN_WAVES : 1) void gemm_kernel(const GemmArgs g_in) {
   gemm_body<P, BM, BN, BK, TA, TB, EPI, S>(g_in, (int)blockIdx.x);
 }
-// Two GEMMs of one tile configuration in one launch: workgroups [0, n0) are the first's, the rest the second's. The
-// weight-gradient GEMMs of a layer come in pairs whose operands are ready together (FFN2 + FFN1, out-proj + QKV): at
-// small batches every launch costs its ramp and its tail -- 16 launches of 7.8 us at batch 32 (round 3).
-struct GemmPair { GemmArgs g[2]; int n0; };
+// Up to four GEMMs of one tile configuration in one launch: workgroups [start[i], start[i + 1]) are GEMM i's. The
+// weight-gradient GEMMs of a layer -- FFN2, FFN1, out-proj, QKV -- go out together once the layer's last operand (dQKV)
+// exists: at small batches every launch costs its ramp and its tail -- 16 launches of 7.8 us at batch 32 (round 3).
+struct GemmGroup { GemmArgs g[4]; int start[5]; };
 template <class P, int BM, int BN, int BK, bool TA, bool TB, int EPI, uint32_t S>
-__global__ __launch_bounds__(256, 1) void gemm_pair_kernel(const GemmPair p) {
-  const bool second = (int)blockIdx.x >= p.n0;
-  gemm_body<P, BM, BN, BK, TA, TB, EPI, S>(second ? p.g[1] : p.g[0], second ? (int)blockIdx.x - p.n0 : (int)blockIdx.x);
+__global__ __launch_bounds__(256, 1) void gemm_group_kernel(const GemmGroup p) {
+  const int b = (int)blockIdx.x;
+  const int i = (b >= p.start[1]) + (b >= p.start[2]) + (b >= p.start[3]);  // (unused entries start at the grid's end)
+  gemm_body<P, BM, BN, BK, TA, TB, EPI, S>(p.g[i], b - p.start[i]);
 }
 
-
-// ---- fused FFN forward (bf16 storage, H = 128) -----------------------------------------------------------------------
-//   u = x W1^T + b1 (T x I)  ->  g = gelu(u)  ->  y = g W2^T + b2  ->  dropout, + residual, LayerNorm
-// (TF:modeling_bert.py:325-351) in ONE kernel: a workgroup owns 64 token rows and walks I in chunks of CH columns; the
-// second GEMM reads g from LDS, never from HBM. Written for the backward (bf16): g (the dW2 GEMM's operand) and the
-// PRE-activation u, from which the FFN2 dX epilogue evaluates gelu'(u) -- the two-kernel form saves gelu'(u) instead;
-// the backward is told which (encoder.hip: ffn_fused). Measured alternatives: writing gelu'(u) from here (one erf gives
-// both, but +16 us in this kernel against +4 us in the dX epilogue); storing only u and applying gelu on the dW2 GEMM's
-// way into LDS (that GEMM went from 27 to 53 us, more than the 105 MB of writes saved). u is rounded to bf16 BEFORE the
-// GELU, as the reference's bf16 autocast holds the Linear's output. Per layer at T = 102 400, I = 512: 418 MB instead
-// of 524 MB.
-//   LDS (CH = 64): sG [64][72] bf16 (u, then g in place: the A operand of the second GEMM) + sW 18 KB (the W1 chunk
-//   [64][136], then the W2 chunk [128][72]; the x tile before the first chunk, the epilogue's scratch after the last):
-//   27.6 KB. The x tile's MFMA fragments stay in registers for the whole tile (32 VGPRs); 168 VGPRs = 3 waves per SIMD.
-//   Weights stream from L2 (256 KB per layer, shared by every workgroup) through two register sets, a chunk ahead.
-//   Measured at T = 102 400 (rocprofv3): 110 us against 59 + 65 us for the two launches it replaces (the pair was not
-//   bound by the re-read of g: the kernel is as sensitive to its VALU work as to its bytes). Tried and not kept:
-//   128-column chunks (two workgroups per CU: 118 us); barriers that leave global operations in flight
-//   (s_waitcnt lgkmcnt(0) + s_barrier instead of __syncthreads: no change).
 struct FfnFwdArgs {
   const __bf16* X;    // [M][128]
   const __bf16* W1;   // [I][128]
@@ -1257,6 +1239,35 @@ __global__ __launch_bounds__(256) void multi_rowsum_kernel(MultiSegs m) {
   const XfReduceSeg sg = m.s[si];
   const int bx = (int)blockIdx.x - m.first[si];
   const bool vec = !((sg.cols | sg.ld) & 3) && !(reinterpret_cast<uintptr_t>(sg.src) & 15);
+  if (sg.pad) {
+    // Short and wide (xf_multi_rowsum marks them: <= 64 rows, >= 256 columns, 16-byte pieces): 256 columns per block, 4 row
+    // groups of 64 lanes x 4 columns, every row of the segment in flight at once. The split-K slabs of a small batch are
+    // 15-50 rows: in the 64-column form a block moved 4-13 KB and the launch was bound by its 70 k blocks (config 4: 140 us
+    // for 360 MB).
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = bx * 256 + 4 * cq;
+    float4 s[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s[u] = make_float4(0, 0, 0, 0);
+    if (col < sg.cols) {
+      const float* src = sg.src + col;
+      const int64_t ld = sg.ld;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = rg + 4 * u;
+        if (r < sg.rows) s[u] = *reinterpret_cast<const float4*>(src + r * ld);
+      }
+    }
+    auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    const float4 t = add4(add4(add4(add4(s[0], s[1]), add4(s[2], s[3])), add4(add4(s[4], s[5]), add4(s[6], s[7]))),
+                          add4(add4(add4(s[8], s[9]), add4(s[10], s[11])), add4(add4(s[12], s[13]), add4(s[14], s[15]))));
+    float4* red4 = reinterpret_cast<float4*>(&red[0][0]);  // [4 row groups][64 lanes]
+    red4[rg * 64 + cq] = t;
+    __syncthreads();
+    if (rg == 0 && col < sg.cols)
+      *reinterpret_cast<float4*>(sg.dst + col) = add4(add4(red4[cq], red4[64 + cq]), add4(red4[128 + cq], red4[192 + cq]));
+    return;
+  }
   if (vec) {
     const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int col = bx * 64 + 4 * cq;
@@ -1654,49 +1665,51 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
   return dispatch_gemm<true, true, EPI_SPLITK, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, splits, precision, st);
 }
 
-// internal (encoder.hip): the split-K weight-gradient GEMMs of TWO Linears over the same M tokens in ONE launch
-// (gemm_pair_kernel); anything but the bf16 production form falls back to two launches. Results are those of
+// internal (encoder.hip): the split-K weight-gradient GEMMs of up to FOUR Linears over the same M tokens in ONE launch
+// (gemm_group_kernel); anything but the bf16 production form falls back to one launch each. Results are those of
 // xf_linear_bwd_dw_deferred bit for bit (same tiles, same splits, same order inside each).
-int xf_linear_bwd_dw_pair(const void* dy0, const void* x0, int32_t N0, int32_t K0, float* slabs0, float* bias0,
-                          int* splits0, const void* dy1, const void* x1, int32_t N1, int32_t K1, float* slabs1,
-                          float* bias1, int* splits1, int64_t M, int32_t precision, uint32_t s16, hipStream_t st) {
+int xf_linear_bwd_dw_group(const XfDwItem* items, int n, int64_t M, int32_t precision, uint32_t s16, hipStream_t st) {
   constexpr uint32_t SAB = XF_S16_A | XF_S16_B;
+  if (!items || n < 1 || n > 4) return XFMR_EINVAL;
   static const bool env_tiles = getenv("XFMR_DW_TILE") || getenv("XFMR_GEMM_TILE");
-  const bool pairable = precision == XFMR_PREC_BF16 && (s16 & SAB) == SAB && !env_tiles && dy0 && x0 && slabs0 &&
-                        splits0 && dy1 && x1 && slabs1 && splits1 && M > 0 && N0 > 64 && K0 > 64 && N1 > 64 && K1 > 64 &&
-                        !((N0 | K0 | N1 | K1) & 7) && xf_aligned16(dy0) && xf_aligned16(x0) && xf_aligned16(slabs0) &&
-                        xf_aligned16(dy1) && xf_aligned16(x1) && xf_aligned16(slabs1);
-  if (!pairable) {
-    const int rc = xf_linear_bwd_dw_deferred(dy0, x0, M, N0, K0, precision, s16, slabs0, bias0, splits0, st);
-    if (rc != XFMR_OK) return rc;
-    return xf_linear_bwd_dw_deferred(dy1, x1, M, N1, K1, precision, s16, slabs1, bias1, splits1, st);
+  bool groupable = n > 1 && precision == XFMR_PREC_BF16 && (s16 & SAB) == SAB && !env_tiles && M > 0;
+  for (int i = 0; i < n && groupable; ++i) {
+    const XfDwItem& t = items[i];
+    groupable = t.dy && t.x && t.slabs && t.splits && t.N > 64 && t.K > 64 && !((t.N | t.K) & 7) && xf_aligned16(t.dy) &&
+                xf_aligned16(t.x) && xf_aligned16(t.slabs);
   }
-  GemmPair p{};
-  int64_t blocks[2];
-  const void* dy[2] = {dy0, dy1}; const void* x[2] = {x0, x1};
-  const int32_t N[2] = {N0, N1}, K[2] = {K0, K1};
-  float* slabs[2] = {slabs0, slabs1}; float* bias[2] = {bias0, bias1};
-  int* so[2] = {splits0, splits1};
-  for (int i = 0; i < 2; ++i) {
+  if (!groupable) {
+    for (int i = 0; i < n; ++i) {
+      const XfDwItem& t = items[i];
+      const int rc = xf_linear_bwd_dw_deferred(t.dy, t.x, M, t.N, t.K, precision, s16, t.slabs, t.bias_part, t.splits, st);
+      if (rc != XFMR_OK) return rc;
+    }
+    return XFMR_OK;
+  }
+  GemmGroup p{};
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    const XfDwItem& t = items[i];
     int k_chunk;
-    const int splits = dw_split_plan(M, N[i], K[i], &k_chunk);
+    const int splits = dw_split_plan(M, t.N, t.K, &k_chunk);
     GemmArgs& g = p.g[i];
-    g.A = dy[i]; g.B = x[i]; g.C = slabs[i]; g.lda = N[i]; g.ldb = K[i]; g.ldc = K[i];
-    g.M = N[i]; g.N = K[i]; g.K = (int)M; g.k_chunk = k_chunk;
-    g.s16 = SAB; g.bias_part = bias[i];
+    g.A = t.dy; g.B = t.x; g.C = t.slabs; g.lda = t.N; g.ldb = t.K; g.ldc = t.K;
+    g.M = t.N; g.N = t.K; g.K = (int)M; g.k_chunk = k_chunk;
+    g.s16 = SAB; g.bias_part = t.bias_part;
     g.drop = xf_make_dropout(0.f, 0, 0);
-    g.nt_n = (K[i] + 63) / 64;    // 128 x 64 tiles (launch_gemm_bk)
-    g.nt_m = (N[i] + 127) / 128;
+    g.nt_n = (t.K + 63) / 64;    // 128 x 64 tiles (launch_gemm_bk)
+    g.nt_m = (t.N + 127) / 128;
     g.nt_z = splits;
     const int64_t groups = splits > 1 ? (splits + 7) / 8 : (g.nt_m + 7) / 8;
     const int64_t per = splits > 1 ? (int64_t)g.nt_n * g.nt_m : g.nt_n;
-    blocks[i] = groups * per * 8;
-    *so[i] = splits;
+    p.start[i] = (int)total;
+    total += groups * per * 8;
+    if (total > 0x7fffffffll) return XFMR_EUNSUPPORTED;
+    *t.splits = splits;
   }
-  if (blocks[0] + blocks[1] > 0x7fffffffll) return XFMR_EUNSUPPORTED;
-  p.n0 = (int)blocks[0];
-  hipLaunchKernelGGL((gemm_pair_kernel<PrecBF16, 128, 64, 128, true, true, EPI_SPLITK, SAB>),
-                     dim3((unsigned)(blocks[0] + blocks[1])), dim3(256), 0, st, p);
+  for (int i = n; i <= 4; ++i) p.start[i] = (int)total;
+  hipLaunchKernelGGL((gemm_group_kernel<PrecBF16, 128, 64, 128, true, true, EPI_SPLITK, SAB>), dim3((unsigned)total),
+                     dim3(256), 0, st, p);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
@@ -1711,10 +1724,15 @@ int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st) {
     int order[64];
     for (int i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order, order + n, [&](int x, int y) { return segs[base + x].rows > segs[base + y].rows; });
+    static const bool wide_on = [] { const char* e = getenv("XFMR_ROWSUM_WIDE"); return !(e && *e == '0'); }();  // A/B
     for (int i = 0; i < n; ++i) {
       m.s[i] = segs[base + order[i]];
       m.first[i] = blocks;
-      blocks += m.s[i].cols > 0 ? (m.s[i].cols + 63) / 64 : 0;
+      XfReduceSeg& sg = m.s[i];
+      const bool wide = wide_on && sg.rows <= 64 && sg.cols >= 256 && !((sg.cols | sg.ld) & 3) &&
+                        !(reinterpret_cast<uintptr_t>(sg.src) & 15) && !(reinterpret_cast<uintptr_t>(sg.dst) & 15);
+      sg.pad = wide ? 1 : 0;  // (the field is the launch's own: callers leave it 0)
+      blocks += sg.cols > 0 ? (wide ? (sg.cols + 255) / 256 : (sg.cols + 63) / 64) : 0;
     }
     m.first[n] = blocks;
     m.n = n;

@@ -44,10 +44,9 @@ int xf_colsum_ex(const void* a, bool a16, float* out, int64_t M, int32_t N, void
 size_t xf_linear_bwd_dw_slab_bytes(int64_t M, int32_t N, int32_t K);
 int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t N, int32_t K, int32_t precision,
                               uint32_t s16, float* slabs, float* bias_part, int* splits, hipStream_t st);
-// two of them over the same M tokens in one launch (gemm.hip: gemm_pair_kernel)
-int xf_linear_bwd_dw_pair(const void* dy0, const void* x0, int32_t N0, int32_t K0, float* slabs0, float* bias0,
-                          int* splits0, const void* dy1, const void* x1, int32_t N1, int32_t K1, float* slabs1,
-                          float* bias1, int* splits1, int64_t M, int32_t precision, uint32_t s16, hipStream_t st);
+// up to four of them over the same M tokens in one launch (gemm.hip: gemm_group_kernel)
+struct XfDwItem { const void* dy; const void* x; int32_t N, K; float* slabs; float* bias_part; int* splits; };
+int xf_linear_bwd_dw_group(const XfDwItem* items, int n, int64_t M, int32_t precision, uint32_t s16, hipStream_t st);
 // dst[c] = sum_r src[r * ld + c], r < rows, c < cols, for every segment, in one launch (deterministic order)
 struct XfReduceSeg { const float* src; float* dst; int rows; int cols; int ld; int pad; };
 int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st);
