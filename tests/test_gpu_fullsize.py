@@ -179,6 +179,34 @@ def test_config5_million_item_gather_is_bit_exact_and_ccl_runs(XL, ops):
     assert ac == pytest.approx(a + c, rel=1e-5)
 
 
+@pytest.mark.parametrize("T", [32768, 12800, 3000])
+@pytest.mark.parametrize("head", ["AlignmentContrastiveLoss", "InfoNCELoss", "PairwiseLogisticLoss"])
+def test_h256_gradient_pass_split_plans_agree_with_the_fp32_path(ops, T, head):
+    """H = 256 gradient passes run one workgroup per CU; the launch picks the column-split count by rounds (loss.hip): 256
+    query blocks (config 5's shape) run ONE split and finish their rows inside the kernel, 100 blocks (config 4's) run 5,
+    24 blocks the plan's own count. Whatever the split, loss and gradient must be those of the fp32 policy's generic
+    kernel within the bf16 tolerances, and the statistics' counts equal."""
+    from xfmr_rec_amd import _native as N
+
+    H, V = 256, 1500
+    g = torch.Generator().manual_seed(57)
+    table = _unit_table(V, H, 99).to(DEV)
+    rn, tb = ops.table_prepare(table)
+    tok = torch.randn(T, H, generator=g).to(DEV)
+    mask = (torch.rand(T, generator=g) < 0.97).to(torch.uint8).to(DEV)
+    pos = torch.randint(1, V + 1, (T,), generator=g).to(DEV)
+    neg = torch.randint(1, V + 1, (T,), generator=g).to(DEV)
+    kw = dict(train_head=head, all_heads=True)
+    l16, s16, d16 = ops.sampled_loss(tok, mask, pos, neg, table, rn, precision="bf16", table_bf16=tb, **kw)
+    l32, s32, d32 = ops.sampled_loss(tok, mask, pos, neg, table, rn, precision="fp32", **kw)
+    i = N.LOSS_IDS[head]
+    assert abs(float(l16[i]) - float(l32[i])) <= TOL["bf16"]["loss_rel"] * abs(float(l32[i])), (float(l16[i]), float(l32[i]))
+    assert rel_l2(d16, d32) <= TOL["bf16"]["grad_l2"]
+    assert int(s16[N.STAT["neg_distinct"]]) == int(s32[N.STAT["neg_distinct"]])
+    l16b, _s, d16b = ops.sampled_loss(tok, mask, pos, neg, table, rn, precision="bf16", table_bf16=tb, **kw)
+    assert torch.equal(l16, l16b) and torch.equal(d16, d16b)  # and bit-reproducible
+
+
 # 97 x 200 = 303 tiles of 64 rows + 8 rows; I = 96: the FFN2 / FFN1-dX GEMMs walk 32-deep K slices (K % 64 != 0), whose
 # operand images are smaller than the fused epilogues' LDS scratch + exchange records
 @pytest.mark.parametrize("B,nL,reps,I", [(512, 2, 8, 512), (97, 1, 2, 512), (97, 2, 1, 96)])

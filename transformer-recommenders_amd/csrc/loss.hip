@@ -965,6 +965,25 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
                         !cfg->mask_false_negatives;
     // the online-maximum InfoNCE at H > 128 runs as dQ column parts (loss_dma.inc): it keeps the split form
     const bool col_parts = H > 128 && cfg->train_head == XFMR_LOSS_INFONCE && !cfg->mask_false_negatives && !pinned;
+    // H > 128 below 512 query blocks: these gradient kernels run ONE workgroup per CU (loss_dma.inc), all of them equally
+    // long, so the pass takes ceil(blocks * n / CUs) rounds of 1 / n of the columns each. The fewest splits among the best
+    // such n: config 5 (256 blocks on 256 CUs) runs 1 split -- one full round, the rows finished in the kernel, no 134 MB
+    // of partial dQ written and re-read (6.62 -> 6.51 ms/step); config 4 (100 blocks) 5 splits instead of 10 (two rounds
+    // of 250: 3.06 -> 2.99; 3 splits = 1.17 rounds measured 3.30).
+    if (H > 128 && grid.x < 512 && ns_grad_env <= 0) {
+      static const int cus = [] {
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        return cu > 0 ? cu : 256;
+      }();
+      int best = p.nsplit;
+      double best_cost = 1e30;
+      for (int n = 1; n <= p.nsplit; ++n) {
+        const double cost = (double)(((int64_t)grid.x * n + cus - 1) / cus) / n;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = n; }
+      }
+      ns_grad = best;
+    }
     if (!grad_pass || col_parts) ns_grad = p.nsplit;
     dim3 ggrid(grid.x, (unsigned)ns_grad);
     if (grad_pass) {
