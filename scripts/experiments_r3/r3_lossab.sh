@@ -1,5 +1,5 @@
 #!/bin/bash
-# isolated loss-pass timings for experiment builds at the H = 128 and config-5 shapes: scripts/r3_lossab.sh tree name ...
+# isolated loss-pass timings for experiment builds at the H = 128 and config-5 shapes: scripts/experiments_r3/r3_lossab.sh tree name ...
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 export PYTHONUNBUFFERED=1

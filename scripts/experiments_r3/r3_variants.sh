@@ -1,5 +1,5 @@
 #!/bin/bash
-# isolated loss-pass timings + step A/B for experiment builds: scripts/r3_variants.sh name1 name2 ...   ("tree" = the product build)
+# isolated loss-pass timings + step A/B for experiment builds: scripts/experiments_r3/r3_variants.sh name1 name2 ...   ("tree" = the product build)
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out

@@ -410,7 +410,7 @@ __device__ __forceinline__ void log_acc_fold(const LogAcc& a, RowState& st) {
   st.hinge += log_acc_sum2(a.hinge); st.logi += log_acc_sum2(a.logi); st.cnt_c += log_acc_sum2(a.cnt_c);
   st.contr += log_acc_sum2(a.contr); st.ssum += log_acc_sum2(a.ssum); st.ssq += log_acc_sum2(a.ssq);
 }
-template <bool LSE, bool SHARE, bool MASK = true>
+template <bool LSE, bool SHARE, bool MASK = true, bool PAIR_FENCE = false>
 __device__ __forceinline__ void loss_epilogue_logging_masked_pk(const f32x16& s, RowState& st, LogAcc& la,
                                                                 const LogConst& k, float ycap, const int* nid_sb,
                                                                 const float* rc_sb, const float* mu_sb, int hh) {
@@ -477,6 +477,7 @@ __device__ __forceinline__ void loss_epilogue_logging_masked_pk(const f32x16& s,
       const float s0 = cd0 ? sv.x : qnan, s1 = cd1 ? sv.y : qnan;
       st.smin = fminf(st.smin, fminf(s0, s1));
       st.smax = fmaxf(st.smax, fmaxf(s0, s1));
+      if (PAIR_FENCE) __builtin_amdgcn_sched_barrier(0);  // one pair's temporaries at a time (register-bound variants)
     }
     __builtin_amdgcn_sched_barrier(0);  // (as in loss_epilogue_t: one run of four elements at a time)
   }
