@@ -96,3 +96,30 @@ def test_device_step_counter_changes_the_dropout_mask_and_matches_adamw_by_value
     ops.step_advance_(m.step_device)
     tok1, _ = m._encode_tokens(batches[0]["history_item_idx"])
     assert not torch.equal(tok0, tok1)
+
+
+@pytest.mark.parametrize("mode", ["on", "auto"])
+def test_fit_with_graph_runs_the_same_training_as_eager_steps(X, mode):
+    """Trainer.fit(graph=...): three eager steps, then (mode "on") every step a replay of ONE captured hipGraph, or (mode
+    "auto") timed eager steps, timed replays and the faster form for the rest. Whatever ran, the sequence of steps is the
+    eager one with the device-side step counter: same losses, same parameters, bit for bit; a batch of another shape
+    takes the eager step."""
+    eager, batches = _setup(X)
+    eager.model.use_device_step(True)
+    tr_e = X.Trainer(eager)
+    tr_e.optimizer.step_device = eager.model.step_device
+    graphed, _ = _setup(X)
+    tr_g = X.Trainer(graphed)
+    seq = [batches[i % len(batches)] for i in range(16)]
+    short = {k: v[:5].clone() for k, v in batches[2].items()}  # a short last batch
+    seq.append(short)
+    want = [float(tr_e.fit_step(b)) for b in seq]
+    got = tr_g.fit(seq, graph=mode, graph_probe_steps=4)
+    assert got == want
+    torch.cuda.synchronize()
+    assert torch.equal(eager.model.flat, graphed.model.flat)
+    assert int(graphed.model.step_device) == len(seq)
+    if mode == "on":
+        assert tr_g.graph_choice == "graph"
+    else:
+        assert tr_g.graph_choice in ("graph", "eager") and set(tr_g.graph_probe) == {"eager_ms", "graph_ms"}

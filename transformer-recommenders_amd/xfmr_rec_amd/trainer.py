@@ -15,6 +15,7 @@ HIP kernels from ``libxfmr_hip.so``; torch supplies memory, streams, autograd bo
 
 from __future__ import annotations
 
+import contextlib
 import time
 
 import torch
@@ -538,39 +539,103 @@ class Trainer:
         m.on_train_batch_end(loss, batch, 0)  # joins the logging stream (leaving the pass to finish underneath the next
         return loss.detach()                  # step's forward measured no gain: 3.411 vs 3.414 ms)
 
-    def fit(self, batches, max_steps: int | None = None, *, ring_slots: int = 6) -> list[float]:
+    def fit(self, batches, max_steps: int | None = None, *, ring_slots: int = 6, graph: str = "off",
+            graph_probe_steps: int = 20) -> list[float]:
         """Steps over an iterable of collated batches. Batches that arrive in HOST memory (the reference's DataLoader
         output, ``data.py:915-927``) are handed over through a :class:`~xfmr_rec_amd.data.PinnedBatchRing`: the copy of
-        batch i + 1 runs underneath step i; device-resident batches (``DeviceSeqDataset.sample_batch``) are used as they are."""
+        batch i + 1 runs underneath step i; device-resident batches (``DeviceSeqDataset.sample_batch``) are used as they are.
+
+        ``graph``: "off" -- every step is enqueued launch by launch; "on" -- after three eager steps (they create every
+        lazily made object) the step is captured once as a hipGraph (:class:`GraphedStep`) and replayed for every batch
+        of the captured shape; "auto" -- ``graph_probe_steps`` eager steps are timed, then as many replays, and the faster
+        form runs the rest (replay wins where the host's launch rate bounds the step -- BASELINE config 1's shape: 0.31
+        against 0.48 ms -- and changes nothing where the GPU does: DESIGN.md section 5). Every probe step is a real
+        training step on its own batch. Batches of another shape (a short last batch) take the eager step. Single
+        process only; ``self.graph_choice`` records what ran."""
         from .data import SEQ_BATCH_KEYS, PinnedBatchRing
+
+        if graph not in ("off", "on", "auto"):
+            raise ValueError(f"graph must be 'off', 'on' or 'auto', got {graph!r}")
+        if self.world_size != 1:
+            graph = "off"  # (the all-reduce of a data-parallel step is not captured)
+        if graph != "off":
+            # the step counter the captured kernels read (dropout stream, AdamW bias corrections) lives in HBM from the
+            # first step on, so that the eager steps in front of the capture and the replays after it are one sequence
+            mdl = self.module.model
+            if getattr(mdl, "step_device", None) is None:
+                mdl.use_device_step(True)
+                done = max((st.get("step", 0) for st in self.optimizer.state.values()), default=0)
+                mdl.step_device.fill_(int(done))
+            self.optimizer.step_device = mdl.step_device
+            if getattr(self.module, "defer_logging", "auto") == "auto":
+                self.module.defer_logging = False  # one stream: what the capture records (GraphedStep)
+        gstep, use_graph = None, False
+        probe: dict = {}
+        self.graph_choice = "eager"
+        n_warm = 3
+
+        def _sync_time():
+            torch.cuda.synchronize(self.module.model.device)
+            return time.perf_counter()
 
         out = []
         t0 = time.time()
         ring = None
-        it = iter(batches)
-        nxt = next(it, None)
-        i = 0
-        while nxt is not None and (max_steps is None or i < max_steps):
-            b = nxt
-            on_host = not b[SEQ_BATCH_KEYS[0]].is_cuda
-            if on_host:
-                if ring is None or b[SEQ_BATCH_KEYS[0]].shape[0] > ring.shape[1] or b[SEQ_BATCH_KEYS[0]].shape[1] > ring.shape[2]:
-                    if ring is not None:
-                        ring.close()
-                    bs, width = b[SEQ_BATCH_KEYS[0]].shape
-                    ring = PinnedBatchRing(self.module.model.device, bs, max(width, self.module.model.max_seq_length),
-                                           slots=ring_slots)
-                if ring.pending == 0:
-                    ring.stage(b)
-                dev_b = ring.take()
-            else:
-                dev_b = b
+        # torch's capture protocol: the eager steps in front of a capture run on a NON-default stream (autograd's
+        # AccumulateGrad nodes are bound to the stream of their first backward; captured from the default stream the
+        # capture faults). The whole loop therefore runs on a side stream when a graph may be captured.
+        dev = self.module.model.device
+        cur = torch.cuda.current_stream(dev) if graph != "off" else None
+        side = torch.cuda.Stream(device=dev) if graph != "off" else None
+        if side is not None:
+            side.wait_stream(cur)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            it = iter(batches)
             nxt = next(it, None)
-            if nxt is not None and ring is not None and not nxt[SEQ_BATCH_KEYS[0]].is_cuda \
-                    and nxt[SEQ_BATCH_KEYS[0]].shape[0] <= ring.shape[1] and nxt[SEQ_BATCH_KEYS[0]].shape[1] <= ring.shape[2]:
-                ring.stage(nxt)  # in flight while this step computes
-            out.append(self.fit_step(dev_b))
-            i += 1
+            i = 0
+            while nxt is not None and (max_steps is None or i < max_steps):
+                b = nxt
+                on_host = not b[SEQ_BATCH_KEYS[0]].is_cuda
+                if on_host:
+                    if ring is None or b[SEQ_BATCH_KEYS[0]].shape[0] > ring.shape[1] or b[SEQ_BATCH_KEYS[0]].shape[1] > ring.shape[2]:
+                        if ring is not None:
+                            ring.close()
+                        bs, width = b[SEQ_BATCH_KEYS[0]].shape
+                        ring = PinnedBatchRing(self.module.model.device, bs, max(width, self.module.model.max_seq_length),
+                                               slots=ring_slots)
+                    if ring.pending == 0:
+                        ring.stage(b)
+                    dev_b = ring.take()
+                else:
+                    dev_b = b
+                nxt = next(it, None)
+                if nxt is not None and ring is not None and not nxt[SEQ_BATCH_KEYS[0]].is_cuda \
+                        and nxt[SEQ_BATCH_KEYS[0]].shape[0] <= ring.shape[1] and nxt[SEQ_BATCH_KEYS[0]].shape[1] <= ring.shape[2]:
+                    ring.stage(nxt)  # in flight while this step computes
+                if graph != "off" and i >= n_warm:
+                    if graph == "auto" and "eager_t0" not in probe:
+                        probe["eager_t0"], probe["eager_i0"] = _sync_time(), i
+                    eager_done = graph == "on" or i - probe["eager_i0"] >= graph_probe_steps
+                    if gstep is None and eager_done:
+                        if graph == "auto":
+                            probe["eager_ms"] = (_sync_time() - probe["eager_t0"]) / (i - probe["eager_i0"]) * 1e3
+                        gstep = GraphedStep(self, dev_b, warmup=0)
+                        use_graph = True
+                        if graph == "auto":
+                            probe["graph_t0"], probe["graph_i0"] = _sync_time(), i
+                    elif graph == "auto" and gstep is not None and "graph_ms" not in probe \
+                            and i - probe["graph_i0"] >= graph_probe_steps:
+                        probe["graph_ms"] = (_sync_time() - probe["graph_t0"]) / (i - probe["graph_i0"]) * 1e3
+                        use_graph = probe["graph_ms"] < probe["eager_ms"]
+                    self.graph_choice = "graph" if use_graph else "eager"
+                if use_graph and gstep.matches(dev_b):
+                    out.append(gstep(dev_b).clone())  # (the captured loss tensor is overwritten by the next replay)
+                else:
+                    out.append(self.fit_step(dev_b))
+                i += 1
+        if side is not None:
+            cur.wait_stream(side)
+        self.graph_probe = {k: round(v, 4) for k, v in probe.items() if k.endswith("_ms")}
         if ring is not None:
             ring.release()
             ring.close()
@@ -592,7 +657,9 @@ class GraphedStep:
         step = GraphedStep(trainer, example_batch)     # device tensors of the shape every batch will have
         loss = step(batch)                             # copies the indices into the captured buffers, replays
 
-    Single process only (the all-reduce of a data-parallel step is not captured here)."""
+    Single process only (the all-reduce of a data-parallel step is not captured here). The eager steps in front of the
+    capture must NOT have run on the default stream (torch's capture protocol; the capture faults otherwise:
+    scripts/probe/fit_graph_probe.py) -- the warm-up here and ``Trainer.fit(graph=...)`` both use a side stream."""
 
     def __init__(self, trainer: Trainer, example_batch: dict, warmup: int = 3, overlap: bool = False):
         """``overlap=True`` captures the step with its two forks at ANY size -- the weight-gradient GEMMs on the context's
@@ -618,18 +685,24 @@ class GraphedStep:
         m.train()
         self.static = {k: example_batch[k].to(dev, torch.int64).clone() for k in self.keys}
         # eager warm-up on a side stream (torch's capture protocol): creates every lazily made object -- optimizer state,
-        # the model's xfmr_context, allocator pools -- so that the capture itself creates nothing
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                trainer.fit_step(self.static)
-        torch.cuda.current_stream().wait_stream(side)
+        # the model's xfmr_context, allocator pools -- so that the capture itself creates nothing. ``warmup=0``: the caller
+        # has already run eager steps of this shape (Trainer.fit does, on real batches).
+        if warmup > 0:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    trainer.fit_step(self.static)
+            torch.cuda.current_stream().wait_stream(side)
         trainer.optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = trainer.fit_step(self.static)
         self.logged = dict(m.logged)  # 0-dim device tensors inside the graph's pool: refreshed by every replay
+
+    def matches(self, batch: dict) -> bool:
+        """Whether ``batch`` has the captured shape (a replay needs it)."""
+        return all(tuple(batch[k].shape) == tuple(self.static[k].shape) for k in self.keys)
 
     def __call__(self, batch: dict) -> torch.Tensor:
         for k in self.keys:
