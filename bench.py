@@ -11,16 +11,21 @@ MI355X of one node, data-parallel over RCCL.
 One "step" = zero_grad -> gather+mask+BertEmbeddings -> 4 x BertLayer -> fused loss (all seven heads +
 LogitsStatistics + dL/dtok, as the reference's training_step evaluates them, xfmr_rec/trainer.py:250-264) ->
 encoder backward -> flat-gradient all-reduce (N > 1) -> AdamW, dropout 0.1 ON. `value` is measured with the batch
-(3 x B x 200 int64) already resident in HBM; `h2d_inclusive` repeats the timed region with the three index tensors
-copied from pinned host memory inside every step (SURVEY section 8d counts that copy into the metric). Rank 0 prints
-ONE JSON line; see the task contract for the fields. Extra objects:
+(3 x B x 200 int64) starting in page-locked HOST memory (SURVEY section 8d counts that copy into the metric: one
+hipMemcpyAsync per batch on a copy stream one batch ahead, xfmr_rec_amd.data.PinnedBatchRing); `resident` repeats the
+timed region on batches that already lie in HBM. Rank 0 prints ONE JSON line; see the task contract for the fields.
+Extra objects:
 
-  roofline     the DOMINANT kernel of the step by GPU time (profiles/: the values-only logging pass of the fused loss,
-               loss_main_dma_kernel<128,-2>, which evaluates the six logging heads + LogitsStatistics): executed flops
-               per launch = 2 * Np * Nd * H / average launch duration from HIP events recorded on its launch stream
-               inside the timed region, against the dense bf16 MFMA peak. `kernels` lists the same for the gradient
-               pass (the logit GEMM + dQ GEMM: 4 * Np * Nd * H); `step` = executed flops of the whole step / ms_per_step;
-               fields that come from a committed rocprof run instead of this run carry a `source`.
+  roofline     the DOMINANT kernel of the step = the one with the most GPU time per step (launch duration x launches per
+               step; the top row of profiles/*_kernel_stats.md), chosen among the kernels this run times LIVE with HIP events
+               on their launch stream: the four big kernels of an encoder layer (xfmr_encoder_cfg.profile_*: fused FFN
+               forward, fused FFN backward dX chain, attention forward / backward; bound "hbm": ALGORITHMIC bytes per launch
+               / duration against 8 TB/s) and the two passes of the fused loss (xfmr_loss_cfg.profile_*; bound "mfma":
+               executed flops 2 or 4 * Np * Nd * H / duration against the dense bf16 MFMA peak). `frac` uses the duration
+               with nothing beside the kernel (steps after the timed region with everything on one stream -- what a
+               one-stream rocprofv3 trace shows); `*_overlapped` the duration inside the timed region. `kernels` lists all
+               of them; `valu` prices the logging pass against the vector pipe it is bound by; `step` = executed flops of
+               the whole step / ms_per_step; fields that come from a committed rocprof run carry a `source`.
   cpu_baseline the CPU oracle (oracle/, a restatement of the reference: 'port') timed on this host's cores on bounded
                samples: reference-faithful fp32 (the headline), bf16-autocast (the reference's default precision),
                reference-lean (train head only, GEMM-form logits) and BASELINE config 1 (ML-100K-shaped).
@@ -395,7 +400,19 @@ def main():
     lib = N.load()
     ar_events = HipEvents(max(args.steps, 1)) if world > 1 else None  # around the exchange, on the compute stream
 
-    def step(i, from_host=False, in_line=False, profile=None):
+    # The four big kernels of a layer, bracketed by HIP events on their launch stream (xfmr_encoder_cfg.profile_*) -- where
+    # each IS one kernel: the fused forms of d_model 128 in bf16 storage from 16 384 tokens (csrc/encoder.hip: ln_fused).
+    ENC_PARTS = ((N.PROF_FFN_FWD, "ffn_fwd_fused_kernel"), (N.PROF_FFN_BWD, "ffn_bwd_dx_fused_kernel"),
+                 (N.PROF_ATTN_FWD, "attn_fwd_seq_bf16_kernel"), (N.PROF_ATTN_BWD, "attn_bwd_fused_bf16_kernel"))
+    ENC_LAYER = min(1, args.layers - 1)
+    enc_parts_ok = (args.precision == "bf16" and H == 128 and B * L >= 16384 and L <= 256 and args.inter % 128 == 0
+                    and args.inter <= 1024 and not os.environ.get("XFMR_LN_UNFUSED") and not os.environ.get("XFMR_FFN_UNFUSED")
+                    and not os.environ.get("XFMR_FFN_BWD_UNFUSED") and not os.environ.get("XFMR_ATTN_BWD_SPLIT")
+                    and not os.environ.get("XFMR_ATTN_FWD_SPLIT"))
+
+    enc_flags0 = getattr(mod.model, "enc_flags", 0)
+
+    def step(i, from_host=False, in_line=False, profile=None, enc_profile=None):
         """zero_grad -> training_step -> backward -> [all-reduce] -> optimizer.step -> on_train_batch_end: the module's
         Lightning seam in Lightning's order (= Trainer.fit_step)."""
         if from_host == "inline":  # Lightning's plain batch transfer: three copies on the compute stream itself
@@ -409,6 +426,10 @@ def main():
             batch = batches[i % n_batches]
         if gstep is not None and not in_line and profile is None:
             return gstep(batch), mod.last_out  # one hipGraph launch: the same step, captured (GraphedStep)
+        mod.model.enc_profile = enc_profile  # (kernel, layer, ev0, ev1): xfmr_encoder_cfg.profile_*
+        # in line = ONE stream: the weight-gradient GEMMs too (otherwise they run beside the bracketed kernel and its
+        # duration contains what they take from it)
+        mod.model.enc_flags = (enc_flags0 | N.ENC_DW_INLINE) if in_line else enc_flags0
         opt = trainer.optimizer
         opt.zero_grad(set_to_none=True)
         mod.defer_logging = bool(overlap and not in_line)
@@ -436,7 +457,10 @@ def main():
             prof = None
             if events is not None:  # even steps time the gradient pass, odd steps the logging pass (xfmr_loss_cfg.profile_*)
                 prof = (None, events.pairs[i]) if (i & 1) else (events.pairs[i], None)
-            loss, out = step(i, from_host, profile=prof)
+            encp = None
+            if events is not None and enc_events is not None:  # one of the four encoder parts per step, layer ENC_LAYER
+                encp = (ENC_PARTS[i % 4][0], ENC_LAYER) + enc_events.pairs[i]
+            loss, out = step(i, from_host, profile=prof, enc_profile=encp)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -459,6 +483,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     ev = HipEvents(args.steps) if gstep is None else None  # (a captured step has no per-launch events: see `alone_ms`)
+    enc_events = HipEvents(args.steps) if (gstep is None and enc_parts_ok) else None
     # THE timed region: batch in page-locked host memory -> H2D of the three index tensors -> gather ->
     # encoder -> loss -> backward -> [all-reduce] -> AdamW
     for i in range(2):
@@ -472,13 +497,20 @@ def main():
     # sits on a lowest-priority stream underneath the encoder backward, so its duration there includes the time it is held
     # back -- what a one-stream rocprofv3 trace (profiles/*_kernel_stats.md) sees is this figure.
     alone_ms, alone_grad_ms = [], []
+    alone_enc = {k: [] for k, _ in ENC_PARTS}
     if (overlap or gstep is not None) and not args.lean:
         ev2 = HipEvents(12)
+        ev3 = HipEvents(12) if enc_parts_ok else None
         for i in range(12):  # even: the gradient pass, odd: the logging pass -- both on the main stream, one after the other
-            step(i, in_line=True, profile=(None, ev2.pairs[i]) if (i & 1) else (ev2.pairs[i], None))
+            encp = (ENC_PARTS[i % 4][0], ENC_LAYER) + ev3.pairs[i] if ev3 is not None else None
+            step(i, in_line=True, profile=(None, ev2.pairs[i]) if (i & 1) else (ev2.pairs[i], None), enc_profile=encp)
         torch.cuda.synchronize()
         alone_ms = ev2.elapsed_ms({i for i in range(12) if i & 1})
         alone_grad_ms = ev2.elapsed_ms({i for i in range(12) if not (i & 1)})
+        if ev3 is not None:
+            for j, (k, _) in enumerate(ENC_PARTS):
+                alone_enc[k] = ev3.elapsed_ms({i for i in range(12) if i % 4 == j})
+    mod.model.enc_profile = None
 
     stats = out["stats/device"].tolist()
     n_valid, n_query = stats[N.STAT["n_valid"]], stats[N.STAT["n_query"]]
@@ -521,10 +553,48 @@ def main():
             k |= {"avg_launch_ms_overlapped": k["avg_launch_ms"], "achieved_overlapped": k["achieved"],
                   "frac_overlapped": k["frac"]}
             k |= {"avg_launch_ms": round(a, 4), "achieved": round(tf, 2), "frac": round(tf / peak, 5), "note": note}
-    # dominant = the longer kernel with nothing beside it (profiles/*_kernel_stats.md); the timed-region durations overlap
-    log_cmp = k_log["avg_launch_ms"]
-    grad_cmp = k_grad["avg_launch_ms"]
-    dominant = k_log if (log_ms and log_cmp > grad_cmp) else k_grad
+    k_log["launches_per_step"] = k_grad["launches_per_step"] = 1
+    # The encoder's four big kernels (one launch per layer each), against HBM: ALGORITHMIC bytes per launch = what the kernel
+    # must read and write once (scripts/kernel_roofline.py holds the same table) / the launch duration.
+    Tt = B * L
+    TH, TI = Tt * H, Tt * args.inter
+    A_heads = args.heads or H // 32
+    enc_model = {
+        N.PROF_FFN_FWD: ("ffn_fwd_fused_kernel (FFN1 + GELU + FFN2 + dropout + residual + LayerNorm; writes u, g)",
+                         TH * 2 + TH * 4 + 2 * TI * 2 + 2 * TH * 4 + TH * 2, 4.0 * Tt * args.inter * H),
+        N.PROF_FFN_BWD: ("ffn_bwd_dx_fused_kernel (FFN2 dX x gelu'(u) -> dI -> FFN1 dX + LayerNorm backward)",
+                         TH * 2 + 2 * TI * 2 + TH * 4 * 3 + TH * 2, 4.0 * Tt * args.inter * H),
+        N.PROF_ATTN_FWD: ("attn_fwd_seq_bf16_kernel (one workgroup per (batch, head))",
+                          3 * TH * 2 + TH * 2 + B * A_heads * L * 4, 4.0 * B * A_heads * L * (L + 1) / 2 * 32),
+        N.PROF_ATTN_BWD: ("attn_bwd_fused_bf16_kernel (one workgroup per (batch, head): dQ, dK, dV)",
+                          2 * 3 * TH * 2 + 2 * TH * 2, 10.0 * B * A_heads * L * (L + 1) / 2 * 32),
+    }
+    enc_entries = []
+    if enc_parts_ok:
+        over = {k: (enc_events.elapsed_ms({i for i in range(args.steps) if i % 4 == j}) if enc_events is not None else [])
+                for j, (k, _) in enumerate(ENC_PARTS)}
+        for k, _short in ENC_PARTS:
+            ms_alone, ms_over = alone_enc.get(k) or [], over.get(k) or []
+            ms = ms_alone or ms_over
+            if not ms:
+                continue
+            name, nbytes, flops = enc_model[k]
+            avg = sum(ms) / len(ms)
+            e = {"kernel": name, "bound": "hbm", "achieved": round(nbytes / (avg * 1e-3) / 1e12, 3), "peak": PEAK_HBM_TBPS,
+                 "unit": "TB/s", "frac": round(nbytes / (avg * 1e-3) / 1e12 / PEAK_HBM_TBPS, 5),
+                 "avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_launch": float(nbytes),
+                 "launches_per_step": args.layers, "launches_timed": len(ms), "layer_timed": ENC_LAYER,
+                 "mfma_tflops": round(flops / (avg * 1e-3) / 1e12, 1)}
+            if ms_alone and ms_over:
+                e["avg_launch_ms_overlapped"] = round(sum(ms_over) / len(ms_over), 4)
+            enc_entries.append(e)
+    # dominant = the kernel with the most GPU time per step (launch duration with nothing beside it x launches per step):
+    # the top row of a one-stream rocprofv3 trace (profiles/*_kernel_stats.md). (The 4 x layers weight-gradient GEMMs run on
+    # a side stream in many launches and are not bracketed; their sum per step is in profiles/.)
+    cands = ([k_log] if log_ms else []) + [k_grad] + enc_entries
+    dominant = max(cands, key=lambda e: e["avg_launch_ms"] * e["launches_per_step"])
+    for e in cands:
+        e["ms_per_step"] = round(e["avg_launch_ms"] * e["launches_per_step"], 4)
     # whole step: executed flops of the encoder (fwd + bwd, valid tokens) and of the two loss passes / step time
     step_ms = elapsed / args.steps * 1e3
     enc_flops = n_valid * encoder_flops_per_token(tokens_per_seq, H, args.inter, args.layers)
@@ -535,16 +605,24 @@ def main():
     if rank == 0:
         seqs = B * world * args.steps
         roofline = dict(dominant)
+        ktraffic = static.get("kernel_hbm_bytes_per_launch") or {}
+        dom_key = next((short for k, short in ENC_PARTS if dominant["kernel"].startswith(short)), None)
+        if dom_key is None:
+            dom_key = "loss_logging_pass" if dominant is k_log else "loss_gradient_pass"
+        dom_traffic = ktraffic.get(dom_key)
+        if dom_traffic is None and dominant is k_log:
+            dom_traffic = static.get("dominant_kernel_hbm_bytes_per_launch")
         roofline |= {
-            "traffic": static.get("dominant_kernel_hbm_bytes_per_launch"),
-            "traffic_source": static.get("source") if static.get("dominant_kernel_hbm_bytes_per_launch") else None,
+            "traffic": dom_traffic,
+            "traffic_source": static.get("source") if dom_traffic else None,
             "columns": int(n_cols), "sampled_negative_columns": int(n_valid),
             "reference_form_flops_per_launch": ref_form_flops,
-            "kernels": [k_grad] + ([k_log] if log_ms else []),
+            "kernels": [k_grad] + ([k_log] if log_ms else []) + enc_entries,
             "step": {"executed_flops": step_flops, "achieved": round(step_tf, 1), "unit": "TFLOP/s", "peak": peak,
                      "frac": round(step_tf / peak, 4),
                      "note": "encoder fwd+bwd on valid tokens + both loss passes, / ms_per_step"},
-            "valu": valu_roofline(static.get("dominant_kernel_valu"), dominant["avg_launch_ms"]) if dominant is k_log else None,
+            "valu": valu_roofline(static.get("dominant_kernel_valu"), k_log["avg_launch_ms"]) if log_ms else None,
+            "valu_kernel": k_log["kernel"] if log_ms else None,
             "gemm_family_tbps": static.get("gemm_family_tbps"),
             "gemm_family_tbps_source": static.get("source") if static.get("gemm_family_tbps") else None,
             "hbm_peak_tbps": PEAK_HBM_TBPS,

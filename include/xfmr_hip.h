@@ -174,7 +174,16 @@ typedef struct xfmr_encoder_cfg {
                          enqueued and records the event behind them: the data-parallel all-reduce of that half can run
                          underneath the lower layers' backward (xfmr_rec_amd/distributed.py). The rest of the buffer is
                          complete when the call's last launch has run, as always. Ignored by xfmr_encoder_fwd.        */
+  /* Measurement (bench.py, like xfmr_loss_cfg.profile_*): two hipEvent_t recorded on `stream` in front of and behind ONE
+     part of the encoder -- the kernel(s) XFMR_PROF_* names, of layer `profile_layer` -- by whichever of xfmr_encoder_fwd /
+     xfmr_encoder_bwd launches it. profile_kernel 0 or a null event: nothing is recorded.                               */
+  int32_t profile_kernel;
+  int32_t profile_layer;
+  void* profile_events[2];
 } xfmr_encoder_cfg;
+/* xfmr_encoder_cfg.profile_kernel: the FFN forward (one kernel in the fused form: FFN1 + GELU + FFN2 + dropout + residual +
+ * LayerNorm), the FFN backward's dX chain (one kernel in the fused form), the attention forward, the attention backward. */
+enum { XFMR_PROF_NONE = 0, XFMR_PROF_FFN_FWD = 1, XFMR_PROF_FFN_BWD = 2, XFMR_PROF_ATTN_FWD = 3, XFMR_PROF_ATTN_BWD = 4 };
 /* Element offset at which the early-finished upper half of the flat gradient begins (0 for a one-layer encoder: the
  * event then marks the whole buffer, recorded behind the last launch). */
 int64_t xfmr_param_half_offset(const xfmr_encoder_cfg* cfg);

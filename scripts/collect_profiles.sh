@@ -32,4 +32,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
   python3 "$ROOT/bench.py" --steps 10 --warmup 3 --spinup-steps 0 --no-cpu-baseline --overlap off --graph off --batch 32 > "$OUT/trace_b32.log" 2>&1
 # SQ counters of the same kernels (instruction mix, wait / stall shares, matrix-core busy cycles): two more passes
 "$ROOT/scripts/pmc_loss_passes.sh" "$TAG"
+# HBM traffic of EVERY kernel of the step (FETCH_SIZE / WRITE_SIZE / L2 hits, separate passes): the dominant kernel's `traffic`
+"$ROOT/scripts/pmc_traffic.sh" "$TAG"
 echo done > "$OUT/DONE"

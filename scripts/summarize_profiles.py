@@ -94,6 +94,26 @@ def main():
         (prof / f"{a.tag}_loss_traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
         if "logging_pass" in traffic:
             static["dominant_kernel_hbm_bytes_per_launch"] = traffic["logging_pass"]["hbm_bytes_per_launch"]
+    # per-kernel HBM traffic of the whole step (scripts/pmc_traffic.sh): bytes per launch, FETCH_SIZE doubled + WRITE_SIZE
+    sf = find(src / "pmc_fetch" / "**" / "*counter_collection.csv")
+    sw = find(src / "pmc_write" / "**" / "*counter_collection.csv")
+    if sf and sw:
+        per = {}
+        for key, needle in (("ffn_fwd_fused_kernel", "ffn_fwd_fused_kernel"), ("ffn_bwd_dx_fused_kernel", "ffn_bwd_dx_fused_kernel"),
+                            ("attn_fwd_seq_bf16_kernel", "attn_fwd_seq_bf16_kernel"),
+                            ("attn_bwd_fused_bf16_kernel", "attn_bwd_fused_bf16_kernel"),
+                            ("loss_logging_pass", "loss_main_dma_kernel<128, -3>"),
+                            ("loss_gradient_pass", "loss_main_dma_kernel<128, 7>")):
+            fk, wk = pmc_mean(sf, "FETCH_SIZE", needle), pmc_mean(sw, "WRITE_SIZE", needle)
+            if fk is not None and wk is not None:
+                per[key] = (2 * fk + wk) * 1024
+        if per:
+            static["kernel_hbm_bytes_per_launch"] = per
+            static["kernel_hbm_bytes_source"] = (f"profiles/{a.tag}_step_traffic.md (scripts/pmc_traffic.sh {a.tag}: rocprofv3 --pmc "
+                                                 "FETCH_SIZE | WRITE_SIZE over two bench steps, one stream; FETCH_SIZE doubled)")
+        md = subprocess.run([sys.executable, str(ROOT / "scripts" / "summarize_traffic.py"), a.tag], capture_output=True, text=True)
+        if md.returncode == 0 and md.stdout:
+            (prof / f"{a.tag}_step_traffic.md").write_text(md.stdout)
     # GEMM family: compulsory bytes / GPU time of every gemm_kernel launch of one step (scripts/kernel_roofline.py table)
     stats = prof / f"{a.tag}_kernel_stats.csv"
     if stats.exists():

@@ -363,6 +363,53 @@ def test_grouped_weight_gradient_launches_give_the_same_bits(ops, B, L, H, A, I)
         assert torch.equal(run(cfg), one_each)
 
 
+def test_encoder_profile_events_bracket_the_named_kernel_of_the_named_layer(ops):
+    """xfmr_encoder_cfg.profile_kernel / profile_layer / profile_events (bench.py's live per-kernel durations): the pair is
+    recorded around that part of that layer by the call that launches it -- elapsed time > 0 and plausible (a fused FFN
+    forward of 25 600 tokens takes tens of microseconds, not the whole forward) --, results are untouched, and an unknown
+    kernel id is refused."""
+    import ctypes
+
+    from xfmr_rec_amd import _native as N
+
+    lib = N.load()
+    B, L, H, A, V, I, nL = 128, 200, 128, 4, 500, 512, 3
+    g = torch.Generator().manual_seed(3)
+    table = _unit_table(V, H, 5).to(DEV)
+    kw = dict(batch=B, seq_len=L, hidden=H, heads=A, inter=I, layers=nL, max_pos=L, precision="bf16",
+              hidden_dropout=0.1, attn_dropout=0.1, seed=9)
+    cfg0 = ops.make_encoder_cfg(**kw)
+    flat = (0.05 * torch.randn(lib.xfmr_param_count(ctypes.byref(cfg0)), generator=g)).to(DEV)
+    idx = torch.randint(1, V + 1, (B, L), generator=g).to(DEV)
+    d_out = torch.randn(B, L, H, generator=g).to(DEV)
+
+    def run(c):
+        tok, key_mask, acts = ops.encoder_fwd(c, flat, idx, table)
+        return tok, ops.encoder_bwd(c, flat, d_out.clone(), key_mask, acts)
+
+    tok0, g0 = run(cfg0)
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    N.check(lib.xfmr_event_create(ctypes.byref(a), 1), "xfmr_event_create")
+    N.check(lib.xfmr_event_create(ctypes.byref(b), 1), "xfmr_event_create")
+    whole = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for kind in (N.PROF_FFN_FWD, N.PROF_FFN_BWD, N.PROF_ATTN_FWD, N.PROF_ATTN_BWD):
+        cfg = ops.make_encoder_cfg(**kw, profile=(kind, 1, a.value, b.value))
+        run(cfg)  # warm
+        whole[0].record()
+        tok, gr = run(cfg)
+        whole[1].record()
+        torch.cuda.synchronize()
+        ms = ctypes.c_float()
+        assert lib.xfmr_event_elapsed_ms(a.value, b.value, ctypes.byref(ms)) == 0
+        assert 0.002 < ms.value < 0.5 * whole[0].elapsed_time(whole[1]), (kind, ms.value)
+        assert torch.equal(tok, tok0) and torch.equal(gr, g0)
+    bad = ops.make_encoder_cfg(**kw, profile=(7, 0, a.value, b.value))
+    with pytest.raises(Exception):
+        run(bad)
+    lib.xfmr_event_destroy(a.value)
+    lib.xfmr_event_destroy(b.value)
+
+
 @pytest.mark.parametrize("head,heads", [("InfoNCELoss", True), ("PairwiseLogisticLoss", 2), ("AlignmentContrastiveLoss", False)])
 def test_loss_in_two_halves_equals_the_single_call(ops, head, heads):
     """xfmr_sampled_loss_prepare (query compaction, multiplicities, distinct negatives: needs the key mask and the index

@@ -104,6 +104,12 @@ bool mixed_storage(const xfmr_encoder_cfg* c) {
 // LayerNorm-fused GEMM epilogues plus I a multiple of its chunk widths. The forward and the backward of one step must
 // agree on it (f1 holds u after the fused kernel, gelu'(u) after the two-kernel form): a pure function of the
 // configuration, its XFMR_ENC_*_UNFUSED flag bits included -- both calls of a step get the same cfg.
+// measurement events of the call's configuration (xfmr_encoder_cfg.profile_*): event `which` of the pair, on `st`, when
+// this is the part and the layer the caller named
+int prof(const xfmr_encoder_cfg* c, int kind, int layer, int which, hipStream_t st) {
+  if (c->profile_kernel != kind || c->profile_layer != layer || !c->profile_events[which]) return XFMR_OK;
+  return hipEventRecord((hipEvent_t)c->profile_events[which], st) == hipSuccess ? XFMR_OK : XFMR_EHIP;
+}
 bool ln_fused(const xfmr_encoder_cfg* c, int64_t T) {
   // out-proj / FFN2 GEMM + LayerNorm as one kernel: its 64 x 128 tiles are T / 64 workgroups -- below one per CU
   // (T < 16 384) the two-kernel form with 64 x 64 tiles is faster (batch 32: -1.5 % fused; batch 128: +0.9 %; 512: +1.8 %)
@@ -206,6 +212,7 @@ int check_cfg(const xfmr_encoder_cfg* c) {
   if ((c->hidden != c->heads * 32 && c->hidden != c->heads * 64) || (c->inter & 3)) return XFMR_EUNSUPPORTED;
   if (c->precision != XFMR_PREC_F32 && c->precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   if (c->flags & ~(uint32_t)XFMR_ENC_FLAGS_ALL) return XFMR_EINVAL;  // unknown flag bits
+  if (c->profile_kernel < XFMR_PROF_NONE || c->profile_kernel > XFMR_PROF_ATTN_BWD) return XFMR_EINVAL;
   return XFMR_OK;
 }
 
@@ -346,8 +353,10 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     float* out = (i == cfg->layers - 1) ? tok : l.x2;
     XF_TRY(xf_linear_fwd_ex(xg, W(p.wqkv), params + p.bqkv, l.qkv, T, 3 * H, H, XFMR_EPI_BIAS, nullptr, nullptr,
                             0.f, 0, 0, prec, (mix ? XF_S16_C : 0) | sA | sB, st));
+    XF_TRY(prof(cfg, XFMR_PROF_ATTN_FWD, i, 0, st));
     XF_TRY(xf_attn_fwd_ex(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, sd, site_attn(i), prec,
                           mix, causal, st));
+    XF_TRY(prof(cfg, XFMR_PROF_ATTN_FWD, i, 1, st));
     if (fuse_ln) {  // LayerNorm in the GEMM epilogue (the tile spans whole rows)
       XF_TRY(xf_linear_ln_fwd_ex(l.ctx, W(p.wo), params + p.bo, l.pre1, T, H, H, x, cfg->hidden_dropout, sd,
                                  site_out(i), params + p.ln1g, params + p.ln1b, cfg->ln_eps, l.x1, l.x1b, l.mean1,
@@ -359,10 +368,12 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
                                  l.rstd1, T, H, cfg->ln_eps, st));
     }
     const bool last = i == cfg->layers - 1;
+    XF_TRY(prof(cfg, XFMR_PROF_FFN_FWD, i, 0, st));
     if (fuse_ffn) {  // FFN1 -> GELU -> FFN2 -> dropout + residual + LayerNorm in one kernel; f1 <- the PRE-activation, g <- gelu
       XF_TRY(xf_ffn_fwd_fused_ex(l.x1b, W(p.w1), params + p.b1, W(p.w2), params + p.b2, l.f1, l.g, l.pre2, T, H, I, l.x1,
                                  cfg->hidden_dropout, sd, site_ffn(i), params + p.ln2g, params + p.ln2b,
                                  cfg->ln_eps, out, last ? nullptr : l.x2b, l.mean2, l.rstd2, st));
+      XF_TRY(prof(cfg, XFMR_PROF_FFN_FWD, i, 1, st));
       x = out;
       xg = mix ? (const void*)l.x2b : (const void*)out;
       continue;
@@ -380,6 +391,7 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
       XF_TRY(xf_layernorm_fwd_ex(l.pre2, params + p.ln2g, params + p.ln2b, out, (mix && !last) ? l.x2b : nullptr,
                                  l.mean2, l.rstd2, T, H, cfg->ln_eps, st));
     }
+    XF_TRY(prof(cfg, XFMR_PROF_FFN_FWD, i, 1, st));
     x = out;
     xg = mix ? (const void*)l.x2b : (const void*)out;
   }
@@ -497,6 +509,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       seg(r.w2, grads + p.w2, splits, (int64_t)H * I, (int64_t)H * I);
     }
     const void* const dlin_ffn = dlin;
+    XF_TRY(prof(cfg, XFMR_PROF_FFN_BWD, i, 0, st));  // (in the unfused forms: FFN2 dX ... LayerNorm 1 backward on `st`)
     if (fuse_ffn_bwd) {  // FFN2 dX * gelu'(u) -> dI -> FFN1 dX (+= d(pre2)) -> LayerNorm 1 backward in one kernel
       XF_TRY(xf_ffn_bwd_dx_fused_ex(dlin, W(p.w2), l.f1, W(p.w1), dI, T, H, I, a.dA, l.pre1, l.mean1, l.rstd1,
                                     params + p.ln1g, cfg->hidden_dropout, sd, site_out(i), dX, dLinO, r.ln1,
@@ -523,6 +536,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
                                    mix, nullptr, nullptr, nullptr, T, H, off,
                                    xf_make_dropout(cfg->hidden_dropout, sd, site_out(i)), r.ln1, st, &blocks));
     }
+    XF_TRY(prof(cfg, XFMR_PROF_FFN_BWD, i, 1, st));
     seg(r.ln1, grads + p.ln1g, blocks, H, 3 * H);
     seg(r.ln1 + H, grads + p.ln1b, blocks, H, 3 * H);
     seg(r.ln1 + 2 * H, grads + p.bo, blocks, H, 3 * H);
@@ -532,8 +546,10 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
       seg(r.wo, grads + p.wo, splits, (int64_t)H * H, (int64_t)H * H);
     }
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
+    XF_TRY(prof(cfg, XFMR_PROF_ATTN_BWD, i, 0, st));
     XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, dQKV, B, L, A, H, cfg->attn_dropout, sd,
                           site_attn(i), prec, mix, causal, st));
+    XF_TRY(prof(cfg, XFMR_PROF_ATTN_BWD, i, 1, st));
     if (group_dw) {
       const XfDwItem items[4] = {
           {dlin_ffn, l.g, (int32_t)H, (int32_t)I, r.w2, nullptr, &splits_w2},

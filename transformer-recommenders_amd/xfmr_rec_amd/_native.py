@@ -51,7 +51,11 @@ class EncoderCfg(C.Structure):
         ("flags", C.c_uint32), ("seed", C.c_uint64),
         ("step_device", C.c_void_p), ("embed_event", C.c_void_p), ("context", C.c_void_p),
         ("grads_half_event", C.c_void_p),
+        ("profile_kernel", C.c_int32), ("profile_layer", C.c_int32), ("profile_events", C.c_void_p * 2),
     ]
+
+
+PROF_FFN_FWD, PROF_FFN_BWD, PROF_ATTN_FWD, PROF_ATTN_BWD = 1, 2, 3, 4
 
 
 class LossCfg(C.Structure):

@@ -328,6 +328,7 @@ class RecommenderModel(torch.nn.Module):
             context=ctx.handle if ctx is not None else None,
             grads_half_event=getattr(self, "grads_half_event", None),  # set by distributed.HalvedAllReduce
             extra_flags=getattr(self, "enc_flags", 0),  # e.g. ENC_DW_SIDE_ANY inside a captured step (GraphedStep)
+            profile=getattr(self, "enc_profile", None) if train else None,  # (kernel, layer, ev0, ev1): bench.py
         )
 
     def _encode_tokens(self, item_idx=None, item_embeds=None, embed_event=None):

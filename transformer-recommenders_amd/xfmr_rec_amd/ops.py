@@ -388,10 +388,11 @@ def encoder_flags_from_env() -> int:
 
 def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, precision, ln_eps=1e-12,
                      hidden_dropout=0.0, attn_dropout=0.0, seed=0, causal=True, flags=None, step_device=None,
-                     embed_event=None, context=None, grads_half_event=None, extra_flags=0) -> N.EncoderCfg:
+                     embed_event=None, context=None, grads_half_event=None, extra_flags=0, profile=None) -> N.EncoderCfg:
     """``step_device``: a uint32 device tensor (or pointer) mixed into the dropout stream on the device;
     ``embed_event``: a hipEvent_t handle the forward records once the key mask exists; ``context``: an
-    ``xfmr_context`` handle (side stream of the backward's weight-gradient GEMMs)."""
+    ``xfmr_context`` handle (side stream of the backward's weight-gradient GEMMs); ``profile``: (N.PROF_*, layer,
+    event0, event1) -- HIP events recorded around that part of the encoder (measurement)."""
     f = encoder_flags_from_env() if flags is None else int(flags)
     f |= int(extra_flags)
     if not causal:
@@ -404,6 +405,8 @@ def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, p
         precision=N.precision_id(precision), ln_eps=ln_eps, hidden_dropout=hidden_dropout,
         attn_dropout=attn_dropout, flags=f, seed=seed, step_device=step_device, embed_event=embed_event,
         context=context, grads_half_event=grads_half_event,
+        profile_kernel=int(profile[0]) if profile else 0, profile_layer=int(profile[1]) if profile else 0,
+        profile_events=(C.c_void_p * 2)(profile[2], profile[3]) if profile else (C.c_void_p * 2)(None, None),
     )
 
 
