@@ -451,34 +451,39 @@ __device__ __forceinline__ float xf_rcp(float x) { return __builtin_amdgcn_rcpf(
 // (|error| <= 1.5e-7, i.e. fp32 rounding level; measured against fp64: gelu 4.6e-7, gelu' 3.0e-7 absolute -- torch's
 // own fp32 gelu is 1.2e-6 off fp64): one v_rcp, one v_exp and eight fma, branch-free, instead of libm's erff. The
 // GELU epilogues of the two FFN GEMMs evaluate this on T x I elements per layer and were VALU-bound on erff.
-// e_out = exp(-x^2 / 2), shared with the derivative's Gaussian term.
-__device__ __forceinline__ float xf_erf_sqrt2(float x, float& e_out) {  // erf(x / sqrt(2))
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = xf_rcp(fmaf(0.3275911f, z, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
+// h(x) = 0.5 - 0.5 erfc(|x| / sqrt 2) = Phi(|x|) - 0.5, from the same A-S 7.1.26 terms with the 1 / sqrt 2 folded into the
+// rational's constant and the 0.5 into the polynomial: 0.5 erfc(z) = (0.5 a1 t + ...) t exp(-z^2), t = 1 / (1 + p z),
+// z = |x| / sqrt 2. e_out = exp(-x^2 / 2). Then gelu(x) = x Phi(x) = 0.5 x + |x| h(x) and Phi(x) = 0.5 + copysign(h, x):
+// two instructions fewer per element than erf -> 1 + erf -> 0.5 x (...), no maximum (its operand would be canonicalised
+// first) -- round 3: the fused FFN kernels are bound by their vector instructions.
+__device__ __forceinline__ float xf_phi_minus_half(float ax, float x, float& e_out) {  // ax = |x|
+  const float t = xf_rcp(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
   p *= t;
-  const float e = xf_exp2(-(z * z) * 1.4426950408889634f);
+  const float e = xf_exp2((x * x) * (-0.5f * 1.4426950408889634f));
   e_out = e;
-  return copysignf(fmaf(-p, e, 1.f), x);
+  return fmaf(-p, e, 0.5f);
 }
 __device__ __forceinline__ float xf_gelu(float x) {
   float e;
-  return 0.5f * x * (1.f + xf_erf_sqrt2(x, e));
+  const float ax = fabsf(x);
+  return fmaf(ax, xf_phi_minus_half(ax, x, e), 0.5f * x);
 }
-// gelu(x) and gelu'(x) = Phi(x) + x phi(x) from ONE erf / exp evaluation
+// gelu(x) and gelu'(x) = Phi(x) + x phi(x) from ONE evaluation
 __device__ __forceinline__ float xf_gelu_both(float x, float& grad) {
   float e;
-  const float cdf = 0.5f * (1.f + xf_erf_sqrt2(x, e));
-  grad = fmaf(x * 0.3989422804014327f, e, cdf);
-  return x * cdf;
+  const float ax = fabsf(x);
+  const float h = xf_phi_minus_half(ax, x, e);
+  grad = fmaf(x * 0.3989422804014327f, e, 0.5f + copysignf(h, x));
+  return fmaf(ax, h, 0.5f * x);
 }
 __device__ __forceinline__ float xf_gelu_grad(float x) {
   float e;
-  const float er = xf_erf_sqrt2(x, e);
-  return fmaf(x * 0.3989422804014327f, e, 0.5f * (1.f + er));
+  const float h = xf_phi_minus_half(fabsf(x), x, e);
+  return fmaf(x * 0.3989422804014327f, e, 0.5f + copysignf(h, x));
 }
 __device__ __forceinline__ float xf_softplus(float x) {
   return fmaxf(x, 0.f) + 0.6931471805599453f * xf_log2(1.f + xf_exp2(-fabsf(x) * 1.4426950408889634f));
