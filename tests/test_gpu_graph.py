@@ -98,12 +98,12 @@ def test_device_step_counter_changes_the_dropout_mask_and_matches_adamw_by_value
     assert not torch.equal(tok0, tok1)
 
 
-@pytest.mark.parametrize("mode", ["on", "auto"])
-def test_fit_with_graph_runs_the_same_training_as_eager_steps(X, mode):
+@pytest.mark.parametrize("mode,host", [("on", False), ("auto", False), ("on", True)])
+def test_fit_with_graph_runs_the_same_training_as_eager_steps(X, mode, host):
     """Trainer.fit(graph=...): three eager steps, then (mode "on") every step a replay of ONE captured hipGraph, or (mode
     "auto") timed eager steps, timed replays and the faster form for the rest. Whatever ran, the sequence of steps is the
     eager one with the device-side step counter: same losses, same parameters, bit for bit; a batch of another shape
-    takes the eager step."""
+    takes the eager step; batches handed over from host memory (the ring's device slots) replay the same."""
     eager, batches = _setup(X)
     eager.model.use_device_step(True)
     tr_e = X.Trainer(eager)
@@ -114,6 +114,8 @@ def test_fit_with_graph_runs_the_same_training_as_eager_steps(X, mode):
     short = {k: v[:5].clone() for k, v in batches[2].items()}  # a short last batch
     seq.append(short)
     want = [float(tr_e.fit_step(b)) for b in seq]
+    if host:  # batches arrive in host memory: PinnedBatchRing slots feed the captured buffers
+        seq = [{k: v.cpu() for k, v in b.items()} for b in seq]
     got = tr_g.fit(seq, graph=mode, graph_probe_steps=4)
     assert got == want
     torch.cuda.synchronize()
