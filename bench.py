@@ -83,7 +83,7 @@ def parse(argv=None):
     ap.add_argument("--heads", type=int, default=0, help="attention heads (default hidden/32: head size 32)")
     ap.add_argument("--negatives", default="in_batch", choices=["in_batch", "catalogue"],
                     help="catalogue = full-catalogue softmax (BASELINE config 4; SURVEY F9)")
-    ap.add_argument("--preset", default=None, choices=["config2", "config3", "config4", "config5", "reference-default"],
+    ap.add_argument("--preset", default=None, choices=["config1", "config2", "config3", "config4", "config5", "reference-default"],
                     help="the other BASELINE.json configs as sanity workloads (the bench line is config2, the default)")
     ap.add_argument("--spinup-steps", type=int, default=300,
                     help="untimed steps of the same workload BEFORE the --warmup steps (same count on every rank): a "
@@ -93,6 +93,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=7.0, help="time budget of EACH cpu_baseline variant")
     args = ap.parse_args(argv)
     presets = {
+        # BASELINE configs[0]: MovieLens-100K-shaped, the reference's CPU-runnable case (the cpu_baseline's last variant)
+        "config1": dict(items=1682, seq_len=50, hidden=64, layers=2, inter=256, batch=64),
         "config2": {},
         "config3": dict(loss="PairwiseLogisticLoss"),
         "config4": dict(items=27278, hidden=256, layers=6, inter=1024, batch=64, negatives="catalogue"),

@@ -20,3 +20,5 @@ run config4 --preset config4
 run config4_inbatch --items 27278 --hidden 256 --layers 6 --inter 1024 --batch 64
 run config5 --preset config5
 run refdefault --preset reference-default
+run config1 --preset config1
+run config1_eager --preset config1 --graph off
