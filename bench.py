@@ -149,7 +149,10 @@ def dry_run(args) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ok = bool((flat == world * (world + 1) / 2).all())
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "dry": True, "n_gpus": world, "allreduce_ok": ok, "value": None}), flush=True)
+        print(json.dumps({"metric": METRIC, "dry": True, "n_gpus": world, "allreduce_ok": ok, "value": None, "scaling": "weak",
+                          "exchange": {"backend": "gloo (dry run; the GPU run uses torch.distributed 'nccl' = RCCL)",
+                                       "rccl_world": world, "message_bytes": int(flat.numel()) * 4,
+                                       "form": "one all-reduce after the backward"}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -383,6 +383,14 @@ enum {
                                    must read 0) -- the caller did it, e.g. on another stream underneath the encoder
                                    forward (52 MB at T = 102 400) -- so the call skips its memset                  */
 };
+/* Launch-plan overrides inside `flags` (0 = the library's own plan, which depends on the number of 128-query blocks):
+ * bits 8-15 the column-split count of the plan (the logging pass's), bits 16-23 the gradient pass's (clamped to the
+ * former). Results do not depend on the plan beyond fp32 summation order; the parity tests walk several plans in one
+ * process with these (tests/test_gpu_fullsize.py). Workspaces must be sized with the *_workspace_cfg functions. */
+#define XFMR_LOSS_NSPLIT(n) (((uint32_t)(n) & 0xffu) << 8)
+#define XFMR_LOSS_NSPLIT_GRAD(n) (((uint32_t)(n) & 0xffu) << 16)
+#define XFMR_LOSS_NSPLIT_OF(flags) (((flags) >> 8) & 0xffu)
+#define XFMR_LOSS_NSPLIT_GRAD_OF(flags) (((flags) >> 16) & 0xffu)
 size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows);            /* num_hard_negatives == 0 */
 size_t xfmr_sampled_loss_workspace_cfg(const xfmr_loss_cfg* cfg, int64_t positions, int32_t H, int64_t n_rows);
 int xfmr_sampled_loss(const xfmr_loss_cfg* cfg, const float* tok, const uint8_t* key_mask, const int64_t* pos_idx,

@@ -11,9 +11,22 @@ import torch
 #   fp32 MFMA path vs fp32 oracle: values |d| <= 1e-4 * max(1,|x|); gradients rel-L2 <= 1e-4
 #   bf16 MFMA path vs fp32 oracle: loss rel <= 1e-2; gradients rel-L2 <= 3e-2
 TOL = {
-    "fp32": dict(val=1e-4, grad_l2=2e-4, loss_rel=1e-4),
+    "fp32": dict(val=1e-4, grad_l2=1e-4, loss_rel=1e-4),
     "bf16": dict(val=3e-2, grad_l2=3e-2, loss_rel=1e-2),
 }
+
+
+def loss_tol(prec: str, want: float, *, flips: bool) -> float:
+    """Absolute limit for a loss value. `flips`: the value goes through a DISCONTINUOUS selection that bf16 logits can
+    decide differently from fp32 ones -- the false-negative mask `logits < pos_logit` (losses.py:289-292) or the top-k
+    of hard negatives (:295-330); SURVEY section 7 measured up to 8.5e-3 for CPU bf16-autocast against fp32 on
+    PairwiseHinge, so those cases (and only those, and only in bf16) get 3x the section-8(d) limit."""
+    return TOL[prec]["loss_rel"] * max(1.0, abs(want)) * (3 if (prec == "bf16" and flips) else 1)
+
+
+def grad_tol(prec: str, *, flips: bool) -> float:
+    """rel-L2 limit for a gradient; `flips` as in :func:`loss_tol`."""
+    return TOL[prec]["grad_l2"] * (3 if (prec == "bf16" and flips) else 1)
 
 
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:

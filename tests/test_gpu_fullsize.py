@@ -16,7 +16,7 @@ closed forms (a dense matmul / indexing), never as the thing under test.
 import pytest
 import torch
 
-from helpers import TOL, rel_l2
+from helpers import TOL, grad_tol, loss_tol, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -434,3 +434,109 @@ def test_loss_in_two_halves_equals_the_single_call(ops, head, heads):
     assert torch.equal(l0, l1) and torch.allclose(s0, s1, rtol=0, atol=0, equal_nan=True)
     assert (d0 is None and d1 is None) or torch.equal(d0, d1)
 
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The launch plan the HEADLINE is measured with: BASELINE config 2 at the benchmark batch, 512 x 200 = 102 400 positions =
+# 800 blocks of 128 queries. From 512 query blocks on, loss.hip switches plans: the logging pass runs >= 4 column splits and
+# the gradient pass ONE split that finishes its rows inside the kernel (no partial dQ, no gradient work in the combine
+# kernel). Checked here against the CPU oracle at that size: (1) a sample of query rows in the REFERENCE's form -- their
+# [rowdot | q E_neg^T] logits against all 102 400 sampled negatives through the unmodified heads with autograd
+# (oracle/lean.py: rows_reference_form) -> the rows of d_tok; (2) all seven sums and the statistics in the item-weighted
+# restatement (oracle/lean.py: heads_by_item, pinned against the materialised oracle by tests/test_oracle_golden.py); (3)
+# other plans (1 and 5 column splits for both passes, through xfmr_loss_cfg.flags) give the same sums and gradient to
+# summation order.
+# ------------------------------------------------------------------------------------------------------------------
+def _b512_inputs(lengths: str, H=128, V=3883, B=512, L=200, seed=61):
+    g = torch.Generator().manual_seed(seed)
+    table = _unit_table(V, H, 1234)
+    tok = torch.randn(B * L, H, generator=g)
+    if lengths == "dense":
+        lens = torch.full((B,), L)
+    else:  # MovieLens-like: len = clip(round(exp(N(4.35, 1))), 16, L), right-padded
+        lens = torch.exp(4.35 + torch.randn(B, generator=g)).round().clamp(16, L).long()
+    mask = (torch.arange(L)[None, :] < lens[:, None]).reshape(-1)
+    pos = torch.randint(1, V + 1, (B * L,), generator=g)
+    neg = torch.randint(1, V + 1, (B * L,), generator=g)
+    pos[torch.rand(B * L, generator=g) < 0.01] = 0  # valid positions whose positive is padding (models.py:413)
+    pos[~mask] = 0
+    neg[~mask] = 0
+    return table, tok, mask, pos, neg
+
+
+_ORACLE_SUMS: dict = {}
+
+
+def _oracle_sums(key, tok, mask, pos, neg, table, **cfg):
+    from oracle import lean
+
+    if key not in _ORACLE_SUMS:
+        qsel = mask & (pos != 0)
+        _ORACLE_SUMS[key] = lean.heads_by_item(tok[qsel], pos[qsel], neg[mask], table, **cfg)
+    return _ORACLE_SUMS[key]
+
+
+def _check_against_oracle(ops, prec, lengths, H, V, B, L, heads, plans, seed):
+    from oracle import lean
+    from oracle import losses as OL
+    from xfmr_rec_amd import _native as N
+
+    table, tok, mask, pos, neg = _b512_inputs(lengths, H=H, V=V, B=B, L=L, seed=seed)
+    tdev = table.to(DEV)
+    rn, tb = ops.table_prepare(tdev)
+    dev = dict(tok=tok.to(DEV), mask=mask.to(torch.uint8).to(DEV), pos=pos.to(DEV), neg=neg.to(DEV))
+    qsel = mask & (pos != 0)
+    assert (int(tok.shape[0]) + 127) // 128 >= 512  # the plan under test: >= 512 query blocks
+    g = torch.Generator().manual_seed(3)
+    qidx = qsel.nonzero().flatten()
+    rows = qidx[torch.randperm(qidx.numel(), generator=g)[:512]]
+
+    def run(head, **plan):
+        return ops.sampled_loss(dev["tok"], dev["mask"], dev["pos"], dev["neg"], tdev, rn, train_head=head, all_heads=True,
+                                precision=prec, table_bf16=tb if prec == "bf16" else None, **plan)
+
+    want = _oracle_sums((lengths, H, V, B, L, seed), tok, mask, pos, neg, table)
+    for head in heads:
+        l0, s0, d0 = run(head)
+        # (1) sampled rows, reference form
+        _loss_rows, g_rows = lean.rows_reference_form(head, tok[rows], pos[rows], neg[mask], table)
+        e = rel_l2(d0[rows.to(DEV)], g_rows)
+        assert e <= grad_tol(prec, flips=True), (head, prec, e)
+        assert float(d0[(~qsel).to(DEV)].abs().max()) == 0.0  # rows that are not queries read 0
+        # (2) every sum + statistics of the same call
+        for i, k in enumerate(OL.LOSS_KINDS):
+            w = want[f"loss/{k}"]
+            assert abs(float(l0[i]) - w) <= loss_tol(prec, w, flips=True), (head, k, float(l0[i]), w)
+        st = s0.tolist()
+        assert int(st[N.STAT["n_valid"]]) == int(mask.sum()) and int(st[N.STAT["n_query"]]) == int(qsel.sum())
+        assert int(st[N.STAT["neg_distinct"]]) == int(torch.unique(neg[mask]).numel())
+        vt = TOL[prec]["val"]
+        for name in ("neg_density", "pos_mean", "pos_std", "pos_min", "pos_max", "neg_mean", "neg_std", "neg_min", "neg_max"):
+            ok = name.replace("_", "/", 1)
+            w = want[f"logits/{ok}"]
+            assert abs(st[N.STAT[name]] - w) <= vt * max(1.0, abs(w)), (head, name, st[N.STAT[name]], w)
+        assert abs(st[N.STAT["neg_count"]] - want["logits/neg/count"]) <= (2e-3 if prec == "bf16" else 1e-5) * want["logits/neg/count"]
+        # (3) other plans: same sums, same gradient (fp32 summation order only)
+        for ns, nsg in plans:
+            l1, s1, d1 = run(head, nsplit=ns, nsplit_grad=nsg)
+            for i in range(len(OL.LOSS_KINDS)):
+                assert float(l1[i]) == pytest.approx(float(l0[i]), rel=1e-6, abs=1e-6), (head, ns, nsg, i)
+            assert rel_l2(d1, d0) <= 1e-6, (head, ns, nsg)
+            assert torch.allclose(s1, s0, rtol=1e-6, atol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("lengths", ["dense", "ragged"])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_config2_batch512_loss_plan_vs_oracle(ops, prec, lengths):
+    """BASELINE config 2 at the benchmark batch (the plan `bench.py` runs): InfoNCE (sampled softmax), BPR, CCL."""
+    _check_against_oracle(ops, prec, lengths, H=128, V=3883, B=512, L=200,
+                          heads=("InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"),
+                          plans=((1, 1), (5, 5), (5, 2)), seed=61)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_h256_loss_with_512_query_blocks_vs_oracle(ops, prec):
+    """H = 256 (configs 4 / 5's width) with >= 512 query blocks: 330 x 200 = 66 000 positions (516 blocks), ragged."""
+    _check_against_oracle(ops, prec, "ragged", H=256, V=1500, B=330, L=200,
+                          heads=("InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"),
+                          plans=((1, 1), (5, 5)), seed=67)

@@ -125,3 +125,91 @@ def test_fit_with_graph_runs_the_same_training_as_eager_steps(X, mode, host):
         assert tr_g.graph_choice == "graph"
     else:
         assert tr_g.graph_choice in ("graph", "eager") and set(tr_g.graph_probe) == {"eager_ms", "graph_ms"}
+
+
+def test_capture_after_default_stream_eager_steps_is_refused_with_a_python_error(X):
+    """torch's capture protocol: eager steps on the device's DEFAULT stream bind autograd's AccumulateGrad node
+    of `flat` to that stream; a capture on a side stream afterwards faulted in round 3. Now (1) the step keeps only
+    DETACHED tensors past its end -- no autograd graph survives into the next step --, and (2) a Trainer that has run
+    default-stream steps refuses `fit(graph=...)` / GraphedStep with a clear RuntimeError instead of attempting the capture.
+    Steps on a side stream, or a fresh Trainer, capture as before."""
+    mod, batches = _setup(X)
+    tr = X.Trainer(mod)
+    loss = tr.fit_step(batches[0])  # default stream
+    assert tr.default_stream_steps == 1
+    assert loss.grad_fn is None and all(not (torch.is_tensor(v) and v.requires_grad) for v in mod.last_out.values())
+    with pytest.raises(RuntimeError, match="default stream"):
+        tr.fit([batches[1], batches[2]], graph="on")
+    with pytest.raises(RuntimeError, match="default stream"):
+        X.GraphedStep(tr, batches[0])
+    assert tr.fit([batches[1]], graph="off")  # eager steps go on
+    # the same module under a NEW trainer whose eager steps run on a side stream: the capture is taken
+    mod2, _ = _setup(X)
+    tr2 = X.Trainer(mod2)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tr2.fit_step(batches[0])
+    torch.cuda.current_stream().wait_stream(side)
+    assert tr2.default_stream_steps == 0
+    out = tr2.fit([batches[i % 5] for i in range(6)], graph="on")
+    assert len(out) == 6 and tr2.graph_choice == "graph"
+
+
+def test_step_counter_is_one_sequence_across_eager_steps_replays_and_state_dict(X):
+    """GraphedStep seeds the device-side counter from the optimizer's completed steps (AdamW's bias correction
+    and the dropout stream continue, they do not restart at 1 on warm moments), and the replays' steps reach
+    optimizer.state_dict() (they advance the counter on the device only)."""
+    mod, batches = _setup(X)
+    tr = X.Trainer(mod)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(4):
+            tr.fit_step(batches[i])  # host-side step count: 4 completed steps
+        gs = X.GraphedStep(tr, batches[0], warmup=0)
+        torch.cuda.synchronize()
+        assert int(mod.model.step_device.item()) == 4
+        for i in range(3):
+            gs(batches[i])
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert int(mod.model.step_device.item()) == 7
+    sd = tr.optimizer.state_dict()
+    assert all(st["step"] == 7 for st in sd["state"].values())
+    # fit() restores the caller's defer_logging and leaves the counter written back
+    mod3, _ = _setup(X)
+    mod3.defer_logging = "auto"
+    tr3 = X.Trainer(mod3)
+    tr3.fit([batches[i % 5] for i in range(7)], graph="on")
+    assert mod3.defer_logging == "auto"
+    assert all(st["step"] == 7 for st in tr3.optimizer.state.values())
+
+
+def test_deferred_step_logs_the_batch_constants_and_ring_needs_two_slots(X):
+    """trainer.py:241-244 logs batch/size, batch/seq_len, batch/numel every step: the sync-free path carries them too (host
+    constants, no device sync). PinnedBatchRing(slots=1) would stage into the slot the running step reads: refused."""
+    from xfmr_rec_amd.data import PinnedBatchRing
+
+    mod, batches = _setup(X)
+    tr = X.Trainer(mod)
+    tr.fit_step(batches[0])
+    B, L = batches[0]["history_item_idx"].shape
+    assert int(mod.logged["batch/size"]) == B and int(mod.logged["batch/seq_len"]) == L and int(mod.logged["batch/numel"]) == B * L
+    vals = mod.logged_values(mod.last_out)
+    assert vals["batch/size"] == B and vals["batch/numel"] == B * L
+    assert vals["batch/attention_density"] == pytest.approx(float(mod.logged["batch/attention_density"]), rel=1e-6)
+    with pytest.raises(ValueError, match="at least 2 slots"):
+        PinnedBatchRing(DEV, B, L, slots=1)
+    # a pageable batch staged over and over through two slots: every take returns what was staged
+    ring = PinnedBatchRing(DEV, B, L, slots=2)
+    host = [{k: v.cpu() + i for k, v in batches[0].items()} for i in range(5)]
+    ring.stage(host[0])
+    for i in range(5):
+        got = ring.take()
+        if i + 1 < 5:
+            ring.stage(host[i + 1])
+        for k in host[i]:
+            assert torch.equal(got[k].cpu(), host[i][k]), (i, k)
+    ring.release()
+    ring.close()

@@ -195,6 +195,81 @@ def test_attention_fwd_bwd(ops, prec, B, L, A, lengths, causal, dh):
     assert_close("attn.d_qkv", d_qkv, ref_in.grad, prec, "grad")
 
 
+def _bf16r(x):
+    """fp64 -> (fp32 ->) bf16 -> fp64: the rounding the kernels apply to an fp32 value on its way into an MFMA operand."""
+    return x.to(torch.float32).to(torch.bfloat16).to(torch.float64)
+
+
+def _attention_bf16_emulation(qkv, key_mask, A, w, causal=True):
+    """fp64 arithmetic with the bf16 kernels' ROUNDING POINTS (attention.hip, head size 32): operands Q / K / V / dO are
+    bf16 values (the caller passes bf16-representable inputs, so staging rounds nothing); forward = online softmax over
+    32-key blocks, p = 2^(s c - m_running) rounded to bf16 as the P V operand while the row sum takes the unrounded p;
+    backward: P = exp(s / sqrt(dh) - lse) from the forward's lse, bf16(P) into dV, dS = P (dP - delta) rounded to bf16
+    into dQ and dK, delta = rowsum(dO * ctx) in full precision. What is left between this and the kernels is fp32
+    accumulation order and the 1-ulp exp2 -- parity at the fp32 level (1e-4) for the kernels no fp32-policy run reaches
+    (L > 256: the two-block forward and the dQ + dK/dV pair)."""
+    B, L, H3 = qkv.shape
+    H = H3 // 3
+    dh = H // A
+    q, k, v = (t.double().view(B, L, A, dh).transpose(1, 2) for t in qkv.split(H, dim=-1))  # (B,A,L,dh)
+    do = w.double().view(B, L, A, dh).transpose(1, 2)
+    s = q @ k.transpose(2, 3)
+    tri = torch.ones(L, L, dtype=torch.bool)
+    vis = ((tri.tril() if causal else tri)[None] & key_mask.bool()[:, None, :])[:, None].expand(B, A, L, L)
+    c = dh**-0.5 * 1.4426950408889634
+    m = torch.full((B, A, L), -float("inf"), dtype=torch.float64)
+    lsum = torch.zeros(B, A, L, dtype=torch.float64)
+    o = torch.zeros(B, A, L, dh, dtype=torch.float64)
+    for k0 in range(0, L, 32):
+        sb = (s[..., k0:k0 + 32] * c).masked_fill(~vis[..., k0:k0 + 32], -float("inf"))
+        mnew = torch.maximum(m, sb.max(dim=-1).values)
+        msafe = torch.where(torch.isinf(mnew), torch.zeros_like(mnew), mnew)
+        alpha = torch.exp2(m - msafe)
+        p = torch.exp2(sb - msafe[..., None])
+        lsum = lsum * alpha + p.sum(-1)
+        o = o * alpha[..., None] + _bf16r(p) @ v[:, :, k0:k0 + 32]
+        m = mnew
+    ctx = o / lsum.clamp(min=1e-300)[..., None]
+    ctx = torch.where((lsum > 0)[..., None], ctx, torch.zeros_like(ctx))
+    lse = (m + torch.log2(lsum)) * 0.6931471805599453  # natural log, as the kernel stores it
+    pr = torch.exp(s * dh**-0.5 - lse[..., None]).masked_fill(~vis, 0.0)
+    pr = torch.nan_to_num(pr, nan=0.0)
+    dp = do @ v.transpose(2, 3)
+    delta = (do * ctx).sum(-1, keepdim=True)
+    ds = _bf16r(pr * (dp - delta))
+    dv = _bf16r(pr).transpose(2, 3) @ do
+    dq = (ds @ k) * dh**-0.5
+    dk = (ds.transpose(2, 3) @ q) * dh**-0.5
+    back = lambda t: t.transpose(1, 2).reshape(B, L, H)  # noqa: E731
+    return back(ctx), torch.cat([back(dq), back(dk), back(dv)], dim=-1)
+
+
+@pytest.mark.parametrize("causal", [True, False], ids=["causal", "bidirectional"])
+@pytest.mark.parametrize("B,L,A,lengths", [(1, 512, 2, [512]), (2, 320, 2, [320, 301]), (2, 200, 4, [200, 150])])
+def test_bf16_attention_kernels_at_fp32_level_against_their_rounding_model(ops, B, L, A, lengths, causal):
+    """BASELINE config 5's L = 512 attention (and 320; 200 = the fused one-workgroup kernels, for comparison) in the bf16
+    policy, at the FP32 tolerances: values 1e-4, gradient rel-L2 1e-4, against the fp64 model of the kernels' own
+    rounding points on bf16-representable inputs. test_attention_fwd_bwd holds these shapes to the exact fp64 attention
+    at the bf16 tolerance (3e-2): an indexing slip worth 1 % would pass there, not here."""
+    H = 32 * A
+    qkv = _rand(B, L, 3 * H, seed=13).to(torch.bfloat16).float()
+    mask = torch.zeros(B, L, dtype=torch.uint8)
+    for b, n in enumerate(lengths):
+        mask[b, :n] = 1
+    if B > 1:
+        mask[1, 2] = 0
+    w = (_rand(B, L, H, seed=14) * mask[..., None]).to(torch.bfloat16).float()
+    ctx, lse = ops.attn_fwd(qkv.to(DEV), mask.to(DEV), A, precision="bf16", causal=causal)
+    want_ctx, want_d = _attention_bf16_emulation(qkv, mask, A, w, causal)
+    valid = mask.bool()
+    assert_close("attn.ctx", ctx.cpu()[valid], want_ctx[valid], "fp32")
+    # the backward under test reads the FORWARD KERNEL's ctx / lse; the model used its own (equal to 1e-4 by the line above)
+    d_qkv = ops.attn_bwd(qkv.to(DEV), mask.to(DEV), ctx, lse, w.to(DEV), A, precision="bf16", causal=causal)
+    assert_close("attn.d_qkv", d_qkv, want_d, "fp32", "grad")
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert_close(f"attn.{name}", d_qkv[..., sl], want_d[..., sl], "fp32", "grad")
+
+
 def test_attention_causality_and_padding_invariance(ops):
     """Changing a later key/value or a masked key never changes an earlier / any output."""
     B, L, A = 1, 96, 2

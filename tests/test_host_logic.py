@@ -234,7 +234,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _ddp_worker(rank, world, port, out_dir):
+def _ddp_worker(rank, world, port, out_dir, nL=2):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "transformer-recommenders_amd"))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -247,7 +247,7 @@ def _ddp_worker(rank, world, port, out_dir):
 
     r, _local, w = D.init_process_group_from_env(backend="gloo")
     assert (r, w) == (rank, world)
-    H, A, I, nL, L, V, B = 64, 2, 64, 2, 12, 40, 6
+    H, A, I, L, V, B = 64, 2, 64, 12, 40, max(6, 2 * world)
     cfg = X.ModelConfig(hidden_size=H, num_attention_heads=A, intermediate_size=I, num_hidden_layers=nL, max_seq_length=L)
     model = X.RecommenderModel(cfg, seed=3)  # same seed on every rank == replicated weights
     table = unit_table(V, H)
@@ -274,22 +274,36 @@ def _ddp_worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_data_parallel_gloo_world2(tmp_path):
-    world, port = 2, _free_port()
-    mp.start_processes(_ddp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+@pytest.mark.parametrize("world,nL", [(2, 2), (8, 3), (2, 1)])
+def test_data_parallel_gloo_world2(tmp_path, world, nL):
+    """World sizes 2 and 8 (the node the scaling bench runs on); HalvedAllReduce with an even layer count, an odd one
+    (boundary = layer nL // 2's first tensor) and a single layer (boundary = 0: the "tail" is the whole buffer and no head
+    message is sent, distributed.py: `if b > 0`)."""
+    port = _free_port()
+    mp.start_processes(_ddp_worker, args=(world, port, str(tmp_path), nL), nprocs=world, join=True, start_method="spawn")
     r = [torch.load(tmp_path / f"r{i}.pt", weights_only=True) for i in range(world)]
-    assert sorted(r[0]["rows"] + r[1]["rows"]) == list(range(6)) and not set(r[0]["rows"]) & set(r[1]["rows"])
-    total = r[0]["local"] + r[1]["local"]
-    for i in range(world):
-        torch.testing.assert_close(r[i]["reduced"], total, rtol=1e-6, atol=1e-7)
+    B = max(6, 2 * world)
+    assert sorted(sum((x["rows"] for x in r), [])) == list(range(B))  # every row on exactly one rank
+    total = sum(x["local"].double() for x in r).float()
+    for i in range(world):  # (fp32 sums of 8 addends depend on the collective's order: a few ulp)
+        torch.testing.assert_close(r[i]["reduced"], total, rtol=1e-5, atol=1e-6)
     assert not torch.allclose(r[0]["local"], r[1]["local"])  # shards really differ (negatives stay rank-local)
-    # two halves == one message, bit for bit (a SUM of two ranks is exact either way); the boundary is layer 1's first tensor
+    # two halves == one message: bit for bit for two ranks (a + b is exact either way), to summation order for eight
+    # (a ring all-reduce splits its message into per-rank chunks, so an element's order of addition depends on the length)
     for i in range(world):
-        assert torch.equal(r[i]["halved"], r[i]["reduced"])
+        if world == 2:
+            assert torch.equal(r[i]["halved"], r[i]["reduced"])
+        else:
+            torch.testing.assert_close(r[i]["halved"], r[i]["reduced"], rtol=1e-5, atol=1e-6)
+        assert torch.equal(r[i]["halved"], r[0]["halved"])  # every replica holds the same bits
     import xfmr_rec_amd as X
 
-    names, shapes, offsets, total = X.models.flat_layout(64, 64, 12, 2)
-    assert r[0]["boundary"] == offsets[names.index("encoder.layer.1.attention.self.query.weight")] and 0 < r[0]["boundary"] < total
+    names, shapes, offsets, n_total = X.models.flat_layout(64, 64, 12, nL)
+    if nL == 1:
+        assert r[0]["boundary"] == 0
+    else:
+        first = f"encoder.layer.{nL // 2}.attention.self.query.weight"
+        assert r[0]["boundary"] == offsets[names.index(first)] and 0 < r[0]["boundary"] < n_total
 
 
 def test_saved_directory_is_a_loadable_hf_bert_with_the_sentence_transformer_layout(tmp_path):
@@ -365,6 +379,14 @@ def test_bench_gpus_n_launches_its_own_ranks():
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout  # ONE line, printed by rank 0
     assert lines[0]["n_gpus"] == 2 and lines[0]["allreduce_ok"] is True and lines[0]["dry"] is True
+    assert lines[0]["exchange"]["rccl_world"] == 2
+    # the node the driver's scaling bench uses: 8 ranks
+    r8 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True,
+                        timeout=600)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    l8 = [json.loads(l) for l in r8.stdout.splitlines() if l.startswith("{")]
+    assert len(l8) == 1 and l8[0]["n_gpus"] == 8 and l8[0]["exchange"]["rccl_world"] == 8 and l8[0]["allreduce_ok"] is True
+    assert l8[0]["scaling"] == "weak"
     # launched as a single rank of a 1-rank world but asked to report 2 GPUs: refused
     bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)

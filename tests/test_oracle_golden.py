@@ -176,3 +176,40 @@ def test_lean_form_equals_materialised_form(g3):
             params, table, batch, num_heads=cfg["A"], max_seq_length=cfg["L"], kind=kind, loss_cfg={},
         )
         np.testing.assert_allclose(float(lean), g3[f"loss/{kind}"], rtol=1e-4, atol=1e-5, err_msg=kind)
+
+
+@pytest.mark.parametrize("mask_fn", [True, False])
+def test_lean_by_item_equals_the_materialised_oracle(mask_fn):
+    """oracle/lean.py (the item-weighted restatement that the FULL-SIZE GPU parity tests use: sum_j f(l_ij) =
+    sum_u mult_u f(l_iu)) against the materialised oracle of the reference's form -- (Np, 1+N, H) candidates through
+    oracle.losses, which the fixtures above pin to the imported reference -- on a batch small enough for both, with
+    repeated items, exact positive/negative ties and a non-unit table. All seven sums, the statistics, and the
+    sampled-rows form with its gradient."""
+    from oracle import lean
+
+    g = torch.Generator().manual_seed(7)
+    V, H, Np, Nn = 40, 16, 57, 230
+    table = torch.randn(V + 1, H, generator=g) * (0.5 + torch.rand(V + 1, 1, generator=g))
+    table[0] = 0
+    q = torch.randn(Np, H, generator=g)
+    pos = torch.randint(1, V + 1, (Np,), generator=g)
+    neg = torch.randint(1, V + 1, (Nn,), generator=g)
+    neg[:3] = pos[:3]  # exact ties
+    cand = torch.cat([table[pos][:, None, :], table[neg][None, :, :].expand(Np, -1, -1)], dim=1)
+    ties = torch.cat([torch.zeros(Np, 1, dtype=torch.bool), neg[None, :] == pos[:, None]], dim=1)
+    cfg = dict(mask_false_negatives=mask_fn, scale=1.7, margin=0.3)
+    got = lean.heads_by_item(q, pos, neg, table, chunk=20, **cfg)
+    for kind in OL.LOSS_KINDS:
+        want = OL.embed_loss(kind, q, cand, ties=ties, **cfg).item()
+        assert got[f"loss/{kind}"] == pytest.approx(want, rel=2e-6, abs=1e-6), kind
+    stats = OL.logits_statistics(q, cand, ties=ties, **cfg)
+    for k, v in stats.items():
+        assert got[k] == pytest.approx(v, rel=2e-5, abs=1e-6), k
+    rows = torch.tensor([0, 1, 2, 9, 33, 56])
+    for kind in ("InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss", "NCELoss"):
+        qr = q[rows].clone().requires_grad_(True)
+        want = OL.embed_loss(kind, qr, cand[rows], ties=ties[rows], **cfg)
+        want.backward()
+        loss, grad = lean.rows_reference_form(kind, q[rows], pos[rows], neg, table, **cfg)
+        assert loss.item() == pytest.approx(want.item(), rel=2e-6, abs=1e-6), kind
+        np.testing.assert_allclose(grad.numpy(), qr.grad.numpy(), rtol=2e-5, atol=2e-6)

@@ -790,7 +790,9 @@ struct Plan {
   int nblocks;
 };
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
-Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
+// `ns_override` (xfmr_loss_cfg.flags, XFMR_LOSS_NSPLIT(n)): a column-split count forced by the caller (parity tests walk
+// several plans in one process); 0 = the plan's own choice below.
+Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false, int ns_override = 0) {
   Plan p;
   const int64_t qblocks = (T + QB - 1) / QB;
   const int64_t cols = T > n_rows ? T : n_rows;
@@ -810,6 +812,7 @@ Plan make_plan(int64_t T, int H, int64_t n_rows, bool hard = false) {
   if (ns < 4 && qblocks >= 512) ns = 4;
   static const int ns_env = [] { const char* e = getenv("XFMR_LOSS_NSPLIT"); return e ? atoi(e) : 0; }();  // tuning experiments
   if (ns_env > 0) ns = ns_env;
+  if (ns_override > 0) ns = ns_override;
   if (ns > tiles) ns = tiles;
   if (ns < 1) ns = 1;
   p.nsplit = (int)ns;
@@ -895,7 +898,7 @@ size_t xfmr_sampled_loss_workspace(int64_t positions, int32_t H, int64_t n_rows)
 }
 size_t xfmr_sampled_loss_workspace_cfg(const xfmr_loss_cfg* cfg, int64_t positions, int32_t H, int64_t n_rows) {
   if (!cfg || positions <= 0 || H <= 0) return 0;
-  return make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0).total;
+  return make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0, (int)XFMR_LOSS_NSPLIT_OF(cfg->flags)).total;
 }
 
 static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* table, const float* table_rnorm,
@@ -922,6 +925,8 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   if (grid.x >= 512) ns_grad = 1;
   static const int ns_grad_env = [] { const char* e = getenv("XFMR_LOSS_NSPLIT_GRAD"); return e ? atoi(e) : 0; }();
   if (ns_grad_env > 0) ns_grad = ns_grad_env;
+  const int ns_grad_flag = (int)XFMR_LOSS_NSPLIT_GRAD_OF(cfg->flags);  // (tests: several plans in one process)
+  if (ns_grad_flag > 0) ns_grad = ns_grad_flag;
   if (ns_grad < 1) ns_grad = 1;
   if (ns_grad > p.nsplit) ns_grad = p.nsplit;  // (the workspace is carved for p.nsplit)
   int ns_part = p.nsplit;  // split count the records in a.part (and partO) are written with
@@ -970,7 +975,7 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
     // such n: config 5 (256 blocks on 256 CUs) runs 1 split -- one full round, the rows finished in the kernel, no 134 MB
     // of partial dQ written and re-read (6.62 -> 6.51 ms/step); config 4 (100 blocks) 5 splits instead of 10 (two rounds
     // of 250: 3.06 -> 2.99; 3 splits = 1.17 rounds measured 3.30).
-    if (H > 128 && grid.x < 512 && ns_grad_env <= 0) {
+    if (H > 128 && grid.x < 512 && ns_grad_env <= 0 && ns_grad_flag <= 0) {
       static const int cus = [] {
         int dev = 0, cu = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1100,7 +1105,7 @@ int xfmr_sampled_loss_prepare(const xfmr_loss_cfg* cfg, const uint8_t* key_mask,
     return XFMR_EINVAL;
   if (cfg->mode == XFMR_NEG_SHARED && !neg_idx) return XFMR_EINVAL;
   if (!xf_aligned16(workspace)) return XFMR_EALIGN;
-  const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0);
+  const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0, (int)XFMR_LOSS_NSPLIT_OF(cfg->flags));
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
@@ -1131,7 +1136,7 @@ int xfmr_sampled_loss_prepared(const xfmr_loss_cfg* cfg, const float* tok, const
     return rc;
   if (!key_mask || !pos_idx) return XFMR_EINVAL;
   if (cfg->mode == XFMR_NEG_SHARED && !neg_idx) return XFMR_EINVAL;
-  const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0);
+  const Plan p = make_plan(positions, H, n_rows, cfg->num_hard_negatives > 0, (int)XFMR_LOSS_NSPLIT_OF(cfg->flags));
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const bool zeroed = (cfg->flags & XFMR_LOSS_DTOK_ZEROED) != 0;  // the caller zeroed d_tok itself
@@ -1163,7 +1168,7 @@ size_t xfmr_sampled_loss_lists_workspace_cfg(const xfmr_loss_cfg* cfg, int64_t n
                                              int64_t n_rows) {
   const int64_t rows = n_query > n_neg ? n_query : n_neg;
   if (!cfg || rows <= 0 || H <= 0) return 0;
-  return make_plan(rows, H, n_rows, cfg->num_hard_negatives > 0).total;
+  return make_plan(rows, H, n_rows, cfg->num_hard_negatives > 0, (int)XFMR_LOSS_NSPLIT_OF(cfg->flags)).total;
 }
 
 int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const int64_t* pos_items,
@@ -1175,7 +1180,7 @@ int xfmr_sampled_loss_lists(const xfmr_loss_cfg* cfg, const float* query, const 
     return rc;
   if (!pos_items || n_query <= 0) return XFMR_EINVAL;
   if (cfg->mode == XFMR_NEG_SHARED && (!neg_items || n_neg <= 0)) return XFMR_EINVAL;
-  const Plan p = make_plan(rows, H, n_rows, cfg->num_hard_negatives > 0);
+  const Plan p = make_plan(rows, H, n_rows, cfg->num_hard_negatives > 0, (int)XFMR_LOSS_NSPLIT_OF(cfg->flags));
   if (workspace_bytes < p.total) return XFMR_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;

@@ -117,6 +117,10 @@ class PinnedBatchRing:
 
         self.device = torch.device(device)
         self.slots = int(slots)
+        if self.slots < 2:
+            # with one slot the next stage() would overwrite the batch the running step is still reading (take() hands the
+            # slot back only at the NEXT take / release)
+            raise ValueError(f"PinnedBatchRing needs at least 2 slots, got {slots}")
         self.shape = (3, int(batch), int(width))
         self.lib = N.load()
         with torch.cuda.device(self.device):
@@ -132,6 +136,8 @@ class PinnedBatchRing:
                     N.check(self.lib.xfmr_event_create(ctypes.byref(e), 0), "xfmr_event_create")
                     lst.append(e.value)
         self.used = [False] * self.slots  # slot read by a step at least once (its free event has been recorded)
+        self.staged = [False] * self.slots  # slot has had a copy issued into it (its ready event has been recorded)
+        self.keep = [None] * self.slots  # the copy's SOURCE block, referenced until the slot's next copy may start
         self.shapes = [self.shape] * self.slots
         self.head = 0  # next slot to stage into
         self.tail = 0  # next slot to take
@@ -153,6 +159,12 @@ class PinnedBatchRing:
             shape = tuple(blk.shape)
         if len(shape) != 3 or shape[0] != 3 or shape[1] > self.shape[1] or shape[2] > self.shape[2]:
             raise ValueError(f"batch of shape {shape} does not fit the ring's slots {self.shape}")
+        if self.staged[s]:
+            # hipMemcpyAsync from page-locked memory reads its source until the copy COMPLETES, not until the call returns:
+            # the slot's previous copy (slots batches ago) must be done before its host block is rewritten or its
+            # caller-supplied source released. Returns at once unless the copy stream is a whole ring behind.
+            N.check(self.lib.xfmr_event_synchronize(self.ready[s]), "xfmr_event_synchronize")
+            self.keep[s] = None
         if blk is None or not (blk.is_pinned() and blk.is_contiguous() and blk.dtype == torch.int64):
             dst = self.host[s].view(-1)[: shape[0] * shape[1] * shape[2]].view(shape)
             if blk is None:
@@ -164,7 +176,8 @@ class PinnedBatchRing:
         nbytes = 8 * shape[0] * shape[1] * shape[2]
         N.check(self.lib.xfmr_batch_upload(self.dev[s].data_ptr(), blk.data_ptr(), nbytes, self.copy_stream,
                                            self.free[s] if self.used[s] else None, self.ready[s]), "xfmr_batch_upload")
-        self._keep = blk  # the source must stay alive until the copy has been issued (it has: the call returned)
+        self.keep[s] = blk  # the source stays referenced until this slot's copy has completed (checked at its next stage)
+        self.staged[s] = True
         self.shapes[s] = shape
         self.head = (s + 1) % self.slots
         self.pending += 1

@@ -100,7 +100,15 @@ class HalvedAllReduce:
                 dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
             return flat_grad
         from . import _native as N
+        from . import ops
 
+        if flat_grad.data_ptr() != ops.last_encoder_grad_ptr:
+            # `grads_half_event` says when xfmr_encoder_bwd finished the upper half of ITS output buffer. That is `.grad`
+            # itself only when the step started from `.grad = None` (zero_grad(set_to_none=True): autograd then adopts the
+            # backward's buffer); with an accumulating `.grad`, AccumulateGrad's += runs after the whole backward and the
+            # event would release half-written sums. One message behind the backward instead.
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            return flat_grad
         main = torch.cuda.current_stream()
         N.check(self._lib.xfmr_stream_wait_event(self.comm.cuda_stream, self.event), "xfmr_stream_wait_event")
         with torch.cuda.stream(self.comm):

@@ -175,7 +175,7 @@ class EmbedLoss(torch.nn.Module, abc.ABC):
         if isinstance(candidate_embed, SharedNegatives):
             if self.config.target_position != "first":
                 raise ValueError("SharedNegatives candidates put the positive at column 0: target_position='first'")
-            return ops.SampledLossListsFunction.apply(
+            return ops.sampled_loss_lists_train(
                 q, candidate_embed.pos_items, candidate_embed.neg_items, candidate_embed.table,
                 candidate_embed.table_rnorm,
                 self._opts(N.NEG_SHARED, all_heads=all_heads) | {"table_bf16": candidate_embed.table_bf16},
@@ -187,7 +187,7 @@ class EmbedLoss(torch.nn.Module, abc.ABC):
             if opts["mask_false_negatives"]:
                 # the reference would additionally mask catalogue items scoring above the positive; supported
                 pass
-            return ops.SampledLossListsFunction.apply(
+            return ops.sampled_loss_lists_train(
                 q, target.contiguous(), None, candidate_embed.table, candidate_embed.table_rnorm, opts
             )
         # the reference's own calling convention: a dense (N,C,H) tensor (xfmr_dense_loss, C <= 8192). The training
@@ -199,7 +199,7 @@ class EmbedLoss(torch.nn.Module, abc.ABC):
             num_hard_negatives=c.num_hard_negatives, scale=c.scale, margin=c.margin,
         )
         tgt = None if target is None else target.contiguous().to(torch.int64)
-        return ops.DenseLossFunction.apply(q, candidate_embed.contiguous().to(torch.float32), tgt, opts)
+        return ops.dense_loss_train(q, candidate_embed.contiguous().to(torch.float32), tgt, opts)
 
     def forward(self, query_embed, candidate_embed, target=None):
         """Summed loss over the batch (``losses.py:128-155``)."""

@@ -312,11 +312,24 @@ class RecommenderModel(torch.nn.Module):
         self.step_device = torch.zeros(1, dtype=torch.int32, device=self.device) if on else None
 
     def _cfg(self, B: int, L: int, embed_event=None) -> N.EncoderCfg:
+        return ops.make_encoder_cfg(**self._cfg_kwargs(B, L, embed_event))
+
+    def _cfg_kwargs(self, B: int, L: int, embed_event=None) -> dict:
+        """make_encoder_cfg's keyword arguments for this model, in plain Python (traced code builds the scalar arguments
+        of torch.ops.xfmr.encoder from them; eager code the xfmr_encoder_cfg)."""
         c = self.config
         train = self.training
         step_dev = getattr(self, "step_device", None)
-        ctx = self.context() if train else None
-        return ops.make_encoder_cfg(
+        if torch.compiler.is_compiling():
+            # inside a traced region nothing may be created through ctypes: the side stream is used if it already exists
+            # (model.context() before compiling), and the per-step part of the dropout seed has to live on the device
+            ctx = getattr(self, "_context", None) if train else None
+            if train and step_dev is None:
+                raise RuntimeError("compiling a TRAINING step: call model.use_device_step(True) first (the dropout stream "
+                                   "must be keyed by a device-side counter; a host-side step count would be baked in)")
+        else:
+            ctx = self.context() if train else None
+        return dict(
             batch=B, seq_len=L, hidden=c.hidden_size, heads=c.num_attention_heads, inter=c.intermediate_size,
             layers=c.num_hidden_layers, max_pos=c.max_seq_length, precision=self.precision, ln_eps=LAYER_NORM_EPS,
             hidden_dropout=HIDDEN_DROPOUT_PROB if train else 0.0,
@@ -346,9 +359,10 @@ class RecommenderModel(torch.nn.Module):
         else:
             msg = "either `item_idx` or `item_embeds` must be provided"
             raise ValueError(msg)
-        if self.training:
+        if self.training and not torch.compiler.is_compiling():  # (traced training steps key dropout on the device)
             self._step += 1
-        tok, key_mask = ops.EncoderFunction.apply(self.flat, idx, table, self._cfg(B, L, embed_event))
+        # torch.ops.xfmr.encoder when traced (custom_ops.py), the autograd.Function over the same C-ABI calls in eager mode
+        tok, key_mask = ops.encoder(self.flat, idx, table, self._cfg_kwargs(B, L, embed_event))
         return tok, key_mask
 
     def forward(self, item_idx=None, *, item_embeds=None) -> dict[str, torch.Tensor]:

@@ -187,6 +187,8 @@ def mean_pool(tok, key_mask):
 
 def pool(tok, key_mask, mode: str = "mean"):
     """sentence-transformers Pooling(pooling_mode) over (B,L,H) tokens; forward only."""
+    if use_torch_ops():
+        return torch.ops.xfmr.pool(tok, key_mask, N.POOL_MODES[mode])
     B, L, H = tok.shape
     out = _empty((B, H), tok)
     N.check(N.load().xfmr_pool(N.ptr(tok), N.ptr(key_mask), N.ptr(out), B, L, H, N.POOL_MODES[mode], N.stream()),
@@ -220,6 +222,8 @@ class L2NormalizeFunction(torch.autograd.Function):
 
 
 def l2_normalize(x, eps: float = 1e-12):
+    if use_torch_ops():
+        return torch.ops.xfmr.l2_normalize(x.contiguous().to(f32), float(eps))[0]
     return L2NormalizeFunction.apply(x, eps)
 
 
@@ -244,20 +248,28 @@ def step_advance_(step_device):
     N.check(N.load().xfmr_step_advance(N.ptr(step_device), N.stream()), "xfmr_step_advance")
 
 
+def _plan_flags(nsplit: int = 0, nsplit_grad: int = 0) -> int:
+    """XFMR_LOSS_NSPLIT(n) | XFMR_LOSS_NSPLIT_GRAD(n): launch-plan overrides inside xfmr_loss_cfg.flags (0 = library's plan)."""
+    assert 0 <= nsplit < 256 and 0 <= nsplit_grad < 256
+    return (nsplit << 8) | (nsplit_grad << 16)
+
+
 def sampled_loss_workspace(like, T, H, n_rows, *, train_head, all_heads=True, mask_false_negatives=True, mode=N.NEG_SHARED,
-                           scale=1.0, margin=0.5, precision="bf16", num_hard_negatives=0, **_):
+                           scale=1.0, margin=0.5, precision="bf16", num_hard_negatives=0, nsplit=0, nsplit_grad=0, **_):
     """An (unprepared) workspace for sampled_loss(..., workspace=...) on `like`'s device."""
-    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives)
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives,
+                    flags=_plan_flags(nsplit, nsplit_grad))
     return _bytes(N.load().xfmr_sampled_loss_workspace_cfg(C.byref(cfg), T, H, n_rows), like)
 
 
 def sampled_loss_prepare(ws, key_mask, pos_idx, neg_idx, rnorm, n_rows, H, *, train_head, all_heads=True,
                          mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
-                         num_hard_negatives=0, **_):
+                         num_hard_negatives=0, nsplit=0, nsplit_grad=0, **_):
     """The index-only half of the loss (query compaction, multiplicities, distinct negatives) into `ws`, on the
     current stream: needs the key mask, not the token embeddings. Follow with sampled_loss(..., workspace=ws,
     prepared=True) with the same options."""
-    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives)
+    cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives,
+                    flags=_plan_flags(nsplit, nsplit_grad))
     N.check(
         N.load().xfmr_sampled_loss_prepare(C.byref(cfg), N.ptr(key_mask), N.ptr(pos_idx), N.ptr(neg_idx), N.ptr(rnorm),
                                            n_rows, key_mask.numel(), H, N.ptr(ws), ws.numel(), N.stream()),
@@ -268,16 +280,17 @@ def sampled_loss_prepare(ws, key_mask, pos_idx, neg_idx, rnorm, n_rows, H, *, tr
 def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, all_heads=True,
                  mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
                  need_grad=True, table_bf16=None, num_hard_negatives=0, workspace=None, prepared=False, d_tok_zeroed=None,
-                 profile_grad=None, profile_log=None):
+                 profile_grad=None, profile_log=None, nsplit=0, nsplit_grad=0):
     """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H). `workspace` (sampled_loss_workspace) +
     `prepared=True`: sampled_loss_prepare already ran on it; `d_tok_zeroed`: a zero-filled buffer like tok to take the
     gradient (the call then skips its own memset); `profile_grad` / `profile_log`: (start, stop) hipEvent_t handles
-    recorded around the gradient-pass / logging-pass kernel (measurement)."""
+    recorded around the gradient-pass / logging-pass kernel (measurement); `nsplit` / `nsplit_grad`: column-split counts
+    of the launch plan forced by the caller (0 = the library's plan; parity tests walk several plans)."""
     H = tok.shape[-1]
     T = tok.numel() // H
     lib = N.load()
     d_tok = (d_tok_zeroed if d_tok_zeroed is not None else torch.empty_like(tok)) if need_grad else None
-    flags = 0
+    flags = _plan_flags(nsplit, nsplit_grad)
     if d_tok_zeroed is not None and need_grad:
         assert d_tok.shape == tok.shape and d_tok.dtype == tok.dtype
         flags |= N.LOSS_DTOK_ZEROED
@@ -451,10 +464,15 @@ def encoder_fwd(cfg: N.EncoderCfg, flat_params, item_idx, table):
     return tok, key_mask, acts
 
 
+last_encoder_grad_ptr = 0  # device address of the flat gradient buffer the last xfmr_encoder_bwd call wrote
+
+
 def encoder_bwd(cfg: N.EncoderCfg, flat_params, d_tok, key_mask, acts, grads=None):
     """d_tok is clobbered. Returns the flat gradient buffer."""
+    global last_encoder_grad_ptr
     if grads is None:
         grads = torch.empty_like(flat_params)
+    last_encoder_grad_ptr = grads.data_ptr()  # (distributed.HalvedAllReduce checks that .grad IS this buffer)
     N.check(
         N.load().xfmr_encoder_bwd(C.byref(cfg), N.ptr(flat_params), N.ptr(grads), N.ptr(d_tok), N.ptr(key_mask),
                                   N.ptr(acts), acts.numel(), N.stream()),
@@ -570,3 +588,83 @@ class DenseLossFunction(torch.autograd.Function):
         d_q = outs.pop(0) if need else None
         d_c = outs.pop(0) if need_c else None
         return d_q, d_c, None, None
+
+
+# ------------------------------------------------------------------------------------------------ torch.ops.xfmr.*
+# The same implementations registered as PyTorch custom operators (custom_ops.py: schema + fake tensors + autograd
+# formulas), so that torch.compile / torch.export of a model built from these kernels sees shape-inferable opaque ops.
+# The eager step keeps the autograd.Function route above -- a Python-registered op with an autograd formula costs
+# ~130 us of host time per call against ~12 (custom_ops.py) --; traced code, or XFMR_TORCH_OPS=1, takes the ops.
+from . import custom_ops  # noqa: E402  (registers torch.ops.xfmr.*)
+
+
+def use_torch_ops() -> bool:
+    return torch.compiler.is_compiling() or os.environ.get("XFMR_TORCH_OPS", "") == "1"
+
+
+def encoder_op_args(*, heads, inter, layers, max_pos, precision, ln_eps=1e-12, hidden_dropout=0.0, attn_dropout=0.0,
+                    seed=0, causal=True, flags=None, step_device=None, embed_event=None, context=None,
+                    grads_half_event=None, extra_flags=0, profile=None, **_shape):
+    """make_encoder_cfg's keyword arguments -> the scalar arguments of torch.ops.xfmr.encoder, in plain Python (no ctypes:
+    this runs inside traced code). Returns (scalars..., step_device, handles)."""
+    f = encoder_flags_from_env() if flags is None else int(flags)
+    f |= int(extra_flags)
+    if not causal:
+        f |= N.ENC_BIDIRECTIONAL
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    if seed >= 1 << 63:
+        seed -= 1 << 64
+    prof = list(profile) if profile else [0, 0, 0, 0]
+    handles = [int(embed_event or 0), int(context or 0), int(grads_half_event or 0)] + [int(x or 0) for x in prof]
+    return (int(heads), int(inter), int(layers), int(max_pos), str(precision), float(ln_eps), float(hidden_dropout),
+            float(attn_dropout), f, seed, step_device, handles)
+
+
+def encoder(flat_params, item_idx, table, cfg_kwargs: dict):
+    """tok (B,L,H), key_mask (B,L) = the encoder of `cfg_kwargs` (make_encoder_cfg's keyword arguments) on `item_idx`;
+    differentiable in `flat_params`. Eager: EncoderFunction; traced / XFMR_TORCH_OPS=1: torch.ops.xfmr.encoder."""
+    if use_torch_ops():
+        tok, key_mask, _acts = torch.ops.xfmr.encoder(flat_params, item_idx, table, *encoder_op_args(**cfg_kwargs))
+        return tok, key_mask
+    return EncoderFunction.apply(flat_params, item_idx, table, make_encoder_cfg(**cfg_kwargs))
+
+
+_EAGER_ONLY_LOSS_OPTS = ("workspace", "prepared", "d_tok_zeroed", "profile_grad", "profile_log")
+
+
+def _loss_op_scalars(opts: dict):
+    head = opts["train_head"]
+    return (N.LOSS_IDS[head] if isinstance(head, str) else int(head), int(opts.get("all_heads", True)),
+            bool(opts.get("mask_false_negatives", True)), int(opts.get("mode", N.NEG_SHARED)), float(opts.get("scale", 1.0)),
+            float(opts.get("margin", 0.5)), str(opts.get("precision", "bf16")), int(opts.get("num_hard_negatives", 0)))
+
+
+def sampled_loss_train(tok, key_mask, pos_idx, neg_idx, table, rnorm, opts: dict):
+    """(train_loss, losses[14], stats[16]) on (B*L) positions; train_loss carries the gradient w.r.t. `tok`."""
+    if use_torch_ops() and not any(opts.get(k) for k in _EAGER_ONLY_LOSS_OPTS):
+        out = torch.ops.xfmr.sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, opts.get("table_bf16"),
+                                          *_loss_op_scalars(opts), bool(tok.requires_grad and torch.is_grad_enabled()),
+                                          [int(opts.get("nsplit", 0)), int(opts.get("nsplit_grad", 0))])
+        return out[0], out[1], out[2]
+    return SampledLossFunction.apply(tok, key_mask, pos_idx, neg_idx, table, rnorm, opts)
+
+
+def sampled_loss_lists_train(query, pos_items, neg_items, table, rnorm, opts: dict):
+    if use_torch_ops():
+        out = torch.ops.xfmr.sampled_loss_lists(query, pos_items, neg_items, table, rnorm, opts.get("table_bf16"),
+                                                *_loss_op_scalars(opts), bool(query.requires_grad and torch.is_grad_enabled()))
+        return out[0], out[1], out[2]
+    return SampledLossListsFunction.apply(query, pos_items, neg_items, table, rnorm, opts)
+
+
+def dense_loss_train(query, cand, target, opts: dict):
+    if use_torch_ops():
+        mode = {"first": N.TARGET_FIRST, "diagonal": N.TARGET_DIAGONAL, None: N.TARGET_EXPLICIT}[opts.get("target_position", "first")]
+        head = opts["train_head"]
+        grad_on = torch.is_grad_enabled()
+        out = torch.ops.xfmr.dense_loss(
+            query, cand, target, mode, N.LOSS_IDS[head] if isinstance(head, str) else int(head), int(opts.get("all_heads", False)),
+            bool(opts.get("mask_false_negatives", True)), float(opts.get("scale", 1.0)), float(opts.get("margin", 0.5)),
+            int(opts.get("num_hard_negatives", 0)), bool(query.requires_grad and grad_on), bool(cand.requires_grad and grad_on))
+        return out[0], out[1], out[2]
+    return DenseLossFunction.apply(query, cand, target, opts)

@@ -89,6 +89,21 @@ class FusedAdamW(torch.optim.Optimizer):
             ops.step_advance_(self.step_device)
         return loss
 
+    def sync_step_from_device(self) -> None:
+        """Write the device-side step counter back into ``state[p]["step"]``. Replays of a captured step advance the counter
+        on the device only: without this a ``state_dict()`` taken after ``fit(graph="on")`` would carry a stale step, and a
+        resume (or a later ``fit`` seeding its counter from it) the wrong bias corrections. One host sync."""
+        if self.step_device is None:
+            return
+        n = int(self.step_device.item())
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = n
+
+    def state_dict(self):
+        self.sync_step_from_device()
+        return super().state_dict()
+
 
 class RecommenderLightningModule(_Base):
     def __init__(self, config: LightningConfig) -> None:
@@ -230,7 +245,7 @@ class RecommenderLightningModule(_Base):
                     **(opts | {"all_heads": 2, "workspace": ws_log, "prepared": True, "profile_log": profile_log})
                 )
             main.wait_event(self._ev_prep)  # (recorded long ago)
-            train_loss, losses_train, stats_t = ops.SampledLossFunction.apply(
+            train_loss, losses_train, stats_t = ops.sampled_loss_train(
                 tok, key_mask, pos, neg, m.embeddings, m.table_rnorm,
                 opts | {"all_heads": False, "workspace": ws_grad, "prepared": True, "d_tok_zeroed": d_tok0,
                         "profile_grad": profile_grad}
@@ -243,7 +258,7 @@ class RecommenderLightningModule(_Base):
                     tns.record_stream(side)
             self._logging_pending = True
         else:
-            train_loss, losses, stats = ops.SampledLossFunction.apply(
+            train_loss, losses, stats = ops.sampled_loss_train(
                 tok, key_mask, pos, neg, m.embeddings, m.table_rnorm,
                 opts | {"profile_grad": profile_grad, "profile_log": profile_log}
             )
@@ -262,11 +277,12 @@ class RecommenderLightningModule(_Base):
             out["losses_train/device"] = losses_train
         batch_size, seq_len = key_mask.shape
         numel = key_mask.numel()
+        # trainer.py:241-244: known without a device sync, logged on every path
+        out |= {"batch/size": batch_size, "batch/seq_len": seq_len, "batch/numel": numel}
         if sync_metrics and not overlap:
             s = stats.tolist()  # one device->host sync (the reference does 11 .item() calls)
             attn_nz, pos_nz = int(s[N.STAT["n_valid"]]), int(s[N.STAT["n_query"]])
             out |= {
-                "batch/size": batch_size, "batch/seq_len": seq_len, "batch/numel": numel,
                 "batch/attention_non_zero": attn_nz, "batch/attention_density": attn_nz / (numel + 1e-9),
                 "batch/positive_non_zero": pos_nz, "batch/positive_density": pos_nz / (attn_nz + 1e-9),
             }
@@ -296,10 +312,13 @@ class RecommenderLightningModule(_Base):
             v = float(out[k]) if (vals is None or cls.__name__ == c.train_loss) else vals[i]
             res[k] = v
             res[k + "Mean"] = v / (pos_nz + 1e-9)
+        res |= {k: out[k] for k in ("batch/size", "batch/seq_len", "batch/numel") if k in out}
         res |= {
             "batch/attention_non_zero": attn_nz, "batch/positive_non_zero": pos_nz,
             "batch/positive_density": pos_nz / (attn_nz + 1e-9),
         }
+        if "batch/numel" in out:
+            res["batch/attention_density"] = attn_nz / (out["batch/numel"] + 1e-9)
         if c.log_all_losses:
             res |= stats_to_dict(s)
         return res
@@ -377,7 +396,10 @@ class RecommenderLightningModule(_Base):
         out = self.compute_losses(batch, sync_metrics=False, defer_logging=bool(defer),
                                   profile_grad=prof[0], profile_log=prof[1])
         key = f"loss/{self.config.train_loss}"
-        self._pending_out = out
+        # only DETACHED tensors outlive the step: a retained train loss would keep the step's autograd graph -- the saved
+        # activations and `flat`'s AccumulateGrad node with the stream it was created on -- alive into the next step (and
+        # into a later hipGraph capture on another stream: ADVICE r3)
+        self._pending_out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
         self.logged = {}
         self.log_dict({key: out[key].detach()})
         return out[key]
@@ -412,6 +434,9 @@ class RecommenderLightningModule(_Base):
                 res[k + "Mean"] = out[k + "Mean"]
             elif side is not None:
                 res[k + "Mean"] = (own if is_train and own is not None else side)[N.NUM_LOSSES + i]
+        for k in ("batch/size", "batch/seq_len", "batch/numel"):  # host constants (trainer.py:241-244)
+            if k in out:
+                res[k] = torch.as_tensor(out[k])
         res["batch/attention_non_zero"] = stats[N.STAT["n_valid"]]
         res["batch/positive_non_zero"] = stats[N.STAT["n_query"]]
         res["batch/attention_density"] = stats[N.STAT["attn_density"]]
@@ -504,19 +529,24 @@ class Trainer:
         self.world_size = world_size
         self.process_group = process_group
         self.exchange = None
+        self.default_stream_steps = 0  # eager steps this trainer ran on the device's DEFAULT stream
         if world_size > 1:
             import os
 
             for g in self.optimizer.param_groups:
                 g["grad_scale"] = 1.0 / world_size  # DDP averages gradients: SUM all-reduce then / W
-            if os.environ.get("XFMR_ALLREDUCE_SINGLE", "0") != "1":  # (=1: one message after the backward, as in round 2)
+            # One message behind the backward by default. XFMR_ALLREDUCE_HALVES=1: two halves, the upper layers' underneath
+            # the lower layers' backward (distributed.HalvedAllReduce) -- its event ordering is tested on one GPU
+            # (tests/test_gpu_ddp.py), but RCCL's transport has never run under it (no multi-GPU box was available to the
+            # build: DESIGN.md section 6), so it stays opt-in until a scaling record exists.
+            if os.environ.get("XFMR_ALLREDUCE_HALVES", "0") == "1" and os.environ.get("XFMR_ALLREDUCE_SINGLE", "0") != "1":
                 from .distributed import HalvedAllReduce
 
                 self.exchange = HalvedAllReduce(module.model, process_group)
 
     def allreduce_(self, flat_grad: torch.Tensor) -> None:
-        """The step's one exchange: SUM of the flat gradient over the ranks (1 / W is folded into AdamW) -- in two
-        halves, the upper layers' underneath the rest of the backward, unless XFMR_ALLREDUCE_SINGLE=1."""
+        """The step's one exchange: SUM of the flat gradient over the ranks (1 / W is folded into AdamW); with
+        XFMR_ALLREDUCE_HALVES=1 in two halves, the upper layers' underneath the rest of the backward."""
         if self.world_size <= 1:
             return
         if self.exchange is not None:
@@ -531,6 +561,10 @@ class Trainer:
         -> [all-reduce] -> optimizer.step -> on_train_batch_end``): what ``bench.py`` times."""
         m = self.module
         m.train()
+        dev = m.model.device
+        if dev.type == "cuda" and not torch.cuda.is_current_stream_capturing() \
+                and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
+            self.default_stream_steps += 1  # (a later hipGraph capture refuses: GraphedStep)
         self.optimizer.zero_grad(set_to_none=True)
         loss = m.training_step(batch, 0)
         loss.backward()
@@ -558,7 +592,9 @@ class Trainer:
             raise ValueError(f"graph must be 'off', 'on' or 'auto', got {graph!r}")
         if self.world_size != 1:
             graph = "off"  # (the all-reduce of a data-parallel step is not captured)
+        defer_before = getattr(self.module, "defer_logging", "auto")
         if graph != "off":
+            _refuse_capture_after_default_stream_steps(self)
             # the step counter the captured kernels read (dropout stream, AdamW bias corrections) lives in HBM from the
             # first step on, so that the eager steps in front of the capture and the replays after it are one sequence
             mdl = self.module.model
@@ -635,12 +671,28 @@ class Trainer:
                 i += 1
         if side is not None:
             cur.wait_stream(side)
+        if graph != "off":
+            self.module.defer_logging = defer_before  # (the capture needed one stream; the caller's setting comes back)
+            self.optimizer.sync_step_from_device()  # replays advanced the counter on the device only
         self.graph_probe = {k: round(v, 4) for k, v in probe.items() if k.endswith("_ms")}
         if ring is not None:
             ring.release()
             ring.close()
         self.elapsed = time.time() - t0
         return [float(v) for v in out]  # (one host sync at the end, not one per step)
+
+
+def _refuse_capture_after_default_stream_steps(trainer: "Trainer") -> None:
+    """torch's capture protocol: autograd's AccumulateGrad node of a parameter is bound to the stream of the first backward
+    that used it and synchronises with that stream from then on; eager steps on the device's DEFAULT (legacy) stream
+    followed by a capture on a side stream made the capture fault (scripts/probe/fit_graph_probe.py, round 3). A clear
+    Python error instead of that fault."""
+    if getattr(trainer, "default_stream_steps", 0) > 0:
+        raise RuntimeError(
+            f"this Trainer has run {trainer.default_stream_steps} eager step(s) on the device's default stream; a hipGraph "
+            "capture after that is refused (torch's capture protocol: warm-up steps must run on a side stream -- "
+            "`with torch.cuda.stream(torch.cuda.Stream()): trainer.fit_step(...)`, or let Trainer.fit(graph=...) / "
+            "GraphedStep(warmup=...) run them). Build a new Trainer for the captured run.")
 
 
 class GraphedStep:
@@ -672,6 +724,7 @@ class GraphedStep:
         m = trainer.module
         if trainer.world_size != 1:
             raise ValueError("GraphedStep captures a single-process step")
+        _refuse_capture_after_default_stream_steps(trainer)
         self.trainer, self.keys = trainer, SEQ_BATCH_KEYS
         dev = m.model.device
         if overlap:
@@ -680,9 +733,15 @@ class GraphedStep:
         elif getattr(m, "defer_logging", "auto") == "auto":
             m.defer_logging = False  # one stream inside the capture
         if getattr(m.model, "step_device", None) is None:
+            # the counter continues the optimizer's completed steps (AdamW's bias corrections and the dropout stream go on
+            # from where the eager steps stopped, as Trainer.fit seeds it)
             m.model.use_device_step(True)
+            done = max((st.get("step", 0) for st in trainer.optimizer.state.values()), default=0)
+            m.model.step_device.fill_(int(done))
         trainer.optimizer.step_device = m.model.step_device
         m.train()
+        m._pending_out = None  # nothing of an earlier step (its tensors, their autograd graph) reaches into the capture
+        m.last_out = None
         self.static = {k: example_batch[k].to(dev, torch.int64).clone() for k in self.keys}
         # eager warm-up on a side stream (torch's capture protocol): creates every lazily made object -- optimizer state,
         # the model's xfmr_context, allocator pools -- so that the capture itself creates nothing. ``warmup=0``: the caller
