@@ -90,7 +90,8 @@ def parse(argv=None):
                          "fresh box can take > 100 ms of sustained load to reach its steady clocks; the cold rate "
                          "(--warmup steps only) is measured first and reported as `cold_start`")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-seconds", type=float, default=7.0, help="time budget of EACH cpu_baseline variant")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0,
+                    help="time budget of EACH cpu_baseline variant beyond its 3 warm-up + 10 timed steps (up to 50 steps)")
     args = ap.parse_args(argv)
     presets = {
         # BASELINE configs[0]: MovieLens-100K-shaped, the reference's CPU-runnable case (the cpu_baseline's last variant)
@@ -242,17 +243,38 @@ def _cpu_variant(args, *, B, L, H, V, layers, inter, faithful, autocast, seconds
         else:
             tr.step(batch)
 
-    step()  # warm-up (allocator, oneDNN primitives)
-    t0 = time.perf_counter()
-    done = 0
-    while done < 50 and (done == 0 or time.perf_counter() - t0 < seconds):
+    # 3 warm-up steps, >= 10 timed steps, the MEDIAN reported. The time budget only extends the
+    # sample beyond the 10 steps the protocol asks for (up to 50); it never cuts it short.
+    for _ in range(3):
         step()
-        done += 1
-    dt = (time.perf_counter() - t0) / done
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 10 or (len(times) < 50 and time.perf_counter() - t_all < seconds):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    n = len(times)
+    dt = times[n // 2] if n % 2 else 0.5 * (times[n // 2 - 1] + times[n // 2])
     return {
         "variant": label, "value": round(B / dt, 3), "unit": "sequences/s", "ms_per_step": round(dt * 1e3, 1),
-        "sample": f"{done} steps of B={B} x L={L} (H={H}, {layers} layers, V={V}; N={B * L} in-batch negatives)",
+        "ms_per_step_min_max": [round(times[0] * 1e3, 1), round(times[-1] * 1e3, 1)],
+        "sample": f"median of {n} steps after 3 warm-up steps, B={B} x L={L} (H={H}, {layers} layers, V={V}; "
+                  f"N={B * L} in-batch negatives)",
     }
+
+
+def cpu_model() -> str:
+    """The host CPU's model name (printed into the result beside the core count)."""
+    try:
+        for line in pathlib.Path("/proc/cpuinfo").read_text().splitlines():
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    import platform
+
+    return platform.processor() or platform.machine() or "unknown"
 
 
 def cpu_baseline(args):
@@ -278,7 +300,9 @@ def cpu_baseline(args):
     ]
     head = variants[0]
     return {
-        "value": head["value"], "unit": "sequences/s", "cores": threads, "kind": "port",
+        "value": head["value"], "unit": "sequences/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+        "protocol": "BASELINE.md section 3: same process and host as the GPU number, torch.set_num_threads(cores), dropout on, "
+                    "3 warm-up steps, >= 10 timed steps, median",
         "sample": head["sample"] + f", fp32, {'7 heads + stats' if not args.lean else 'train head only'}, "
                                    f"{head['ms_per_step']:.0f} ms/step",
         "variants": variants,
@@ -312,12 +336,39 @@ def valu_roofline(v, launch_ms):
             "source": v.get("source")}
 
 
+PROFILE_ROUND = "r04"  # the round whose committed counter runs (profiles/<round>_*) describe THIS build's kernels
+
+
 def static_profile(name):
+    """profiles/<name> (counter figures that one bench run cannot collect itself: --pmc passes slow and serialise the
+    launches) -- only when it was collected for this build's round: a file of another round is refused, `traffic` is then
+    null and says why, instead of a stale number riding along silently."""
     p = ROOT / "profiles" / name
     try:
-        return json.loads(p.read_text()) if p.exists() else None
+        d = json.loads(p.read_text()) if p.exists() else None
     except Exception:  # noqa: BLE001
         return None
+    if d is not None and d.get("round") != PROFILE_ROUND:
+        return None
+    return d
+
+
+def step_algorithmic_bytes(B, L, H, inter, heads, layers, n_params):
+    """HBM bytes one training step must move if every tensor is read and written once (DESIGN.md sections 3 / 5; the table of
+    scripts/kernel_roofline.py): bf16 for the tensors that are only ever MFMA operands, fp32 for the residual stream, its
+    gradient and the LayerNorm inputs. Per layer: QKV / attention / out-proj + LN / fused FFN forward; their backward dX
+    chain; the four weight-gradient GEMMs' operands. Once: gather + embedding LN and its backward, the loss's query rows
+    and gradient, the split-K slabs' reduction is NOT algorithmic (a single-slab dW would not need it) and is left out."""
+    T = B * L
+    TH, TI, T3H = T * H, T * inter, 3 * T * H
+    f32, b16 = 4, 2
+    fwd = (TH * b16 + T3H * b16) + (T3H * b16 + TH * b16 + B * heads * L * f32) + (TH * b16 + 3 * TH * f32 + TH * b16) \
+        + (TH * b16 + TH * f32 + 2 * TI * b16 + 2 * TH * f32 + TH * b16)
+    bwd = (TH * b16 + 2 * TI * b16 + 3 * TH * f32 + TH * b16) + 2 * TH * b16 + (2 * T3H * b16 + 2 * TH * b16) \
+        + (T3H * b16 + 3 * TH * f32 + TH * b16)
+    dw = (TH + TI) * b16 * 2 + (TH + TH) * b16 + (T3H + TH) * b16
+    once = (3 * TH * f32 + TH * b16) + (3 * TH * f32 + TH * b16 // 2) + 3 * TH * f32 + 28 * n_params
+    return float(layers * (fwd + bwd + dw) + once)
 
 
 def main():
@@ -498,23 +549,56 @@ def main():
     ar_ms = ar_events.elapsed_ms() if ar_events is not None else []
     resident_s, _, _ = timed(args.steps)  # the same steps on batches that already lie in HBM
     inline_s, _, _ = timed(args.steps, None, from_host="inline")
+    # SURVEY section 8(d) names two length regimes: dense rows (the roofline stress: `value`) and MovieLens-like ragged rows,
+    # len ~ clip(round(exp(N(4.35, 1))), 16, L), right-padded with 0 as the reference's collate does (data.py:799-805). The
+    # same timed region on ragged batches of the same (B, L) shape, beside the dense figure.
+    ragged = None
+    if args.lengths == "dense":
+        while ring.pending:
+            ring.take()
+        ring.release()
+        dense_sets = (host_batches, batches)
+        r_host, r_dev, r_lens = [], [], []
+        for i in range(n_batches):
+            b, lens = synth_batch(B, L, V, 5000 + rank * 97 + i, "ml")
+            r_host.append(torch.stack([b[k] for k in KEYS]).pin_memory())
+            r_dev.append({k: v.to(dev) for k, v in b.items()})
+            r_lens += lens
+        host_batches, batches = r_host, r_dev
+        for i in range(max(args.warmup, 2)):
+            step(i, True)
+        ragged_s, _, _ = timed(args.steps, None, from_host=True)
+        while ring.pending:
+            ring.take()
+        ring.release()
+        host_batches, batches = dense_sets
+        ragged = {"value": round(B * world * args.steps / ragged_s, 2), "unit": "sequences/s",
+                  "ms_per_step": round(ragged_s / args.steps * 1e3, 4), "lengths": "ml",
+                  "mean_tokens_per_sequence": round(sum(r_lens) / len(r_lens), 1),
+                  "tokens_per_s": round(sum(r_lens) / len(r_lens) * B * world * args.steps / ragged_s, 1),
+                  "note": "the timed region of `value` (H2D included) on MovieLens-like ragged rows of the same (B, L) shape: "
+                          "len = clip(round(exp(N(4.35, 1))), 16, L), right-padded with 0 (SURVEY section 8d, data.py:799-805)"}
     # The dominant kernel once more with nothing beside it (outside the timed region): in the timed region the logging pass
     # sits on a lowest-priority stream underneath the encoder backward, so its duration there includes the time it is held
     # back -- what a one-stream rocprofv3 trace (profiles/*_kernel_stats.md) sees is this figure.
     alone_ms, alone_grad_ms = [], []
-    alone_enc = {k: [] for k, _ in ENC_PARTS}
+    # in line the layer's four weight-gradient GEMMs are ONE launch (gemm_group_kernel) and can be bracketed too, and so can
+    # the backward's final reduction launch
+    ALONE_PARTS = ENC_PARTS + ((N.PROF_DW, "gemm_group_kernel"), (N.PROF_REDUCE, "multi_rowsum_kernel"))
+    alone_enc = {k: [] for k, _ in ALONE_PARTS}
     if (overlap or gstep is not None) and not args.lean:
-        ev2 = HipEvents(12)
-        ev3 = HipEvents(12) if enc_parts_ok else None
-        for i in range(12):  # even: the gradient pass, odd: the logging pass -- both on the main stream, one after the other
-            encp = (ENC_PARTS[i % 4][0], ENC_LAYER) + ev3.pairs[i] if ev3 is not None else None
+        n_alone = 18
+        ev2 = HipEvents(n_alone)
+        ev3 = HipEvents(n_alone) if enc_parts_ok else None
+        for i in range(n_alone):  # even: the gradient pass, odd: the logging pass -- both on the main stream, one after the other
+            encp = (ALONE_PARTS[i % 6][0], ENC_LAYER) + ev3.pairs[i] if ev3 is not None else None
             step(i, in_line=True, profile=(None, ev2.pairs[i]) if (i & 1) else (ev2.pairs[i], None), enc_profile=encp)
         torch.cuda.synchronize()
-        alone_ms = ev2.elapsed_ms({i for i in range(12) if i & 1})
-        alone_grad_ms = ev2.elapsed_ms({i for i in range(12) if not (i & 1)})
+        alone_ms = ev2.elapsed_ms({i for i in range(n_alone) if i & 1})
+        alone_grad_ms = ev2.elapsed_ms({i for i in range(n_alone) if not (i & 1)})
         if ev3 is not None:
-            for j, (k, _) in enumerate(ENC_PARTS):
-                alone_enc[k] = ev3.elapsed_ms({i for i in range(12) if i % 4 == j})
+            for j, (k, _) in enumerate(ALONE_PARTS):
+                alone_enc[k] = ev3.elapsed_ms({i for i in range(n_alone) if i % 6 == j})
     mod.model.enc_profile = None
 
     stats = out["stats/device"].tolist()
@@ -573,15 +657,18 @@ def main():
                           3 * TH * 2 + TH * 2 + B * A_heads * L * 4, 4.0 * B * A_heads * L * (L + 1) / 2 * 32),
         N.PROF_ATTN_BWD: ("attn_bwd_fused_bf16_kernel (one workgroup per (batch, head): dQ, dK, dV)",
                           2 * 3 * TH * 2 + 2 * TH * 2, 10.0 * B * A_heads * L * (L + 1) / 2 * 32),
+        # operands only: dy + g, dI + x1, d_lin + ctx, dQKV + x (all bf16); the split-K slabs it also writes are overhead
+        N.PROF_DW: ("gemm_group_kernel (the layer's four weight-gradient GEMMs, split-K, in one launch: the in-line form)",
+                    (TH + TI) * 2 * 2 + 2 * TH * 2 + (3 * TH + TH) * 2, 2.0 * Tt * (2 * H * args.inter + H * H + 3 * H * H)),
     }
     enc_entries = []
     if enc_parts_ok:
         over = {k: (enc_events.elapsed_ms({i for i in range(args.steps) if i % 4 == j}) if enc_events is not None else [])
                 for j, (k, _) in enumerate(ENC_PARTS)}
-        for k, _short in ENC_PARTS:
+        for k, _short in ALONE_PARTS:
             ms_alone, ms_over = alone_enc.get(k) or [], over.get(k) or []
             ms = ms_alone or ms_over
-            if not ms:
+            if not ms or k not in enc_model:
                 continue
             name, nbytes, flops = enc_model[k]
             avg = sum(ms) / len(ms)
@@ -605,13 +692,15 @@ def main():
     enc_flops = n_valid * encoder_flops_per_token(tokens_per_seq, H, args.inter, args.layers)
     step_flops = enc_flops + grad_flops + (log_flops if log_ms else 0.0)
     step_tf = step_flops / (step_ms * 1e-3) / 1e12
-    static = static_profile("r03_bench_static.json") or static_profile("r02_bench_static.json") or {}
+    static = static_profile(f"{PROFILE_ROUND}_bench_static.json") or {}
+    step_bytes = step_algorithmic_bytes(B, tokens_per_seq, H, args.inter, args.heads or H // 32, args.layers,
+                                        int(mod.model.flat.numel()))
 
     if rank == 0:
         seqs = B * world * args.steps
         roofline = dict(dominant)
         ktraffic = static.get("kernel_hbm_bytes_per_launch") or {}
-        dom_key = next((short for k, short in ENC_PARTS if dominant["kernel"].startswith(short)), None)
+        dom_key = next((short for k, short in ALONE_PARTS if dominant["kernel"].startswith(short)), None)
         if dom_key is None:
             dom_key = "loss_logging_pass" if dominant is k_log else "loss_gradient_pass"
         dom_traffic = ktraffic.get(dom_key)
@@ -619,13 +708,23 @@ def main():
             dom_traffic = static.get("dominant_kernel_hbm_bytes_per_launch")
         roofline |= {
             "traffic": dom_traffic,
-            "traffic_source": static.get("source") if dom_traffic else None,
+            "traffic_source": static.get("source") if dom_traffic else
+                              f"null: profiles/{PROFILE_ROUND}_bench_static.json (scripts/collect_profiles.sh {PROFILE_ROUND}) "
+                              "is missing or holds no counter run of this kernel; files of other rounds are refused",
+            # step level: what the whole step moves if every tensor crosses HBM once / ms_per_step / the HBM peak
+            "step_hbm": {"algorithmic_bytes": step_bytes, "achieved": round(step_bytes / (step_ms * 1e-3) / 1e12, 3),
+                         "peak": PEAK_HBM_TBPS, "unit": "TB/s",
+                         "frac": round(step_bytes / (step_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
+                         "note": "step_algorithmic_bytes() of bench.py (per-kernel compulsory bytes, mean row length) / "
+                                 "ms_per_step; the two loss passes and the attention kernels are not bound by bytes"},
             "columns": int(n_cols), "sampled_negative_columns": int(n_valid),
             "reference_form_flops_per_launch": ref_form_flops,
             "kernels": [k_grad] + ([k_log] if log_ms else []) + enc_entries,
             "step": {"executed_flops": step_flops, "achieved": round(step_tf, 1), "unit": "TFLOP/s", "peak": peak,
                      "frac": round(step_tf / peak, 4),
                      "note": "encoder fwd+bwd on valid tokens + both loss passes, / ms_per_step"},
+            "reduction_launch_ms": (round(sum(alone_enc[N.PROF_REDUCE]) / len(alone_enc[N.PROF_REDUCE]), 4)
+                                    if alone_enc.get(N.PROF_REDUCE) else None),
             "valu": valu_roofline(static.get("dominant_kernel_valu"), k_log["avg_launch_ms"]) if log_ms else None,
             "valu_kernel": k_log["kernel"] if log_ms else None,
             "gemm_family_tbps": static.get("gemm_family_tbps"),
@@ -667,6 +766,7 @@ def main():
             "h2d_on_compute_stream": {"value": round(seqs / inline_s, 2), "ms_per_step": round(inline_s / args.steps * 1e3, 4),
                                       "note": "Lightning's plain batch transfer: three .to(device, non_blocking=True) copies on "
                                               "the compute stream itself, nothing prefetched"},
+            **({"ragged": ragged} if ragged else {}),
             "cold_start": {"value": round(seqs / cold_s, 2), "ms_per_step": round(cold_s / args.steps * 1e3, 4),
                            "note": f"the first {args.steps} steps after {args.warmup} warm-up steps only, before the spin-up"},
             "roofline": roofline,

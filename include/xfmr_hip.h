@@ -183,7 +183,11 @@ typedef struct xfmr_encoder_cfg {
 } xfmr_encoder_cfg;
 /* xfmr_encoder_cfg.profile_kernel: the FFN forward (one kernel in the fused form: FFN1 + GELU + FFN2 + dropout + residual +
  * LayerNorm), the FFN backward's dX chain (one kernel in the fused form), the attention forward, the attention backward. */
-enum { XFMR_PROF_NONE = 0, XFMR_PROF_FFN_FWD = 1, XFMR_PROF_FFN_BWD = 2, XFMR_PROF_ATTN_FWD = 3, XFMR_PROF_ATTN_BWD = 4 };
+enum { XFMR_PROF_NONE = 0, XFMR_PROF_FFN_FWD = 1, XFMR_PROF_FFN_BWD = 2, XFMR_PROF_ATTN_FWD = 3, XFMR_PROF_ATTN_BWD = 4,
+       XFMR_PROF_DW = 5,      /* the layer's four weight-gradient GEMMs where they are ONE launch (the in-line form:
+                                 XFMR_ENC_DW_INLINE / no context; on the side stream they are four launches at four times
+                                 and nothing is recorded) */
+       XFMR_PROF_REDUCE = 6   /* the backward's final reduction launch (split-K slabs, bias rows, LayerNorm records) */ };
 /* Element offset at which the early-finished upper half of the flat gradient begins (0 for a one-layer encoder: the
  * event then marks the whole buffer, recorded behind the last launch). */
 int64_t xfmr_param_half_offset(const xfmr_encoder_cfg* cfg);

@@ -8,6 +8,12 @@ GEMM epilogue that contained it gave intermittently wrong rows in the passes tha
 sources avoid it (XF_PIN_SCALAR in gemm.hip, -fno-slp-vectorize for the two cold files); this check keeps a compiler
 or source change from bringing it back unnoticed.
 
+Second rule (round 4): the kernels that carry the LayerNorm-backward epilogue (gemm_kernel<..., EPI_DX_LNBWD = 6, ...>,
+ffn_bwd_dx_fused_kernel) must not store to LDS straight from the MFMA accumulator file (`ds_write_b32 v, aN`). Every failing
+diagnostic build did (launch bound 1: the accumulators live in AGPRs); the product build (launch bound 3) keeps its
+accumulators in VGPRs and the epilogue routes each value through a VGPR anyway -- the second resource the failing builds
+share beyond the op_sel marker. Cheap to hold, so it is held.
+
 usage: check_isa.py obj1.o obj2.o ...   (prints a per-object count; exit 1 on any hit)"""
 import pathlib
 import re
@@ -17,6 +23,8 @@ import tempfile
 
 LLVM = pathlib.Path("/opt/rocm/lib/llvm/bin")
 BAD = re.compile(r"\bv_pk_(add|mul|fma)_f32\b.*\bop_sel:\[")
+AGPR_LDS_STORE = re.compile(r"\bds_write_b(32|64|128)\s+v\d+, a\[?\d+")
+LNBWD_KERNEL = re.compile(r"ffn_bwd_dx_fused_kernel|gemm_kernelI\w+?Lb[01]ELb[01]ELi6E")
 
 
 def disassemble(obj: pathlib.Path) -> str:
@@ -43,9 +51,12 @@ def main(argv):
                 kernel = m.group(1)
             elif BAD.search(line):
                 hits.setdefault(kernel, []).append(line.strip())
+            elif LNBWD_KERNEL.search(kernel) and AGPR_LDS_STORE.search(line):
+                hits.setdefault(kernel + " [AGPR-sourced LDS store in the LayerNorm-backward epilogue]", []).append(line.strip())
         n = sum(len(v) for v in hits.values())
         bad_total += n
-        print(f"check_isa: {name}: {n} packed-fp32 op_sel low-lane-selects-high-dword instructions")
+        print(f"check_isa: {name}: {n} packed-fp32 op_sel low-lane-selects-high-dword instructions / AGPR-sourced LDS stores "
+              f"in the LayerNorm-backward epilogue")
         for k, v in hits.items():
             print(f"  {k}: {len(v)} e.g. {v[0]}")
     return 1 if bad_total else 0

@@ -1121,6 +1121,252 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(const AttnA
   }
 }
 
+// ---- fused backward, two ROLES per workgroup (round 4) ----------------------------------------------------------------
+// The lock-step form above makes four waves share every query tile's dQ: 7-9 barriers, a read-modify-write of the fp32 dQ
+// tile through LDS per step, a dS image per wave -- 2 048 workgroups of ~28 us whose waves wait half their resident cycles
+// (profiles/r02_step_pmc.md). Here ONE workgroup per (batch, head) still stages Q, K, V, dO (+ delta = rowsum(dO * O), lse,
+// dropout row keys, key-mask bits) once, but it has EIGHT waves in two roles that never talk to each other again:
+//   waves 0-3 own KEY tiles   (S = Q K^T, query in the registers, key on the lane):  dV^T += dO^T (P.D),  dK^T += Q^T dS
+//   waves 4-7 own QUERY tiles (S^T = K Q^T, key in the registers, query on the lane): dQ^T += K^T dS^T
+// i.e. the loops of the dK/dV kernel and of the dQ kernel (above) side by side on the same images: every probability is
+// evaluated twice (the matrix and vector pipes have the room: 5 % / 35 % busy in the lock-step form), and in exchange there
+// is ONE barrier, no dQ accumulator in LDS, no dS image, no schedule table, and twice the waves per SIMD to hide latencies.
+// Tiles are dealt so that the waves of a role walk the same number of tile pairs (key tile t has nt - t query tiles, query
+// tile t has t + 1 key tiles): even nt: {w, nt-1-w}; odd nt: {0}, {w, nt-w}. Results: the same sums in a fixed order,
+// bit-reproducible; dQ differs from the lock-step form in summation order only (its key tiles are added in ascending order).
+__device__ __forceinline__ void roles_deal(int nt, int w, int out[2]) {  // key-tile indices of dK/dV wave w (-1: none)
+  out[0] = out[1] = -1;
+  if (nt & 1) {
+    if (w == 0) out[0] = 0;
+    else if (w <= (nt - 1) / 2) { out[0] = w; out[1] = nt - w; }
+  } else if (w < nt / 2) {
+    out[0] = w; out[1] = nt - 1 - w;
+  }
+}
+
+template <bool S16>
+__global__ __launch_bounds__(512, 4) void attn_bwd_roles_bf16_kernel(const AttnArgs a_in) {
+  AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
+  XF_CHAIN_PRIO();
+  a.drop = xf_drop_resolve(a.drop);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int L = a.L, H = a.H;
+  const AttnBlock blk = attn_seq_block(a);
+  if (!blk.valid) return;  // (whole workgroup)
+  const int b = blk.by / a.A, h = blk.by % a.A;
+  const int Lp = ((L + 31) / 32) * 32, nt = Lp / 32;
+  __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* sDO = sQ + Lp * DH;
+  __bf16* sK = sDO + Lp * DH;
+  __bf16* sV = sK + Lp * DH;
+  float* sLse = reinterpret_cast<float*>(sV + Lp * DH);
+  float* sDelta = sLse + Lp;
+  uint32_t* sRowKey = reinterpret_cast<uint32_t*>(sDelta + Lp);
+  uint32_t* sBits = sRowKey + Lp;  // key mask, one bit per key (Lp / 32 + 2 words)
+
+  const int64_t tok0 = (int64_t)b * L;
+  const int64_t hoff = tok0 * H + h * DH;
+  {
+    // one round trip: the Q, K, V, dO and ctx pieces of a row chunk are loaded together (all loads of a thread's two
+    // chunks before the first LDS store); delta is reduced over the lanes that hold the row's pieces
+    constexpr int U = 2, PPR = S16 ? 4 : 8;  // 16-byte pieces per 32-wide row of bf16 / fp32
+    const int total = Lp * PPR;
+    for (int c0 = threadIdx.x; c0 < total; c0 += (int)blockDim.x * U) {
+      uint4 vq[U], vk[U], vv[U], vd[U], vo[U];
+      float ls[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * (int)blockDim.x, r = c / PPR, pc = c % PPR;
+        vq[u] = vk[u] = vv[u] = vd[u] = vo[u] = make_uint4(0u, 0u, 0u, 0u);
+        ls[u] = INFINITY;
+        if (c < total && r < L) {
+          const int e = pc * (32 / PPR);  // first element of the piece
+          const int64_t qo = (tok0 + r) * 3 * H + h * DH + e;
+          vq[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.qkv, qo));
+          vk[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.qkv, qo + H));
+          vv[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.qkv, qo + 2 * H));
+          vd[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.d_ctx, hoff + (int64_t)r * H + e));
+          vo[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.ctx, hoff + (int64_t)r * H + e));
+          if (pc == 0) ls[u] = a.lse[(int64_t)blk.by * L + r] * kLog2e;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * (int)blockDim.x, r = c / PPR, pc = c % PPR;
+        float part;
+        if (S16) {
+          if (c < total) {
+            *reinterpret_cast<uint4*>(sQ + AI::off(r, pc)) = vq[u];
+            *reinterpret_cast<uint4*>(sK + AI::off(r, pc)) = vk[u];
+            *reinterpret_cast<uint4*>(sV + AI::off(r, pc)) = vv[u];
+            *reinterpret_cast<uint4*>(sDO + AI::off(r, pc)) = vd[u];
+          }
+          const float4 d0 = xf_bf16x4_to_f32(make_uint2(vd[u].x, vd[u].y)), d1 = xf_bf16x4_to_f32(make_uint2(vd[u].z, vd[u].w));
+          const float4 o0 = xf_bf16x4_to_f32(make_uint2(vo[u].x, vo[u].y)), o1 = xf_bf16x4_to_f32(make_uint2(vo[u].z, vo[u].w));
+          part = d0.x * o0.x + d0.y * o0.y + d0.z * o0.z + d0.w * o0.w + d1.x * o1.x + d1.y * o1.y + d1.z * o1.z +
+                 d1.w * o1.w;
+        } else {
+          const float4 d4 = *reinterpret_cast<const float4*>(&vd[u]), o4 = *reinterpret_cast<const float4*>(&vo[u]);
+          if (c < total) {
+            const int dd = pc * 4, o = AI::off(r, dd >> 3) + (dd & 7);
+            xf_store4<PrecBF16>(sQ + o, *reinterpret_cast<const float4*>(&vq[u]));
+            xf_store4<PrecBF16>(sK + o, *reinterpret_cast<const float4*>(&vk[u]));
+            xf_store4<PrecBF16>(sV + o, *reinterpret_cast<const float4*>(&vv[u]));
+            xf_store4<PrecBF16>(sDO + o, d4);
+          }
+          part = d4.x * o4.x + d4.y * o4.y + d4.z * o4.z + d4.w * o4.w;
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if (!S16) part += __shfl_xor(part, 4, 64);
+        if (c < total && pc == 0) {
+          sDelta[r] = part;
+          sLse[r] = ls[u];
+          sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + r));
+        }
+      }
+    }
+  }
+  stage_key_bits(sBits, a.key_mask + tok0, Lp, L);
+  __syncthreads();
+
+  const int lane = xf_lane(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5;
+  const float sc = 0.17677669529663687f * kLog2e, ks = 0.17677669529663687f;
+  int mine[2];
+  roles_deal(nt, wid & 3, mine);
+  if (wid < 4) {
+    // ---- role 1: this wave's KEY tiles; walks the query tiles at or after each (attn_bwd_dkv_bf16_kernel's loop)
+#pragma unroll 1
+    for (int ti = 0; ti < 2; ++ti) {
+      const int kt = mine[ti];
+      if (kt < 0) continue;
+      const int k0 = kt * 32, key = k0 + (lane & 31);
+      const bool kin = key < L;
+      const bool kvis = (sBits[kt] >> (lane & 31)) & 1u;
+      const bool all_kvis = __builtin_amdgcn_readfirstlane(sBits[kt]) == 0xFFFFFFFFu;
+      const uint32_t colmix = (uint32_t)key * kDropColMul;
+      // (the key rows -- the B operands -- are re-read from the K / V images per tile: 16 registers fewer across the loop)
+      f32x16 dk, dv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+      for (int qb = kt; qb < nt; ++qb) {
+        const int row0 = qb * 32;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        AI::tile_nt(s, sQ, row0, sK, k0);
+        __builtin_amdgcn_sched_barrier(0);  // (phase by phase: operand fragments of a later phase are not fetched early --
+        AI::tile_nt(dp, sDO, row0, sV, k0);  //  this role has to fit the 128 registers of four waves per SIMD)
+        __builtin_amdgcn_sched_barrier(0);
+        const bool interior = all_kvis && qb > kt;  // every query row is after the wave's keys, every key valid
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int qi0 = row0 + 8 * g + 4 * hh;
+          const float4 l4 = *reinterpret_cast<const float4*>(&sLse[qi0]);
+          const float4 d4 = *reinterpret_cast<const float4*>(&sDelta[qi0]);
+          const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+          uint32_t rk[4] = {0u, 0u, 0u, 0u};
+          if (a.drop.on) {
+            const uint4 k4 = *reinterpret_cast<const uint4*>(&sRowKey[qi0]);
+            rk[0] = k4.x; rk[1] = k4.y; rk[2] = k4.z; rk[3] = k4.w;
+          }
+          float pr[4];
+          if (interior) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pr[u] = xf_exp2(fmaf(s[4 * g + u], sc, -ls[u]));
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              pr[u] = (kvis && key <= qi0 + u) ? xf_exp2(fmaf(s[4 * g + u], sc, -ls[u])) : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int r = 4 * g + u;
+            const float p = pr[u];
+            float keep = 1.f;
+            if (a.drop.on) keep = xf_keep_scale_rc(a.drop, rk[u], colmix);
+            s[r] = p * (dp[r] * keep - dl[u]);  // dS
+            dp[r] = p * keep;                   // P.D
+          }
+          // keep the four groups' lse / delta / row-key reads from being hoisted together (48 registers: the loop would spill
+          // at the 128 of four waves per SIMD); the other waves of the SIMD cover the LDS latency
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        AI::tile_xb_tr(dv, sDO, 0, row0, dp);
+        __builtin_amdgcn_sched_barrier(0);
+        AI::tile_xb_tr(dk, sQ, 0, row0, s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kin) {  // lane = key row, 4 consecutive d per register group
+        const int64_t o = (tok0 + key) * 3 * H + h * DH;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          xf_st4<S16>(a.d_qkv, o + H + 8 * g + 4 * hh,
+                      make_float4(dk[4 * g] * ks, dk[4 * g + 1] * ks, dk[4 * g + 2] * ks, dk[4 * g + 3] * ks));
+          xf_st4<S16>(a.d_qkv, o + 2 * H + 8 * g + 4 * hh,
+                      make_float4(dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]));
+        }
+      }
+    }
+  } else {
+    // ---- role 2: this wave's QUERY tiles (the mirror image of the key deal: tile t has t + 1 key tiles); walks the key
+    // tiles at or before each (attn_bwd_dq_bf16_kernel's loop)
+#pragma unroll 1
+    for (int ti = 0; ti < 2; ++ti) {
+      if (mine[ti] < 0) continue;
+      const int qt = nt - 1 - mine[ti];
+      const int q0 = qt * 32, q = q0 + (lane & 31);
+      const float lse2 = sLse[q], delta = sDelta[q];  // (rows >= L: lse = +inf -> every probability 0)
+      const uint32_t rowkey = sRowKey[q];
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+      for (int kb = 0; kb <= qt; ++kb) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        AI::tile_nt(s, sK, kb * 32, sQ, q0);
+        AI::tile_nt(dp, sV, kb * 32, sDO, q0);
+        const uint32_t kword = sBits[kb];
+        const bool interior = kb < qt && __builtin_amdgcn_readfirstlane(kword) == 0xFFFFFFFFu;
+        if (interior) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = xf_exp2(fmaf(s[r], sc, -lse2));
+            float dpv = dp[r];
+            if (a.drop.on) dpv *= xf_keep_scale_rc(a.drop, rowkey, (uint32_t)(kb * 32 + xf_acc_row(r, lane)) * kDropColMul);
+            s[r] = p * (dpv - delta);
+          }
+        } else {
+          const uint32_t kbits = kword >> (4 * hh);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + xf_acc_row(r, lane);
+            const bool vis = key <= q && ((kbits >> ((r & 3) + 8 * (r >> 2))) & 1u);
+            const float p = vis ? xf_exp2(fmaf(s[r], sc, -lse2)) : 0.f;
+            float dpv = dp[r];
+            if (a.drop.on) dpv *= xf_keep_scale_rc(a.drop, rowkey, (uint32_t)key * kDropColMul);
+            s[r] = p * (dpv - delta);
+          }
+        }
+        AI::tile_xb_tr(dq, sK, 0, kb * 32, s);
+      }
+      if (q < L) {  // dq[r] <-> (d = acc_row(r), query = lane & 31): 4 consecutive d per register group
+        const int64_t o = (tok0 + q) * 3 * H + h * DH;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          xf_st4<S16>(a.d_qkv, o + 8 * g + 4 * hh,
+                      make_float4(dq[4 * g] * ks, dq[4 * g + 1] * ks, dq[4 * g + 2] * ks, dq[4 * g + 3] * ks));
+      }
+    }
+  }
+}
+
+size_t bf16_smem_roles(int L) {  // Q, dO, K, V images; lse + delta + row keys; key-mask bits
+  const size_t Lp = ((size_t)L + 31) / 32 * 32;
+  return 4 * Lp * DH * 2 + 3 * Lp * 4 + (Lp / 32 + 2) * sizeof(uint32_t);
+}
+
 size_t bf16_smem_fused(int L) {  // Q + dO images, fp32 dQ accumulator, lse + delta + row keys, 4 dS images
   const size_t Lp = ((size_t)L + 31) / 32 * 32;
   return 2 * Lp * DH * 2 + Lp * DH * 4 + 3 * Lp * 4 + 4 * 32 * DH * 2;
@@ -1182,6 +1428,22 @@ int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
 template <bool S16>
 int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
   static const int two_kernels = [] { const char* e = getenv("XFMR_ATTN_BWD_SPLIT"); return e ? atoi(e) : 0; }();
+  // the one-workgroup forms: round 1's four-wave lock-step form, or -- XFMR_ATTN_BWD_FORM=roles, read per call -- round 4's
+  // "roles" (eight waves, two roles, one barrier). MEASURED, alternating runs on one box, batch 512: 113.9 / 112.1 us per
+  // layer for roles against 111.1 / 110.7 for lock-step (3.330 / 3.333 vs 3.315 / 3.302 ms per step): the barriers and
+  // the dQ read-modify-write it removes are paid back by evaluating every probability twice (the vector pipe: 28 tile
+  // pairs x ~2 800 issue cycles per (batch, head) against 28 x ~2 000) -- not the default. DESIGN.md section 4.
+  const char* form = getenv("XFMR_ATTN_BWD_FORM");
+  const bool roles = form && form[0] == 'r';
+  if (!two_kernels && roles && a.causal && a.L <= kFusedMaxL) {
+    const size_t sr = bf16_smem_roles(a.L);
+    if (hipFuncSetAttribute((const void*)attn_bwd_roles_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sr) != hipSuccess)
+      return XFMR_EHIP;
+    hipLaunchKernelGGL((attn_bwd_roles_bf16_kernel<S16>), dim3((unsigned)(a.A * ((a.B + 7) / 8) * 8)), dim3(512), sr, st, a);
+    XF_LAUNCH_CHECK();
+    return XFMR_OK;
+  }
   const size_t sf = bf16_smem_fused(a.L);
   if (!two_kernels && a.causal && a.L <= kFusedMaxL && sf <= kLdsLimit) {
     if (hipFuncSetAttribute((const void*)attn_bwd_fused_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,

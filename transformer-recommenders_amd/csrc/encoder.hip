@@ -212,7 +212,7 @@ int check_cfg(const xfmr_encoder_cfg* c) {
   if ((c->hidden != c->heads * 32 && c->hidden != c->heads * 64) || (c->inter & 3)) return XFMR_EUNSUPPORTED;
   if (c->precision != XFMR_PREC_F32 && c->precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   if (c->flags & ~(uint32_t)XFMR_ENC_FLAGS_ALL) return XFMR_EINVAL;  // unknown flag bits
-  if (c->profile_kernel < XFMR_PROF_NONE || c->profile_kernel > XFMR_PROF_ATTN_BWD) return XFMR_EINVAL;
+  if (c->profile_kernel < XFMR_PROF_NONE || c->profile_kernel > XFMR_PROF_REDUCE) return XFMR_EINVAL;
   return XFMR_OK;
 }
 
@@ -556,7 +556,9 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
           {dI, mix ? (const void*)l.x1b : (const void*)l.x1, (int32_t)I, (int32_t)H, r.w1, r.b1, &splits_w1},
           {dlin, l.ctx, (int32_t)H, (int32_t)H, r.wo, nullptr, &splits_wo},
           {dQKV, x_in_g, (int32_t)(3 * H), (int32_t)H, r.wqkv, r.bqkv, &splits}};
+      XF_TRY(prof(cfg, XFMR_PROF_DW, i, 0, st));  // (the in-line form: the layer's four weight-gradient GEMMs are ONE launch)
       XF_TRY(xf_linear_bwd_dw_group(items, 4, T, prec, sAB, st));
+      XF_TRY(prof(cfg, XFMR_PROF_DW, i, 1, st));
       seg(r.w2, grads + p.w2, splits_w2, (int64_t)H * I, (int64_t)H * I);
       seg(r.w1, grads + p.w1, splits_w1, (int64_t)I * H, (int64_t)I * H);
       seg(r.b1, grads + p.b1, splits_w1, I, I);
@@ -620,7 +622,9 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   }
   if (chain_rc != XFMR_OK) return chain_rc;
   if (side_rc != XFMR_OK) return side_rc;
+  XF_TRY(prof(cfg, XFMR_PROF_REDUCE, cfg->profile_layer, 0, st));
   XF_TRY(xf_multi_rowsum(segs, nseg, st));  // every weight / bias / LayerNorm gradient of the encoder, one launch
+  XF_TRY(prof(cfg, XFMR_PROF_REDUCE, cfg->profile_layer, 1, st));
   if (cfg->grads_half_event && half_layer < 0 &&  // (a one-layer encoder has no upper half: the event marks the whole buffer)
       hipEventRecord((hipEvent_t)cfg->grads_half_event, st) != hipSuccess)
     return XFMR_EHIP;

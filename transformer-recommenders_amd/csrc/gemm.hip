@@ -494,8 +494,18 @@ __device__ __forceinline__ void epi_dx_lnbwd_64x128(const f32x16 (&acc)[2], unsi
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = acc[j][8 * hf + r];
+      for (int r = 0; r < 8; ++r) {
+        // Second line of defence (round 4; the first is the pinned per-row scalars below + the build's ISA audit): every
+        // build of this epilogue that produced intermittently wrong rows stored the strip straight
+        // from the MFMA accumulator file (ds_write_b32 v, aN); here each value passes through an ordinary VGPR first
+        // (v_accvgpr_read_b32), so the LDS store no longer depends on the AGPR read port beside resident MFMA waves.
+        // 16 moves per half strip: within noise of the kernel's time (measured with the tile's ~900 vector instructions).
+        float v = acc[j][8 * hf + r];
+#if !(XF_LN_DIAG & 32)
+        XF_PIN_SCALAR(v);
+#endif
+        scr[(xf_acc_row(8 * hf + r, lane) - 16 * hf) * SCR_LD + j * 32 + (lane & 31)] = v;
+      }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     float4 gv[NPL], xh[NPL];

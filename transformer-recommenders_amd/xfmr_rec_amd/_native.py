@@ -55,7 +55,7 @@ class EncoderCfg(C.Structure):
     ]
 
 
-PROF_FFN_FWD, PROF_FFN_BWD, PROF_ATTN_FWD, PROF_ATTN_BWD = 1, 2, 3, 4
+PROF_FFN_FWD, PROF_FFN_BWD, PROF_ATTN_FWD, PROF_ATTN_BWD, PROF_DW, PROF_REDUCE = 1, 2, 3, 4, 5, 6
 
 
 class LossCfg(C.Structure):

@@ -132,7 +132,8 @@ def _encoder_backward(ctx, d_tok, _d_mask, _d_acts):
     step_device = rest[0] if rest else None
     d = d_tok.contiguous()
     # the kernel sequence uses this buffer as scratch: in place only when the producer handed it over (ops._consumable)
-    if d.data_ptr() == d_tok.data_ptr() and not getattr(d_tok, "_xfmr_consumable", False):
+    # (`d is d_tok`: contiguous() returned its argument -- no data_ptr() here, this also runs on fake tensors when traced)
+    if d is d_tok and not getattr(d_tok, "_xfmr_consumable", False):
         d = d.clone()
     *sc, handles = ctx.scalars
     grads = torch.ops.xfmr.encoder_bwd(flat_params, d, key_mask, acts, *sc, step_device, handles)
