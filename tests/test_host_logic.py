@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(native):
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"declared in include/xfmr_hip.h but not exported: {missing}"
     assert declared == set(native.EXPORTED_SYMBOLS), declared ^ set(native.EXPORTED_SYMBOLS)
-    assert native.load().xfmr_abi_version() == native.ABI_VERSION == 2
+    assert native.load().xfmr_abi_version() == native.ABI_VERSION == 3
     assert native.load().xfmr_strerror(-2).decode().startswith("shape not supported")
 
 

@@ -22,6 +22,9 @@ struct AttnArgs {
   const float* qkv; const uint8_t* key_mask; float* ctx; float* lse;  // qkv / ctx / d_ctx / d_qkv: fp32, or bf16
   const float* d_ctx; float* d_qkv;                                   // behind the same pointers (S16 kernels)
   int B, L, A, H;
+  const int32_t* offs;  // packed rows (xfmr_encoder_cfg.seq_offsets): sequence b = rows [offs[b], offs[b + 1]) of qkv / ctx /
+                        // key_mask / d_ctx / d_qkv, at most L of them; null: the padded layout, rows [b L, (b + 1) L). The
+                        // one-workgroup-per-(batch, head) kernels only. lse and the dropout row keys stay indexed by L.
   int causal;  // 1: key j is visible to query i only when j <= i (BertConfig.is_decoder=True, the reference's
                // setting, models.py:355); 0: every unpadded key is visible (is_decoder=False)
   XfDropout drop;
@@ -789,16 +792,23 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(const AttnArg
   XF_CHAIN_PRIO();
   a.drop = xf_drop_resolve(a.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int L = a.L, H = a.H;
+  const int H = a.H;
+  int L = a.L;  // this sequence's rows (packed layout: its own length)
   const AttnBlock blk = attn_seq_block(a);
   if (!blk.valid) return;  // (whole workgroup)
   const int b = blk.by / a.A, h = blk.by % a.A;
+  int64_t tok0 = (int64_t)b * a.L;
+  if (a.offs) {  // packed rows: the sequence starts at its offset and is as long as it is
+    const int o0 = a.offs[b];
+    L = a.offs[b + 1] - o0;
+    tok0 = o0;
+    if (L <= 0) return;  // (whole workgroup)
+  }
   const int Lp = ((L + 31) / 32) * 32, nt = Lp / 32;
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sV = sK + Lp * DH;
   uint32_t* sBits = reinterpret_cast<uint32_t*>(sV + Lp * DH);  // key mask, one bit per key
 
-  const int64_t tok0 = (int64_t)b * L;
   const int lane = xf_lane(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5;
   // the wave's (at most two) query tiles; their query rows are in flight while K / V are staged
   const int qt[2] = {nt - 1 - wid, nt - 8 + wid};
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(const AttnArg
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + q));
+    const uint32_t rowkey = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * a.L + q));
     for (int kb = 0; kb <= qt[i]; ++kb) {
       f32x16 s;
 #pragma unroll
@@ -875,7 +885,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(const AttnArg
       for (int g = 0; g < 4; ++g)
         xf_st4<S16>(a.ctx, off + 8 * g + 4 * hh,
                     make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv));
-      if (lane < 32) a.lse[((int64_t)blk.by) * L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
+      if (lane < 32) a.lse[((int64_t)blk.by) * a.L + q] = ltot > 0.f ? (m + log2f(ltot)) * kLn2 : INFINITY;
     }
   }
 }
@@ -891,10 +901,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(const AttnA
   XF_CHAIN_PRIO();
   a.drop = xf_drop_resolve(a.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int L = a.L, H = a.H;
+  const int H = a.H;
+  int L = a.L;  // this sequence's rows (packed layout: its own length)
   const AttnBlock blk = attn_seq_block(a);
   if (!blk.valid) return;  // (whole workgroup)
   const int b = blk.by / a.A, h = blk.by % a.A;
+  int64_t tok0 = (int64_t)b * a.L;
+  if (a.offs) {  // packed rows: the sequence starts at its offset and is as long as it is
+    const int o0 = a.offs[b];
+    L = a.offs[b + 1] - o0;
+    tok0 = o0;
+    if (L <= 0) return;  // (whole workgroup)
+  }
   const int Lp = ((L + 31) / 32) * 32, nt = Lp / 32;
   __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sDO = sQ + Lp * DH;
@@ -904,7 +922,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(const AttnA
   uint32_t* sRowKey = reinterpret_cast<uint32_t*>(sDelta + Lp);
   __bf16* sDS = reinterpret_cast<__bf16*>(sRowKey + Lp);          // [4 waves][32 keys][32 queries] swizzled
 
-  const int64_t tok0 = (int64_t)b * L;
   const int64_t hoff = tok0 * H + h * DH;
   // Staging in ONE round trip: the Q, dO and ctx pieces of a row chunk are loaded together; Q and dO go to the
   // swizzled images, delta[r] = rowsum(dO * O) is reduced over the lanes that hold the row's chunks.
@@ -925,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(const AttnA
           vq[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.qkv, (tok0 + r) * 3 * H + h * DH + e));
           vd[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.d_ctx, hoff + (int64_t)r * H + e));
           vo[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.ctx, hoff + (int64_t)r * H + e));
-          if (pc == 0) ls[u] = a.lse[(int64_t)blk.by * L + r] * kLog2e;
+          if (pc == 0) ls[u] = a.lse[(int64_t)blk.by * a.L + r] * kLog2e;
         }
       }
 #pragma unroll
@@ -957,7 +974,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(const AttnA
         if (c < total && pc == 0) {
           sDelta[r] = part;
           sLse[r] = ls[u];
-          sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + r));
+          sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * a.L + r));
         }
       }
     }
@@ -1150,10 +1167,18 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_roles_bf16_kernel(const AttnA
   XF_CHAIN_PRIO();
   a.drop = xf_drop_resolve(a.drop);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int L = a.L, H = a.H;
+  const int H = a.H;
+  int L = a.L;  // this sequence's rows (packed layout: its own length)
   const AttnBlock blk = attn_seq_block(a);
   if (!blk.valid) return;  // (whole workgroup)
   const int b = blk.by / a.A, h = blk.by % a.A;
+  int64_t tok0 = (int64_t)b * a.L;
+  if (a.offs) {  // packed rows: the sequence starts at its offset and is as long as it is
+    const int o0 = a.offs[b];
+    L = a.offs[b + 1] - o0;
+    tok0 = o0;
+    if (L <= 0) return;  // (whole workgroup)
+  }
   const int Lp = ((L + 31) / 32) * 32, nt = Lp / 32;
   __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sDO = sQ + Lp * DH;
@@ -1164,7 +1189,6 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_roles_bf16_kernel(const AttnA
   uint32_t* sRowKey = reinterpret_cast<uint32_t*>(sDelta + Lp);
   uint32_t* sBits = sRowKey + Lp;  // key mask, one bit per key (Lp / 32 + 2 words)
 
-  const int64_t tok0 = (int64_t)b * L;
   const int64_t hoff = tok0 * H + h * DH;
   {
     // one round trip: the Q, K, V, dO and ctx pieces of a row chunk are loaded together (all loads of a thread's two
@@ -1187,7 +1211,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_roles_bf16_kernel(const AttnA
           vv[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.qkv, qo + 2 * H));
           vd[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.d_ctx, hoff + (int64_t)r * H + e));
           vo[u] = *reinterpret_cast<const uint4*>(xf_at<S16>(a.ctx, hoff + (int64_t)r * H + e));
-          if (pc == 0) ls[u] = a.lse[(int64_t)blk.by * L + r] * kLog2e;
+          if (pc == 0) ls[u] = a.lse[(int64_t)blk.by * a.L + r] * kLog2e;
         }
       }
 #pragma unroll
@@ -1222,7 +1246,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_roles_bf16_kernel(const AttnA
         if (c < total && pc == 0) {
           sDelta[r] = part;
           sLse[r] = ls[u];
-          sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * L + r));
+          sRowKey[r] = xf_drop_rowkey(a.drop, (uint32_t)((int64_t)blk.by * a.L + r));
         }
       }
     }
@@ -1405,7 +1429,8 @@ constexpr size_t kLdsLimit = 160 * 1024;
 template <bool S16>
 int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
   static const int two_blocks = [] { const char* e = getenv("XFMR_ATTN_FWD_SPLIT"); return e ? atoi(e) : 0; }();
-  if (!two_blocks && a.causal && a.L <= kFusedMaxL) {  // the one-workgroup forms walk the causal triangle only
+  if (a.offs && !(a.causal && a.L <= kFusedMaxL)) return XFMR_EUNSUPPORTED;  // packed rows: the one-workgroup forms only
+  if ((!two_blocks || a.offs) && a.causal && a.L <= kFusedMaxL) {  // the one-workgroup forms walk the causal triangle only
     const size_t sf = bf16_smem_fwd_seq(a.L);
     if (hipFuncSetAttribute((const void*)attn_fwd_seq_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sf) != hipSuccess)
@@ -1435,7 +1460,8 @@ int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
   // pairs x ~2 800 issue cycles per (batch, head) against 28 x ~2 000) -- not the default. DESIGN.md section 4.
   const char* form = getenv("XFMR_ATTN_BWD_FORM");
   const bool roles = form && form[0] == 'r';
-  if (!two_kernels && roles && a.causal && a.L <= kFusedMaxL) {
+  if (a.offs && !(a.causal && a.L <= kFusedMaxL)) return XFMR_EUNSUPPORTED;  // packed rows: the one-workgroup forms only
+  if ((!two_kernels || a.offs) && roles && a.causal && a.L <= kFusedMaxL) {
     const size_t sr = bf16_smem_roles(a.L);
     if (hipFuncSetAttribute((const void*)attn_bwd_roles_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sr) != hipSuccess)
@@ -1445,7 +1471,7 @@ int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
     return XFMR_OK;
   }
   const size_t sf = bf16_smem_fused(a.L);
-  if (!two_kernels && a.causal && a.L <= kFusedMaxL && sf <= kLdsLimit) {
+  if ((!two_kernels || a.offs) && a.causal && a.L <= kFusedMaxL && sf <= kLdsLimit) {
     if (hipFuncSetAttribute((const void*)attn_bwd_fused_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sf) != hipSuccess)
       return XFMR_EHIP;
@@ -1501,6 +1527,7 @@ int launch_bwd_generic(const AttnArgs& a, hipStream_t st) {
 // precision x storage x head size -> kernel family
 int dispatch_fwd(const AttnArgs& a, int precision, bool s16, hipStream_t st) {
   const int dh = a.H / a.A;
+  if (a.offs && !(precision == XFMR_PREC_BF16 && dh == 32)) return XFMR_EUNSUPPORTED;  // packed rows: production kernels only
   if (precision == XFMR_PREC_BF16) {
     if (dh == 32) return s16 ? launch_fwd_bf16<true>(a, st) : launch_fwd_bf16<false>(a, st);
     return s16 ? launch_fwd_generic<PrecBF16, 64, true>(a, st) : launch_fwd_generic<PrecBF16, 64, false>(a, st);
@@ -1511,6 +1538,7 @@ int dispatch_fwd(const AttnArgs& a, int precision, bool s16, hipStream_t st) {
 }
 int dispatch_bwd(const AttnArgs& a, int precision, bool s16, hipStream_t st) {
   const int dh = a.H / a.A;
+  if (a.offs && !(precision == XFMR_PREC_BF16 && dh == 32)) return XFMR_EUNSUPPORTED;
   if (precision == XFMR_PREC_BF16) {
     if (dh == 32) return s16 ? launch_bwd_bf16<true>(a, st) : launch_bwd_bf16<false>(a, st);
     return s16 ? launch_bwd_generic<PrecBF16, 64, true>(a, st) : launch_bwd_generic<PrecBF16, 64, false>(a, st);
@@ -1532,13 +1560,13 @@ extern "C" {
 
 int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t A,
                    int32_t H, float dropout_p, XfSeed seed, uint32_t site, int32_t precision, bool s16,
-                   bool causal, hipStream_t st) {
+                   bool causal, hipStream_t st, const int32_t* seq_offsets) {
   if (!qkv || !key_mask || !ctx || !lse) return XFMR_EINVAL;
   if (int rc = check_shape(B, L, A, H)) return rc;
   if (!xf_aligned16(qkv) || !xf_aligned16(ctx)) return XFMR_EALIGN;
   AttnArgs a{};
   a.qkv = (const float*)qkv; a.key_mask = key_mask; a.ctx = (float*)ctx; a.lse = lse; a.B = B; a.L = L; a.A = A;
-  a.H = H; a.causal = causal;
+  a.H = H; a.causal = causal; a.offs = seq_offsets;
   a.drop = xf_make_dropout(dropout_p, seed, site);
   return dispatch_fwd(a, precision, s16, st);
 }
@@ -1559,14 +1587,14 @@ int xfmr_attn_fwd_mode(const float* qkv, const uint8_t* key_mask, float* ctx, fl
 
 int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* d_ctx,
                    void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, XfSeed seed,
-                   uint32_t site, int32_t precision, bool s16, bool causal, hipStream_t st) {
+                   uint32_t site, int32_t precision, bool s16, bool causal, hipStream_t st, const int32_t* seq_offsets) {
   if (!qkv || !key_mask || !ctx || !lse || !d_ctx || !d_qkv) return XFMR_EINVAL;
   if (int rc = check_shape(B, L, A, H)) return rc;
   if (!xf_aligned16(qkv) || !xf_aligned16(ctx) || !xf_aligned16(d_ctx) || !xf_aligned16(d_qkv)) return XFMR_EALIGN;
   AttnArgs a{};
   a.qkv = (const float*)qkv; a.key_mask = key_mask; a.ctx = (float*)const_cast<void*>(ctx);
   a.lse = const_cast<float*>(lse); a.d_ctx = (const float*)d_ctx; a.d_qkv = (float*)d_qkv;
-  a.B = B; a.L = L; a.A = A; a.H = H; a.causal = causal;
+  a.B = B; a.L = L; a.A = A; a.H = H; a.causal = causal; a.offs = seq_offsets;
   a.drop = xf_make_dropout(dropout_p, seed, site);
   return dispatch_bwd(a, precision, s16, st);
 }

@@ -213,6 +213,15 @@ int check_cfg(const xfmr_encoder_cfg* c) {
   if (c->precision != XFMR_PREC_F32 && c->precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   if (c->flags & ~(uint32_t)XFMR_ENC_FLAGS_ALL) return XFMR_EINVAL;  // unknown flag bits
   if (c->profile_kernel < XFMR_PROF_NONE || c->profile_kernel > XFMR_PROF_REDUCE) return XFMR_EINVAL;
+  if (c->seq_offsets) {  // packed rows (ABI 3)
+    if (!c->row_pos || c->packed_rows <= 0 || c->packed_rows > (int64_t)c->batch * c->seq_len) return XFMR_EINVAL;
+    // the kernels that walk a sequence by its offsets: the bf16 policy's one-workgroup attention forms (head size 32, causal,
+    // seq_len <= 256); everything else is row-wise and does not care
+    if (!mixed_storage(c) || c->hidden != c->heads * 32 || c->seq_len > 256 || (c->flags & XFMR_ENC_BIDIRECTIONAL))
+      return XFMR_EUNSUPPORTED;
+  } else if (c->row_pos || c->packed_rows) {
+    return XFMR_EINVAL;
+  }
   return XFMR_OK;
 }
 
@@ -319,7 +328,11 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
   const Acts a = carve(cfg, base, -1, nullptr);
   if (acts_bytes < a.total) return XFMR_EWORKSPACE;
   const int B = cfg->batch, L = cfg->seq_len, H = cfg->hidden, I = cfg->inter, A = cfg->heads;
-  const int64_t T = (int64_t)B * L;
+  // Tplan: what the workspace is carved for and the fusion decisions are made with (batch x seq_len, the same in the forward
+  // and the backward of a step); T: the rows the row-wise kernels run -- fewer in the packed layout
+  const int64_t Tplan = (int64_t)B * L;
+  const int32_t* const offs = cfg->seq_offsets;
+  const int64_t T = offs ? cfg->packed_rows : Tplan;
   const int prec = cfg->precision;
   const bool mix = mixed_storage(cfg);
   const bool causal = !(cfg->flags & XFMR_ENC_BIDIRECTIONAL);
@@ -327,9 +340,15 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
   const XfSeed sd(cfg->seed, cfg->step_device);
   ParamLayout pl;
   layer_base(cfg, 0, &pl);
-  XF_TRY(xf_embed_ln_fwd_ex(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
-                            params + pl.eb, a.x0, mix ? a.x0b : nullptr, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask, B,
-                            L, H, cfg->ln_eps, cfg->hidden_dropout, sd, SITE_EMB, st));
+  if (offs) {
+    XF_TRY(xf_embed_ln_fwd_packed_ex(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
+                                     params + pl.eb, a.x0, mix ? a.x0b : nullptr, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask,
+                                     T, cfg->row_pos, H, cfg->ln_eps, cfg->hidden_dropout, sd, SITE_EMB, st));
+  } else {
+    XF_TRY(xf_embed_ln_fwd_ex(item_idx, table, n_rows, params + pl.pos, params + pl.type, params + pl.eg,
+                              params + pl.eb, a.x0, mix ? a.x0b : nullptr, a.emb_pre, a.emb_mean, a.emb_rstd, key_mask, B,
+                              L, H, cfg->ln_eps, cfg->hidden_dropout, sd, SITE_EMB, st));
+  }
   if (cfg->embed_event && hipEventRecord((hipEvent_t)cfg->embed_event, st) != hipSuccess) return XFMR_EHIP;  // key_mask is written
   const float* x = a.x0;
   const void* xg = mix ? a.x0b : (const void*)a.x0;  // the same activations as the GEMM operand
@@ -341,8 +360,8 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
     XF_LAUNCH_CHECK();
   }
   const uint32_t sB = mix ? XF_S16_B : 0;
-  const bool fuse_ln = ln_fused(cfg, T);  // LayerNorm in the out-proj / FFN2 GEMM epilogues
-  const bool fuse_ffn = ffn_fused(cfg, T);
+  const bool fuse_ln = ln_fused(cfg, Tplan);  // LayerNorm in the out-proj / FFN2 GEMM epilogues
+  const bool fuse_ffn = ffn_fused(cfg, Tplan);
   auto W = [&](int64_t off) -> const float* {  // weight operand: the bf16 copy under mixed storage
     return mix ? reinterpret_cast<const float*>((const __bf16*)a.wbf + off) : params + off;
   };
@@ -355,7 +374,7 @@ int xfmr_encoder_fwd(const xfmr_encoder_cfg* cfg, const float* params, const int
                             0.f, 0, 0, prec, (mix ? XF_S16_C : 0) | sA | sB, st));
     XF_TRY(prof(cfg, XFMR_PROF_ATTN_FWD, i, 0, st));
     XF_TRY(xf_attn_fwd_ex(l.qkv, key_mask, l.ctx, l.lse, B, L, A, H, cfg->attn_dropout, sd, site_attn(i), prec,
-                          mix, causal, st));
+                          mix, causal, st, offs));
     XF_TRY(prof(cfg, XFMR_PROF_ATTN_FWD, i, 1, st));
     if (fuse_ln) {  // LayerNorm in the GEMM epilogue (the tile spans whole rows)
       XF_TRY(xf_linear_ln_fwd_ex(l.ctx, W(p.wo), params + p.bo, l.pre1, T, H, H, x, cfg->hidden_dropout, sd,
@@ -409,7 +428,9 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   hipStream_t st = (hipStream_t)stream;
   const XfSeed sd(cfg->seed, cfg->step_device);
   const int B = cfg->batch, L = cfg->seq_len, H = cfg->hidden, I = cfg->inter, A = cfg->heads;
-  const int64_t T = (int64_t)B * L;
+  const int64_t Tplan = (int64_t)B * L;  // (see xfmr_encoder_fwd)
+  const int32_t* const offs = cfg->seq_offsets;
+  const int64_t T = offs ? cfg->packed_rows : Tplan;
   const int prec = cfg->precision;
   const bool hdrop = cfg->hidden_dropout > 0.f;
   const bool mix = mixed_storage(cfg);
@@ -428,7 +449,8 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   XfReduceSeg segs[12 * 64 + 2], segs_hi[12 * 64 + 2];
   int nseg = 0, nseg_hi = 0;
   if (cfg->layers > 64) return XFMR_EUNSUPPORTED;
-  const int half_layer = (cfg->grads_half_event && cfg->layers >= 2) ? cfg->layers / 2 : -1;
+  const int half_layer = ((cfg->grads_half_event || (cfg->flags & XFMR_ENC_REDUCE_HALF_EARLY)) && cfg->layers >= 2)
+                             ? cfg->layers / 2 : -1;
   const float* const hi_begin = half_layer >= 0 ? grads + layer_params(cfg, half_layer).wqkv : nullptr;
   auto seg = [&](const float* src, float* dst, int rows, int64_t cols, int64_t ld) {
     if (hi_begin && dst >= hi_begin) segs_hi[nseg_hi++] = XfReduceSeg{src, dst, rows, (int)cols, (int)ld, 0};
@@ -437,8 +459,8 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   // LayerNorm backward in the epilogue of the dX GEMM that produces its input gradient (whole-row 64 x 128 tiles: same
   // conditions as the forward fusion): LN1 with the FFN1 dX GEMM of its layer, LN2 of layer i-1 with the QKV dX GEMM of
   // layer i. The top layer's LN2 and the embedding LayerNorm keep their own launches.
-  const bool fuse_lnb = ln_fused(cfg, T);
-  const bool fuse_ffn = ffn_fused(cfg, T);  // what the forward of this step did
+  const bool fuse_lnb = ln_fused(cfg, Tplan);
+  const bool fuse_ffn = ffn_fused(cfg, Tplan);  // what the forward of this step did
   const bool no_ffn_bwd = (cfg->flags & XFMR_ENC_FFN_BWD_UNFUSED) != 0;
   // The weight-gradient GEMMs (16 of the backward's launches, 0.49 ms at batch 512) run on the LOW-PRIORITY side stream of
   // the caller's xfmr_context: the dX -> LayerNorm -> attention chain keeps the CUs it wants, and the dW workgroups fill
@@ -452,7 +474,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   XfContext* const ctx = (XfContext*)cfg->context;
   // (the per-layer gradient buffers make this independent of the LayerNorm-fused forms: a dW GEMM only ever reads dLinF /
   //  dLinO / dI / dQKV of ITS layer and activations of the forward)
-  const bool dw_side = ctx && dw_side_shape(cfg, T) && !(cfg->flags & XFMR_ENC_DW_INLINE);
+  const bool dw_side = ctx && dw_side_shape(cfg, Tplan) && !(cfg->flags & XFMR_ENC_DW_INLINE);
   hipStream_t const side = dw_side ? ctx->side : nullptr;
   hipEvent_t const ev_in = dw_side ? ctx->ev_in : nullptr, ev_done = dw_side ? ctx->ev_done : nullptr;
   bool side_used = false;
@@ -548,7 +570,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     XF_TRY(xf_linear_bwd_dx_ex(dlin, W(p.wo), a.dCtx, T, H, H, nullptr, nullptr, prec, sA | sC | sB, st));  // d(ctx)
     XF_TRY(prof(cfg, XFMR_PROF_ATTN_BWD, i, 0, st));
     XF_TRY(xf_attn_bwd_ex(l.qkv, key_mask, l.ctx, l.lse, a.dCtx, dQKV, B, L, A, H, cfg->attn_dropout, sd,
-                          site_attn(i), prec, mix, causal, st));
+                          site_attn(i), prec, mix, causal, st, offs));
     XF_TRY(prof(cfg, XFMR_PROF_ATTN_BWD, i, 1, st));
     if (group_dw) {
       const XfDwItem items[4] = {
@@ -595,7 +617,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
     if (i == half_layer) {  // every producer of the upper half's slabs / records is enqueued: finish that half now
       hipStream_t rs = dw_stream();  // (the side stream when the dW GEMMs run there: the chain itself does not wait)
       XF_TRY(xf_multi_rowsum(segs_hi, nseg_hi, rs));
-      if (hipEventRecord((hipEvent_t)cfg->grads_half_event, rs) != hipSuccess) return XFMR_EHIP;
+      if (cfg->grads_half_event && hipEventRecord((hipEvent_t)cfg->grads_half_event, rs) != hipSuccess) return XFMR_EHIP;
     }
   }
   ParamLayout pl;
@@ -614,7 +636,8 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   // only layer 0's are left for the end: 3.41 vs 3.34 ms/step -- the low-priority reductions slow the chain's tail.)
   // the position / type embedding gradients need only the chain's last output: in front of the join, underneath whatever
   // the side stream still has to do
-  XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
+  if (offs) XF_TRY(xf_embed_param_grads_packed(a.dA, grads + pl.pos, grads + pl.type, offs, B, L, H, cfg->max_pos, st));
+  else XF_TRY(xfmr_embed_param_grads(a.dA, grads + pl.pos, grads + pl.type, B, L, H, cfg->max_pos, stream));
   return XFMR_OK;
   }();
   if (side_used) {  // the chain joins the side stream: the reduction launch reads every slab

@@ -27,6 +27,9 @@
 #ifndef XF_GEMM_PF
 #define XF_GEMM_PF 1  // operand K slices in flight per workgroup (gemm_kernel)
 #endif
+#ifndef XF_DW_PF
+#define XF_DW_PF 1    // ... of the split-K weight-gradient GEMMs (experiment builds: -DXF_DW_PF=2)
+#endif
 // Barrier of the fused FFN kernels' chunk loops. 1: s_waitcnt lgkmcnt(0) + s_barrier through inline asm -- the LDS hand-off
 // only; __syncthreads() (and __builtin_amdgcn_s_barrier: the backend puts s_waitcnt 0 in front of every S_BARRIER on
 // this target) also drains vmcnt, i.e. every weight / activation prefetch issued since the last barrier.
@@ -638,7 +641,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g_in, const int bid) {
   // 58 more VGPRs, one workgroup fewer per CU, 3.77 against 3.67 ms/step -- co-resident workgroups hide the round
   // trips better than a deeper prefetch inside one; a launch bound of 5 waves for the forward GEMMs (96 VGPRs) changed
   // nothing (3.758 / 3.759). One slice it stays.
-  constexpr int PF = EPI == EPI_SPLITK ? 1 : XF_GEMM_PF;  // (split-K dW: a dozen 128-deep slices; one workgroup more per CU wins)
+  constexpr int PF = EPI == EPI_SPLITK ? XF_DW_PF : XF_GEMM_PF;  // (split-K dW: a dozen 128-deep slices; one workgroup more per CU wins)
   TileA ta[PF];
   TileB tb[PF];
   const bool do_bias = (EPI == EPI_SPLITK) && TA && g.bias_part != nullptr && tix.n == 0;

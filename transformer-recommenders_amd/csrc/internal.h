@@ -53,10 +53,11 @@ int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st);
 int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st);
 int xf_attn_fwd_ex(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t A,
                    int32_t H, float dropout_p, XfSeed seed, uint32_t site, int32_t precision, bool s16,
-                   bool causal, hipStream_t st);
+                   bool causal, hipStream_t st, const int32_t* seq_offsets = nullptr);  // packed rows: xfmr_encoder_cfg
 int xf_attn_bwd_ex(const void* qkv, const uint8_t* key_mask, const void* ctx, const float* lse, const void* d_ctx,
                    void* d_qkv, int32_t B, int32_t L, int32_t A, int32_t H, float dropout_p, XfSeed seed,
-                   uint32_t site, int32_t precision, bool s16, bool causal, hipStream_t st);
+                   uint32_t site, int32_t precision, bool s16, bool causal, hipStream_t st,
+                   const int32_t* seq_offsets = nullptr);
 // loss.hip: deterministic totals of per-block fp64 records [24][nblocks] (each block = rows_per_block queries) ->
 // losses[14], stats[16]; counts = device {n_valid, n_query}; tot = 24 doubles of scratch
 int xf_loss_finalize(const double* blockpart, int nblocks, int rows_per_block, const int* counts, int mode,
@@ -90,6 +91,12 @@ int xf_embed_ln_fwd_ex(const int64_t* item_idx, const float* table, int64_t n_ro
                        const float* type_emb, const float* gamma, const float* beta, float* out, void* out16,
                        float* pre, float* mean, float* rstd, uint8_t* key_mask, int32_t B, int32_t L, int32_t H,
                        float eps, float dropout_p, XfSeed seed, uint32_t site, hipStream_t stream);
+int xf_embed_ln_fwd_packed_ex(const int64_t* item_idx, const float* table, int64_t n_rows, const float* pos_emb,
+                              const float* type_emb, const float* gamma, const float* beta, float* out, void* out16,
+                              float* pre, float* mean, float* rstd, uint8_t* key_mask, int64_t rows, const int32_t* row_pos,
+                              int32_t H, float eps, float dropout_p, XfSeed seed, uint32_t site, hipStream_t stream);
+int xf_embed_param_grads_packed(const float* d_pre, float* d_pos, float* d_type, const int32_t* offs, int32_t B, int32_t L,
+                                int32_t H, int32_t max_pos, hipStream_t st);
 int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           float* dx, void* d_lin, bool lin16, float* d_gamma, float* d_beta, float* d_bias,
                           int64_t rows, int32_t H, XfDropout drop_out, XfDropout drop_lin, void* partials,

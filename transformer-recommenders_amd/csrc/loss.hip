@@ -1063,12 +1063,12 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
     const int nb = (T + kValueRows - 1) / kValueRows;
     hipLaunchKernelGGL(loss_combine_kernel<true>, dim3(nb), dim3(256), 0, st, c);
     XF_LAUNCH_CHECK();
-    return xf_loss_finalize(c.blockpart, nb, kValueRows, counts, cfg->mode, n_rows, T, losses, stats,
+    return xf_loss_finalize(c.blockpart, nb, kValueRows, counts, cfg->mode, n_rows, cfg->padded_positions > 0 ? cfg->padded_positions : (int64_t)T, losses, stats,
                             (double*)(ws + p.off_tot), st);
   }
   hipLaunchKernelGGL(loss_combine_kernel<false>, dim3(p.nblocks), dim3(256), 0, st, c);
   XF_LAUNCH_CHECK();
-  return xf_loss_finalize(c.blockpart, p.nblocks, kCombineRows, counts, cfg->mode, n_rows, T, losses, stats,
+  return xf_loss_finalize(c.blockpart, p.nblocks, kCombineRows, counts, cfg->mode, n_rows, cfg->padded_positions > 0 ? cfg->padded_positions : (int64_t)T, losses, stats,
                           (double*)(ws + p.off_tot), st);
 }
 

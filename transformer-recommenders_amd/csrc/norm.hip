@@ -18,6 +18,7 @@ struct LnFwdArgs {
   const int64_t* idx;      // GATHER: item index per row
   const float* table; int64_t n_rows;
   const float* pos_emb; const float* type_emb; int L;
+  const int32_t* row_pos;  // GATHER, packed rows (xfmr_encoder_cfg.row_pos): the row's position; null: row % L
   const float* gamma; const float* beta;
   float* y; float* pre; float* mean; float* rstd; uint8_t* key_mask;
   int64_t rows; int H; float eps;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a_in) {
     int64_t item = a.idx[row];
     if (item < 0 || item >= a.n_rows) item = 0;
     const float* src = a.table + item * H;
-    const float* pe = a.pos_emb + (int64_t)(row % a.L) * H;
+    const float* pe = a.pos_emb + (int64_t)(a.row_pos ? a.row_pos[row] : (int)(row % a.L)) * H;
     bool nz = false;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const LnFwdArgs a_in) {
       const float4 e = *reinterpret_cast<const float4*>(a.table + item * H + c);
       nz = (e.x != 0.f) | (e.y != 0.f) | (e.z != 0.f) | (e.w != 0.f);
       const float4 ty = *reinterpret_cast<const float4*>(a.type_emb + c);
-      const float4 pe = *reinterpret_cast<const float4*>(a.pos_emb + (int64_t)(row % a.L) * H + c);
+      const float4 pe = *reinterpret_cast<const float4*>(a.pos_emb + (int64_t)(a.row_pos ? a.row_pos[row] : (int)(row % a.L)) * H + c);
       v.x = (e.x + ty.x) + pe.x; v.y = (e.y + ty.y) + pe.y; v.z = (e.z + ty.z) + pe.z; v.w = (e.w + ty.w) + pe.w;
       *reinterpret_cast<float4*>(a.pre + row * H + c) = v;
     }
@@ -524,6 +525,70 @@ int ln_bwd_blocks(int64_t rows, int* rows_per_block) {
   return (int)((rows + rpb - 1) / rpb);
 }
 
+
+// ---- packed rows (xfmr_encoder_cfg.seq_offsets) ----------------------------------------------------------------------
+// one block row per sequence: rows [0, len_b) of the three (B, L) index tensors -> their packed places
+__global__ __launch_bounds__(256) void pack_rows_kernel(const int64_t* hist, const int64_t* pos, const int64_t* neg,
+                                                        const int64_t* offs64, int L, int64_t packed_rows, int64_t* hist_p,
+                                                        int64_t* pos_p, int64_t* neg_p, int32_t* offs32, int32_t* row_pos) {
+  const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+  const int64_t o0 = offs64[b], o1 = offs64[b + 1];
+  if (l == 0) {
+    offs32[b] = (int32_t)o0;
+    if (b == (int)gridDim.y - 1) offs32[b + 1] = (int32_t)o1;
+  }
+  const int64_t len = o1 - o0;
+  if (l >= len || len > L || o0 + l >= packed_rows) return;  // (a malformed offset table writes nothing out of range)
+  const int64_t src = (int64_t)b * L + l, dst = o0 + l;
+  hist_p[dst] = hist[src];
+  pos_p[dst] = pos[src];
+  if (neg) neg_p[dst] = neg[src];
+  row_pos[dst] = l;
+}
+// position-embedding gradient from packed rows: one block of 16 waves per position p; wave w adds the sequences
+// b = w, w + 16, ... that are longer than p (loads of eight sequences in flight), the waves are combined through LDS in
+// wave order: a fixed order, bit-reproducible
+__global__ __launch_bounds__(1024) void pos_grad_packed_kernel(const float* d_pre, float* d_pos, const int32_t* offs, int B,
+                                                               int H) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [16][H]
+  const int p = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc[kMaxPerLane];
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) acc[i] = 0.f;
+  for (int b0 = w; b0 < B; b0 += 16 * 8) {
+    int row[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 16 * u;
+      row[u] = -1;
+      if (b < B) {
+        const int o0 = offs[b], len = offs[b + 1] - o0;
+        if (p < len) row[u] = o0 + p;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (row[u] < 0) continue;  // (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < kMaxPerLane; ++i) {
+        const int c = lane + 64 * i;
+        if (c < H) acc[i] += d_pre[(int64_t)row[u] * H + c];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    if (c < H) red[w * H + c] = acc[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 1024) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q * H + c];
+    d_pos[(int64_t)p * H + c] = s;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -547,6 +612,23 @@ int xf_embed_ln_fwd_ex(const int64_t* item_idx, const float* table, int64_t n_ro
   a.x = nullptr; a.idx = item_idx; a.table = table; a.n_rows = n_rows; a.pos_emb = pos_emb; a.type_emb = type_emb;
   a.L = L; a.gamma = gamma; a.beta = beta; a.y = out; a.pre = pre; a.mean = mean; a.rstd = rstd;
   a.key_mask = key_mask; a.rows = (int64_t)B * L; a.H = H; a.eps = eps;
+  a.drop = xf_make_dropout(dropout_p, seed, site);
+  a.y16 = reinterpret_cast<__bf16*>(out16);
+  return launch_ln_fwd<true>(a, stream);
+}
+
+// packed rows (xfmr_encoder_cfg.seq_offsets): `rows` packed rows, row r adds position row_pos[r]
+int xf_embed_ln_fwd_packed_ex(const int64_t* item_idx, const float* table, int64_t n_rows, const float* pos_emb,
+                              const float* type_emb, const float* gamma, const float* beta, float* out, void* out16,
+                              float* pre, float* mean, float* rstd, uint8_t* key_mask, int64_t rows, const int32_t* row_pos,
+                              int32_t H, float eps, float dropout_p, XfSeed seed, uint32_t site, hipStream_t stream) {
+  if (!item_idx || !table || !pos_emb || !type_emb || !gamma || !beta || !out || !pre || !mean || !rstd || !key_mask || !row_pos)
+    return XFMR_EINVAL;
+  if (rows <= 0 || H <= 0 || n_rows <= 0) return XFMR_EINVAL;
+  LnFwdArgs a{};
+  a.x = nullptr; a.idx = item_idx; a.table = table; a.n_rows = n_rows; a.pos_emb = pos_emb; a.type_emb = type_emb;
+  a.L = 1; a.row_pos = row_pos; a.gamma = gamma; a.beta = beta; a.y = out; a.pre = pre; a.mean = mean; a.rstd = rstd;
+  a.key_mask = key_mask; a.rows = rows; a.H = H; a.eps = eps;
   a.drop = xf_make_dropout(dropout_p, seed, site);
   a.y16 = reinterpret_cast<__bf16*>(out16);
   return launch_ln_fwd<true>(a, stream);
@@ -627,6 +709,32 @@ int xfmr_embed_param_grads(const float* d_pre, float* d_pos, float* d_type, int3
   // d_type[0] = column sums of d_pos viewed as [L][H]; d_type[1] = 0 (token type 1 is never used)
   if (int rc = xf_rowsum(d_type, d_pos, L, H, st)) return rc;
   if (xf_zero_async(d_type + H, (size_t)H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
+  return XFMR_OK;
+}
+
+// packed rows: d_pos[p] = sum over the sequences longer than p of d_pre[offs[b] + p] (ascending b: a fixed order)
+int xf_embed_param_grads_packed(const float* d_pre, float* d_pos, float* d_type, const int32_t* offs, int32_t B, int32_t L,
+                                int32_t H, int32_t max_pos, hipStream_t st) {
+  if (!d_pre || !d_pos || !d_type || !offs || B <= 0 || L <= 0 || H <= 0 || max_pos < L) return XFMR_EINVAL;
+  if (H > 64 * kMaxPerLane) return XFMR_EUNSUPPORTED;
+  hipLaunchKernelGGL(pos_grad_packed_kernel, dim3((unsigned)max_pos), dim3(1024), (size_t)16 * H * sizeof(float), st, d_pre,
+                     d_pos, offs, B, H);
+  XF_LAUNCH_CHECK();
+  if (int rc = xf_rowsum(d_type, d_pos, L, H, st)) return rc;
+  if (xf_zero_async(d_type + H, (size_t)H * sizeof(float), st) != hipSuccess) return XFMR_EHIP;
+  return XFMR_OK;
+}
+
+int xfmr_pack_rows(const int64_t* hist, const int64_t* pos, const int64_t* neg, const int64_t* offsets64, int32_t batch,
+                   int32_t seq_len, int64_t packed_rows, int64_t* hist_p, int64_t* pos_p, int64_t* neg_p,
+                   int32_t* offsets32, int32_t* row_pos, void* stream) {
+  if (!hist || !pos || !offsets64 || !hist_p || !pos_p || !offsets32 || !row_pos) return XFMR_EINVAL;
+  if ((neg == nullptr) != (neg_p == nullptr)) return XFMR_EINVAL;
+  if (batch <= 0 || seq_len <= 0 || packed_rows < 0 || packed_rows > (int64_t)batch * seq_len) return XFMR_EINVAL;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((seq_len + 255) / 256), (unsigned)batch), dim3(256), 0,
+                     (hipStream_t)stream, hist, pos, neg, offsets64, seq_len, packed_rows, hist_p, pos_p, neg_p, offsets32,
+                     row_pos);
+  XF_LAUNCH_CHECK();
   return XFMR_OK;
 }
 

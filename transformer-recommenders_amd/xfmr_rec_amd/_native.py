@@ -24,9 +24,9 @@ NEG_SHARED, NEG_CATALOG = 0, 1
 ATTN_CAUSAL, ATTN_BIDIRECTIONAL = 0, 1  # xfmr_attn_{fwd,bwd}_mode
 # xfmr_encoder_cfg.flags
 ENC_BIDIRECTIONAL, ENC_LN_UNFUSED, ENC_FFN_UNFUSED, ENC_FFN_BWD_UNFUSED, ENC_DW_INLINE, ENC_DW_SIDE_ANY = 1, 2, 4, 8, 16, 32
-ENC_DW_UNPAIRED = 64
+ENC_DW_UNPAIRED, ENC_REDUCE_HALF_EARLY = 64, 128
 LOSS_DTOK_ZEROED = 1  # xfmr_loss_cfg.flags
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_LOSSES, NUM_STATS = 7, 16
 LOSS_IDS = {
     "AlignmentLoss": 0,
@@ -52,6 +52,8 @@ class EncoderCfg(C.Structure):
         ("step_device", C.c_void_p), ("embed_event", C.c_void_p), ("context", C.c_void_p),
         ("grads_half_event", C.c_void_p),
         ("profile_kernel", C.c_int32), ("profile_layer", C.c_int32), ("profile_events", C.c_void_p * 2),
+        # ABI 3: packed rows (all NULL / 0 = the padded (B, L) layout)
+        ("seq_offsets", C.c_void_p), ("row_pos", C.c_void_p), ("packed_rows", C.c_int64),
     ]
 
 
@@ -64,6 +66,7 @@ class LossCfg(C.Structure):
         ("mode", C.c_int32), ("precision", C.c_int32), ("scale", C.c_float), ("margin", C.c_float),
         ("num_hard_negatives", C.c_int32), ("flags", C.c_uint32),
         ("profile_grad", C.c_void_p * 2), ("profile_log", C.c_void_p * 2),
+        ("padded_positions", C.c_int64),  # ABI 3
     ]
 
 
@@ -103,6 +106,7 @@ _SIGNATURES = {
     "xfmr_param_offsets": (C.c_int32, [C.POINTER(EncoderCfg), C.POINTER(C.c_int64), C.c_int32]),
     "xfmr_embed_ln_fwd": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    "xfmr_pack_rows": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "xfmr_embed_param_grads": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "xfmr_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "xfmr_layernorm_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),

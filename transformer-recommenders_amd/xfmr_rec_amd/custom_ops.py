@@ -46,19 +46,8 @@ def _signed64(x: int) -> int:
     return x - (1 << 64) if x >= (1 << 63) else x
 
 
-def pack_encoder_cfg(cfg: N.EncoderCfg):
-    """xfmr_encoder_cfg -> the scalar arguments of xfmr::encoder (everything but batch / seq_len / hidden, which are
-    the tensors' shapes, and step_device, which is a tensor)."""
-    ev = cfg.profile_events
-    handles = [int(cfg.embed_event or 0), int(cfg.context or 0), int(cfg.grads_half_event or 0),
-               int(cfg.profile_kernel), int(cfg.profile_layer), int(ev[0] or 0), int(ev[1] or 0)]
-    return (int(cfg.heads), int(cfg.inter), int(cfg.layers), int(cfg.max_pos), _PREC_NAME[int(cfg.precision)],
-            float(cfg.ln_eps), float(cfg.hidden_dropout), float(cfg.attn_dropout), int(cfg.flags),
-            _signed64(int(cfg.seed)), [_signed64(h) for h in handles])
-
-
 def _encoder_cfg(B, L, H, heads, inter, layers, max_pos, precision, ln_eps, hidden_dropout, attn_dropout, flags, seed,
-                 step_device, handles) -> N.EncoderCfg:
+                 step_device, handles, seq_offsets=None, row_pos=None) -> N.EncoderCfg:
     h = [int(x) & _U64 for x in handles] + [0] * (N_HANDLES - len(handles))
     return N.EncoderCfg(
         batch=int(B), seq_len=int(L), hidden=int(H), heads=heads, inter=inter, layers=layers, max_pos=max_pos,
@@ -67,46 +56,62 @@ def _encoder_cfg(B, L, H, heads, inter, layers, max_pos, precision, ln_eps, hidd
         step_device=step_device.data_ptr() if step_device is not None else None,
         embed_event=h[0] or None, context=h[1] or None, grads_half_event=h[2] or None,
         profile_kernel=h[3], profile_layer=h[4], profile_events=(C.c_void_p * 2)(h[5] or None, h[6] or None),
+        seq_offsets=seq_offsets.data_ptr() if seq_offsets is not None else None,
+        row_pos=row_pos.data_ptr() if row_pos is not None else None,
+        packed_rows=int(row_pos.numel()) if row_pos is not None else 0,
     )
+
+
+def _batch_dims(item_idx, seq_offsets, packed_seq_len):
+    """(B, L) of the call: the index tensor's shape, or -- packed rows -- the offset table's length and the given seq_len."""
+    if seq_offsets is None:
+        B, L = item_idx.shape
+        return B, L
+    return seq_offsets.shape[0] - 1, packed_seq_len
 
 
 # ------------------------------------------------------------------------------------------------ encoder
 @torch.library.custom_op("xfmr::encoder", mutates_args=())
 def encoder(flat_params: Tensor, item_idx: Tensor, table: Tensor, heads: int, inter: int, layers: int, max_pos: int,
             precision: str, ln_eps: float, hidden_dropout: float, attn_dropout: float, flags: int, seed: int,
-            step_device: Optional[Tensor], handles: List[int]) -> Tuple[Tensor, Tensor, Tensor]:
-    """(token_embeddings (B,L,H) f32, key_mask (B,L) u8, saved activations (bytes) u8)."""
+            step_device: Optional[Tensor], handles: List[int], seq_offsets: Optional[Tensor], row_pos: Optional[Tensor],
+            packed_seq_len: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """(token_embeddings (B,L,H) f32, key_mask (B,L) u8, saved activations (bytes) u8). Packed rows (seq_offsets (B+1) i32,
+    row_pos (rows) i32, packed_seq_len = L; ops.pack_rows): item_idx (rows,) -> token_embeddings (rows,H), key_mask (rows)."""
     from . import ops
 
-    B, L = item_idx.shape
+    B, L = _batch_dims(item_idx, seq_offsets, packed_seq_len)
     cfg = _encoder_cfg(B, L, table.shape[1], heads, inter, layers, max_pos, precision, ln_eps, hidden_dropout,
-                       attn_dropout, flags, seed, step_device, handles)
+                       attn_dropout, flags, seed, step_device, handles, seq_offsets, row_pos)
     return ops.encoder_fwd(cfg, flat_params, item_idx, table)
 
 
 @encoder.register_fake
 def _(flat_params, item_idx, table, heads, inter, layers, max_pos, precision, ln_eps, hidden_dropout, attn_dropout, flags,
-      seed, step_device, handles):
-    B, L = item_idx.shape
+      seed, step_device, handles, seq_offsets, row_pos, packed_seq_len):
+    B, L = _batch_dims(item_idx, seq_offsets, packed_seq_len)
     H = table.shape[1]
     cfg = _encoder_cfg(B, L, H, heads, inter, layers, max_pos, precision, ln_eps, hidden_dropout, attn_dropout, flags, seed,
                        None, handles)
     nbytes = N.load().xfmr_encoder_workspace_bytes(C.byref(cfg))  # a host-side size computation: no device needed
     torch._check(nbytes > 0, lambda: "xfmr::encoder: unsupported encoder configuration")
-    return (flat_params.new_empty((B, L, H), dtype=torch.float32), flat_params.new_empty((B, L), dtype=torch.uint8),
+    rows = (row_pos.shape[0],) if seq_offsets is not None else (B, L)
+    return (flat_params.new_empty((*rows, H), dtype=torch.float32), flat_params.new_empty(rows, dtype=torch.uint8),
             flat_params.new_empty((max(int(nbytes), 16),), dtype=torch.uint8))
 
 
 @torch.library.custom_op("xfmr::encoder_bwd", mutates_args=("d_tok",))
 def encoder_bwd(flat_params: Tensor, d_tok: Tensor, key_mask: Tensor, acts: Tensor, heads: int, inter: int, layers: int,
                 max_pos: int, precision: str, ln_eps: float, hidden_dropout: float, attn_dropout: float, flags: int,
-                seed: int, step_device: Optional[Tensor], handles: List[int]) -> Tensor:
-    """Flat gradient of the encoder's trainable tensors; ``d_tok`` (B,L,H) is used as scratch (clobbered)."""
+                seed: int, step_device: Optional[Tensor], handles: List[int], seq_offsets: Optional[Tensor],
+                row_pos: Optional[Tensor], packed_seq_len: int) -> Tensor:
+    """Flat gradient of the encoder's trainable tensors; ``d_tok`` (B,L,H) -- (rows,H) packed -- is used as scratch."""
     from . import ops
 
-    B, L, H = d_tok.shape
+    H = d_tok.shape[-1]
+    B, L = (d_tok.shape[0], d_tok.shape[1]) if seq_offsets is None else (seq_offsets.shape[0] - 1, packed_seq_len)
     cfg = _encoder_cfg(B, L, H, heads, inter, layers, max_pos, precision, ln_eps, hidden_dropout, attn_dropout, flags, seed,
-                       step_device, handles)
+                       step_device, handles, seq_offsets, row_pos)
     return ops.encoder_bwd(cfg, flat_params, d_tok, key_mask, acts)
 
 
@@ -118,25 +123,29 @@ def _(flat_params, d_tok, key_mask, acts, *a):
 def _encoder_setup(ctx, inputs, output):
     flat_params, _idx, _table, *scalars = inputs
     _tok, key_mask, acts = output
-    step_device = scalars[-2]
-    ctx.scalars = scalars[:-2] + [scalars[-1]]
-    ctx.save_for_backward(flat_params, key_mask, acts, *([step_device] if step_device is not None else []))
+    step_device, handles, seq_offsets, row_pos, packed_seq_len = scalars[-5:]
+    ctx.scalars = scalars[:-5] + [handles]
+    ctx.packed_seq_len = packed_seq_len
+    ctx.have = (step_device is not None, seq_offsets is not None)
+    ctx.save_for_backward(flat_params, key_mask, acts, *[t for t in (step_device, seq_offsets, row_pos) if t is not None])
     ctx.set_materialize_grads(False)
 
 
 def _encoder_backward(ctx, d_tok, _d_mask, _d_acts):
-    n_in = 15
+    n_in = 18
     if d_tok is None:
         return (None,) * n_in
     flat_params, key_mask, acts, *rest = ctx.saved_tensors
-    step_device = rest[0] if rest else None
+    step_device = rest.pop(0) if ctx.have[0] else None
+    seq_offsets, row_pos = (rest[0], rest[1]) if ctx.have[1] else (None, None)
     d = d_tok.contiguous()
     # the kernel sequence uses this buffer as scratch: in place only when the producer handed it over (ops._consumable)
     # (`d is d_tok`: contiguous() returned its argument -- no data_ptr() here, this also runs on fake tensors when traced)
     if d is d_tok and not getattr(d_tok, "_xfmr_consumable", False):
         d = d.clone()
     *sc, handles = ctx.scalars
-    grads = torch.ops.xfmr.encoder_bwd(flat_params, d, key_mask, acts, *sc, step_device, handles)
+    grads = torch.ops.xfmr.encoder_bwd(flat_params, d, key_mask, acts, *sc, step_device, handles, seq_offsets, row_pos,
+                                       ctx.packed_seq_len)
     return (grads,) + (None,) * (n_in - 1)
 
 
@@ -158,6 +167,20 @@ def scale_by_device_scalar_(x: Tensor, g: Tensor) -> None:
 @scale_by_device_scalar_.register_fake
 def _(x, g):
     return None
+
+
+@torch.library.custom_op("xfmr::scale_by_device_scalar", mutates_args=())
+def scale_by_device_scalar(x: Tensor, g: Tensor) -> Tensor:
+    """x * g (g a device scalar) as a NEW tensor: what the registered autograd formulas use -- a backward that rescaled a
+    forward output in place is not a graph AOTAutograd's partitioner accepts ("node was invalid, but is output")."""
+    y = x.clone()
+    N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(y), y.numel(), N.ptr(g), N.stream()), "xfmr_scale_by_device_scalar")
+    return y
+
+
+@scale_by_device_scalar.register_fake
+def _(x, g):
+    return torch.empty_like(x)
 
 
 @torch.library.custom_op("xfmr::sampled_loss", mutates_args=())
@@ -202,8 +225,8 @@ def _make_loss_backward(hand_over: bool):
         (d,) = ctx.saved_tensors
         if g is None or d.numel() == 0:
             return (None,) * ctx.n_in
-        torch.ops.xfmr.scale_by_device_scalar_(d, g.contiguous().to(torch.float32))
-        if hand_over and not torch.is_grad_enabled():  # not under create_graph: the buffer is dead after this backward
+        d = torch.ops.xfmr.scale_by_device_scalar(d, g.contiguous().to(torch.float32))
+        if hand_over and not torch.is_grad_enabled():  # a fresh buffer: the encoder backward may use it as scratch
             d._xfmr_consumable = True
         return (d,) + (None,) * (ctx.n_in - 1)
 
@@ -276,11 +299,7 @@ def _dense_backward(ctx, g, _gl, _gs, _gq, _gc):
     g = g.contiguous().to(torch.float32)
     outs = []
     for t in ctx.saved_tensors:
-        if t.numel():
-            torch.ops.xfmr.scale_by_device_scalar_(t, g)
-            outs.append(t)
-        else:
-            outs.append(None)
+        outs.append(torch.ops.xfmr.scale_by_device_scalar(t, g) if t.numel() else None)
     return (outs[0], outs[1]) + (None,) * (ctx.n_in - 2)
 
 
@@ -360,4 +379,5 @@ def _(*a, **k):
 
 
 OP_NAMES = ("encoder", "encoder_bwd", "sampled_loss", "sampled_loss_lists", "dense_loss", "scale_by_device_scalar_",
+            "scale_by_device_scalar",
             "l2_normalize", "l2_normalize_bwd", "pool", "adamw_")

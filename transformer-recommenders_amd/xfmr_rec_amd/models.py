@@ -22,6 +22,8 @@ Differences that are deliberate and visible:
 
 from __future__ import annotations
 
+import os
+
 import json
 import pathlib
 from typing import Literal
@@ -314,7 +316,15 @@ class RecommenderModel(torch.nn.Module):
     def _cfg(self, B: int, L: int, embed_event=None) -> N.EncoderCfg:
         return ops.make_encoder_cfg(**self._cfg_kwargs(B, L, embed_event))
 
-    def _cfg_kwargs(self, B: int, L: int, embed_event=None) -> dict:
+    def supports_packed_rows(self, L: int) -> bool:
+        """Whether the encoder can run the PACKED layout (xfmr_encoder_cfg.seq_offsets: the token axis holds each sequence's own
+        rows only, no padding rows) for sequences of up to L rows: bf16 policy, head size 32, causal, L <= 256."""
+        c = self.config
+        return (self.precision == "bf16" and c.hidden_size == 32 * c.num_attention_heads and bool(c.is_decoder)
+                and min(L, self.max_seq_length) <= 256 and self.flat.is_cuda and os.environ.get("XFMR_ACT_FP32", "0") in ("", "0")
+                and os.environ.get("XFMR_PACKED", "1") != "0")
+
+    def _cfg_kwargs(self, B: int, L: int, embed_event=None, packed=None) -> dict:
         """make_encoder_cfg's keyword arguments for this model, in plain Python (traced code builds the scalar arguments
         of torch.ops.xfmr.encoder from them; eager code the xfmr_encoder_cfg)."""
         c = self.config
@@ -342,10 +352,18 @@ class RecommenderModel(torch.nn.Module):
             grads_half_event=getattr(self, "grads_half_event", None),  # set by distributed.HalvedAllReduce
             extra_flags=getattr(self, "enc_flags", 0),  # e.g. ENC_DW_SIDE_ANY inside a captured step (GraphedStep)
             profile=getattr(self, "enc_profile", None) if train else None,  # (kernel, layer, ev0, ev1): bench.py
+            seq_offsets=packed["seq_offsets"] if packed else None, row_pos=packed["row_pos"] if packed else None,
         )
 
-    def _encode_tokens(self, item_idx=None, item_embeds=None, embed_event=None):
+    def _encode_tokens(self, item_idx=None, item_embeds=None, embed_event=None, packed=None):
+        """tok, key_mask of the history. ``packed`` (ops.pack_rows's dict + "batch" / "seq_len"): the packed layout -- tok is
+        (rows, H), key_mask (rows,): only each sequence's own rows, in order."""
         assert self.embeddings is not None, "call configure_embeddings() first"
+        if packed is not None:
+            if self.training and not torch.compiler.is_compiling():
+                self._step += 1
+            kw = self._cfg_kwargs(int(packed["batch"]), int(packed["seq_len"]), embed_event, packed)
+            return ops.encoder(self.flat, packed["hist"], self.embeddings, kw)
         if item_embeds is not None:
             # the gather kernel reads rows by index: use the given embeddings as the table
             x = item_embeds[:, -self.max_seq_length :, :].to(self.device, torch.float32).contiguous()

@@ -280,7 +280,7 @@ def sampled_loss_prepare(ws, key_mask, pos_idx, neg_idx, rnorm, n_rows, H, *, tr
 def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, all_heads=True,
                  mask_false_negatives=True, mode=N.NEG_SHARED, scale=1.0, margin=0.5, precision="bf16",
                  need_grad=True, table_bf16=None, num_hard_negatives=0, workspace=None, prepared=False, d_tok_zeroed=None,
-                 profile_grad=None, profile_log=None, nsplit=0, nsplit_grad=0):
+                 profile_grad=None, profile_log=None, nsplit=0, nsplit_grad=0, padded_positions=0):
     """Returns (losses[7], stats[16], d_tok or None). tok: (T,H) or (B,L,H). `workspace` (sampled_loss_workspace) +
     `prepared=True`: sampled_loss_prepare already ran on it; `d_tok_zeroed`: a zero-filled buffer like tok to take the
     gradient (the call then skips its own memset); `profile_grad` / `profile_log`: (start, stop) hipEvent_t handles
@@ -295,7 +295,7 @@ def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, a
         assert d_tok.shape == tok.shape and d_tok.dtype == tok.dtype
         flags |= N.LOSS_DTOK_ZEROED
     cfg = _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision, num_hard_negatives,
-                    flags=flags, profile_grad=profile_grad, profile_log=profile_log)
+                    flags=flags, profile_grad=profile_grad, profile_log=profile_log, padded_positions=padded_positions)
     n_rows = table.shape[0]
     losses = _empty((2 * N.NUM_LOSSES,), tok)
     stats = _empty((N.NUM_STATS,), tok)
@@ -315,12 +315,12 @@ def sampled_loss(tok, key_mask, pos_idx, neg_idx, table, rnorm, *, train_head, a
 
 
 def _loss_cfg(train_head, all_heads, mask_false_negatives, mode, scale, margin, precision,
-              num_hard_negatives=0, *, flags=0, profile_grad=None, profile_log=None) -> N.LossCfg:
+              num_hard_negatives=0, *, flags=0, profile_grad=None, profile_log=None, padded_positions=0) -> N.LossCfg:
     cfg = N.LossCfg(
         train_head=N.LOSS_IDS[train_head] if isinstance(train_head, str) else int(train_head),
         all_heads=int(all_heads), mask_false_negatives=int(mask_false_negatives), mode=mode,
         precision=N.precision_id(precision), scale=float(scale), margin=float(margin),
-        num_hard_negatives=int(num_hard_negatives), flags=int(flags),
+        num_hard_negatives=int(num_hard_negatives), flags=int(flags), padded_positions=int(padded_positions),
     )
     if profile_grad is not None:  # (start, stop) hipEvent_t handles around the gradient-pass kernel
         cfg.profile_grad[0], cfg.profile_grad[1] = profile_grad
@@ -396,16 +396,21 @@ def encoder_flags_from_env() -> int:
         f |= N.ENC_DW_INLINE
     if os.environ.get("XFMR_DW_PAIR", "") == "0":
         f |= N.ENC_DW_UNPAIRED
+    if _env_on("XFMR_REDUCE_HALF_EARLY"):
+        f |= N.ENC_REDUCE_HALF_EARLY
     return f
 
 
 def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, precision, ln_eps=1e-12,
                      hidden_dropout=0.0, attn_dropout=0.0, seed=0, causal=True, flags=None, step_device=None,
-                     embed_event=None, context=None, grads_half_event=None, extra_flags=0, profile=None) -> N.EncoderCfg:
+                     embed_event=None, context=None, grads_half_event=None, extra_flags=0, profile=None,
+                     seq_offsets=None, row_pos=None) -> N.EncoderCfg:
     """``step_device``: a uint32 device tensor (or pointer) mixed into the dropout stream on the device;
     ``embed_event``: a hipEvent_t handle the forward records once the key mask exists; ``context``: an
     ``xfmr_context`` handle (side stream of the backward's weight-gradient GEMMs); ``profile``: (N.PROF_*, layer,
-    event0, event1) -- HIP events recorded around that part of the encoder (measurement)."""
+    event0, event1) -- HIP events recorded around that part of the encoder (measurement); ``seq_offsets`` (batch + 1,
+    int32) + ``row_pos`` (packed rows, int32): the PACKED layout (pack_rows) -- the token axis holds only each
+    sequence's own rows."""
     f = encoder_flags_from_env() if flags is None else int(flags)
     f |= int(extra_flags)
     if not causal:
@@ -420,6 +425,7 @@ def make_encoder_cfg(*, batch, seq_len, hidden, heads, inter, layers, max_pos, p
         context=context, grads_half_event=grads_half_event,
         profile_kernel=int(profile[0]) if profile else 0, profile_layer=int(profile[1]) if profile else 0,
         profile_events=(C.c_void_p * 2)(profile[2], profile[3]) if profile else (C.c_void_p * 2)(None, None),
+        seq_offsets=N.ptr(seq_offsets), row_pos=N.ptr(row_pos), packed_rows=0 if row_pos is None else int(row_pos.numel()),
     )
 
 
@@ -446,11 +452,32 @@ class Context:
             pass
 
 
+def pack_rows(hist, pos, neg, offsets64, rows: int):
+    """The PACKED layout of a collated batch (xfmr_pack_rows): hist / pos / neg (B, L) int64 device tensors (neg may be
+    None), offsets64 (B + 1) int64 on the device = the cumulative row lengths, ``rows`` = offsets64[-1] as the HOST knows
+    it (the collate padded the rows: it knows their lengths). Returns the packed (rows,) index tensors, ``seq_offsets``
+    (B + 1) int32 and ``row_pos`` (rows,) int32 for make_encoder_cfg."""
+    B, L = hist.shape
+    dev = hist.device
+    out = {k: torch.empty((rows,), dtype=torch.int64, device=dev) for k in ("hist", "pos")}
+    out["neg"] = torch.empty((rows,), dtype=torch.int64, device=dev) if neg is not None else None
+    out["seq_offsets"] = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    out["row_pos"] = torch.empty((rows,), dtype=torch.int32, device=dev)
+    N.check(N.load().xfmr_pack_rows(N.ptr(hist), N.ptr(pos), N.ptr(neg), N.ptr(offsets64), B, L, rows, N.ptr(out["hist"]),
+                                    N.ptr(out["pos"]), N.ptr(out["neg"]), N.ptr(out["seq_offsets"]), N.ptr(out["row_pos"]),
+                                    N.stream()), "xfmr_pack_rows")
+    return out
+
+
 def encoder_fwd(cfg: N.EncoderCfg, flat_params, item_idx, table):
     lib = N.load()
     T, H = cfg.batch * cfg.seq_len, cfg.hidden
-    tok = _empty((cfg.batch, cfg.seq_len, H), flat_params)
-    key_mask = _empty((cfg.batch, cfg.seq_len), flat_params, torch.uint8)
+    if cfg.packed_rows:  # packed layout: the token axis holds the sequences' own rows only
+        tok = _empty((cfg.packed_rows, H), flat_params)
+        key_mask = _empty((cfg.packed_rows,), flat_params, torch.uint8)
+    else:
+        tok = _empty((cfg.batch, cfg.seq_len, H), flat_params)
+        key_mask = _empty((cfg.batch, cfg.seq_len), flat_params, torch.uint8)
     nbytes = lib.xfmr_encoder_workspace_bytes(C.byref(cfg))
     if nbytes == 0:
         raise RuntimeError("xfmr_encoder_workspace_bytes: unsupported encoder configuration "
@@ -485,9 +512,10 @@ class EncoderFunction(torch.autograd.Function):
     """tok, key_mask = encoder(flat_params, item_idx); backward fills the flat gradient."""
 
     @staticmethod
-    def forward(ctx, flat_params, item_idx, table, cfg):
+    def forward(ctx, flat_params, item_idx, table, cfg, keep=None):
         tok, key_mask, acts = encoder_fwd(cfg, flat_params, item_idx, table)
         ctx.cfg = cfg
+        ctx.keep = keep  # tensors the cfg points into (packed layout: seq_offsets, row_pos) live until the backward has run
         ctx.save_for_backward(flat_params, key_mask, acts)
         ctx.mark_non_differentiable(key_mask)
         ctx.set_materialize_grads(False)  # no zero-filled gradient for the mask output
@@ -497,14 +525,39 @@ class EncoderFunction(torch.autograd.Function):
     def backward(ctx, d_tok, _d_mask):
         flat_params, key_mask, acts = ctx.saved_tensors
         if d_tok is None:
-            return None, None, None, None
+            return None, None, None, None, None
         d = d_tok.contiguous()
         # the kernel sequence reuses this buffer as scratch: it may only do so in place when the producer hands the
         # buffer over (the fused loss does: its saved gradient is dead after its own backward)
         if d.data_ptr() == d_tok.data_ptr() and not getattr(d_tok, "_xfmr_consumable", False):
             d = d.clone()
         grads = encoder_bwd(ctx.cfg, flat_params, d, key_mask, acts)
-        return grads, None, None, None
+        return grads, None, None, None, None
+
+
+_UNIT_GRADS: dict = {}
+
+
+def unit_grad(like: torch.Tensor) -> torch.Tensor:
+    """THE scalar 1 on `like`'s device, one persistent tensor per device. ``loss.backward(gradient=ops.unit_grad(loss))``
+    does what ``loss.backward()`` does without the per-step ones-fill launch, and the fused loss's backward recognises
+    the object and skips its `d_tok *= g` launch (two ~5 us launches between the loss and the encoder backward).
+    ``RecommenderLightningModule.backward`` -- Lightning's overridable hook -- passes it."""
+    key = (like.device.type, like.device.index)
+    t = _UNIT_GRADS.get(key)
+    if t is None:
+        t = _UNIT_GRADS[key] = torch.ones((), dtype=f32, device=like.device)
+    return t
+
+
+unit_grad_hits = 0  # backward calls that recognised the unit gradient (tests)
+
+
+def _is_unit_grad(g: torch.Tensor) -> bool:
+    global unit_grad_hits
+    hit = any(g is t for t in _UNIT_GRADS.values())
+    unit_grad_hits += int(hit)
+    return hit
 
 
 class SampledLossFunction(torch.autograd.Function):
@@ -528,9 +581,10 @@ class SampledLossFunction(torch.autograd.Function):
         if g is None:
             return (None,) * 7
         (d_tok,) = ctx.saved_tensors
-        g = g.contiguous().to(f32)
-        N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(d_tok), d_tok.numel(), N.ptr(g), N.stream()),
-                "xfmr_scale_by_device_scalar")
+        if not _is_unit_grad(g):  # (the persistent unit gradient: nothing to multiply by)
+            g = g.contiguous().to(f32)
+            N.check(N.load().xfmr_scale_by_device_scalar(N.ptr(d_tok), d_tok.numel(), N.ptr(g), N.stream()),
+                    "xfmr_scale_by_device_scalar")
         if not torch.is_grad_enabled():  # not under create_graph: the buffer is dead after this backward
             d_tok._xfmr_consumable = True
         return d_tok, None, None, None, None, None, None
@@ -604,7 +658,7 @@ def use_torch_ops() -> bool:
 
 def encoder_op_args(*, heads, inter, layers, max_pos, precision, ln_eps=1e-12, hidden_dropout=0.0, attn_dropout=0.0,
                     seed=0, causal=True, flags=None, step_device=None, embed_event=None, context=None,
-                    grads_half_event=None, extra_flags=0, profile=None, **_shape):
+                    grads_half_event=None, extra_flags=0, profile=None, seq_offsets=None, row_pos=None, seq_len=0, **_shape):
     """make_encoder_cfg's keyword arguments -> the scalar arguments of torch.ops.xfmr.encoder, in plain Python (no ctypes:
     this runs inside traced code). Returns (scalars..., step_device, handles)."""
     f = encoder_flags_from_env() if flags is None else int(flags)
@@ -617,7 +671,8 @@ def encoder_op_args(*, heads, inter, layers, max_pos, precision, ln_eps=1e-12, h
     prof = list(profile) if profile else [0, 0, 0, 0]
     handles = [int(embed_event or 0), int(context or 0), int(grads_half_event or 0)] + [int(x or 0) for x in prof]
     return (int(heads), int(inter), int(layers), int(max_pos), str(precision), float(ln_eps), float(hidden_dropout),
-            float(attn_dropout), f, seed, step_device, handles)
+            float(attn_dropout), f, seed, step_device, handles, seq_offsets, row_pos,
+            int(seq_len) if seq_offsets is not None else 0)
 
 
 def encoder(flat_params, item_idx, table, cfg_kwargs: dict):
@@ -626,7 +681,8 @@ def encoder(flat_params, item_idx, table, cfg_kwargs: dict):
     if use_torch_ops():
         tok, key_mask, _acts = torch.ops.xfmr.encoder(flat_params, item_idx, table, *encoder_op_args(**cfg_kwargs))
         return tok, key_mask
-    return EncoderFunction.apply(flat_params, item_idx, table, make_encoder_cfg(**cfg_kwargs))
+    keep = (cfg_kwargs.get("seq_offsets"), cfg_kwargs.get("row_pos"))
+    return EncoderFunction.apply(flat_params, item_idx, table, make_encoder_cfg(**cfg_kwargs), keep)
 
 
 _EAGER_ONLY_LOSS_OPTS = ("workspace", "prepared", "d_tok_zeroed", "profile_grad", "profile_log")

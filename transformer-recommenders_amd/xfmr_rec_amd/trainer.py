@@ -196,9 +196,29 @@ class RecommenderLightningModule(_Base):
         L = min(hist.shape[1], m.max_seq_length)  # what _encode_tokens keeps of the history
         pos = batch["pos_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
         neg = None if catalogue else batch["neg_item_idx"][:, -L:].to(dev, torch.int64).contiguous()
+        # PACKED rows (xfmr_encoder_cfg.seq_offsets): when the batch carries its rows' lengths on the HOST -- the collate that
+        # right-padded them knows them (data.py:799-805); PinnedBatchRing hands them over -- the encoder and the loss run on
+        # each sequence's own rows only. The reference's padded layout computes the padding rows too and then drops them
+        # (models.py:392); on MovieLens-like lengths that is half of the encoder's work.
+        packed = None
+        padded_positions = 0
+        lens = batch.get("lengths")
+        if (lens is not None and hist.shape[1] == L and m.supports_packed_rows(L) and not torch.compiler.is_compiling()
+                and not torch.cuda.is_current_stream_capturing()):
+            rows = int(batch["packed_rows"]) if "packed_rows" in batch else int(lens.sum())
+            if 0 < rows <= 0.97 * hist.shape[0] * L:  # (a nearly full batch gains nothing)
+                offs64 = batch.get("offsets")
+                if offs64 is None:
+                    offs64 = torch.zeros(hist.shape[0] + 1, dtype=torch.int64)
+                    offs64[1:] = torch.cumsum(torch.as_tensor(lens, dtype=torch.int64), 0)
+                    offs64 = offs64.to(dev)
+                packed = ops.pack_rows(hist.to(dev, torch.int64).contiguous(), pos, neg, offs64, rows)
+                packed |= {"batch": hist.shape[0], "seq_len": L}
+                pos, neg = packed["pos"], packed["neg"]
+                padded_positions = hist.shape[0] * L
         opts = dict(train_head=c.train_loss, all_heads=c.log_all_losses, mask_false_negatives=c.mask_false_negatives,
                     mode=N.NEG_CATALOG if catalogue else N.NEG_SHARED, scale=c.scale, margin=c.margin, precision=c.precision,
-                    table_bf16=m.table_bf16, num_hard_negatives=c.num_hard_negatives)
+                    table_bf16=m.table_bf16, num_hard_negatives=c.num_hard_negatives, padded_positions=padded_positions)
         overlap = (defer_logging and c.log_all_losses and m.flat.requires_grad and torch.is_grad_enabled()
                    and m.table_bf16 is not None and c.precision == "bf16" and c.num_hard_negatives == 0
                    # unmasked InfoNCE: ONE call runs the logging pass first and pins the gradient pass's running
@@ -210,7 +230,7 @@ class RecommenderLightningModule(_Base):
             # each) needs the key mask, not the token embeddings: it runs on the side stream underneath the forward, behind an
             # event the encoder forward records right after the launch that writes the mask -- instead of 40 us of small
             # launches between the forward's last kernel and the loss kernels.
-            H, n_rows, T = m.config.hidden_size, m.embeddings.shape[0], hist.shape[0] * L
+            H, n_rows, T = m.config.hidden_size, m.embeddings.shape[0], (pos.numel() if packed else hist.shape[0] * L)
             if getattr(self, "_ev_embed", None) is None:
                 self._ev_embed, self._ev_prep = torch.cuda.Event(), torch.cuda.Event()
                 self._ev_embed.record()  # (creates the handle)
@@ -218,10 +238,11 @@ class RecommenderLightningModule(_Base):
             ws_grad = ops.sampled_loss_workspace(m.flat, T, H, n_rows, **opts)
             prep = (ws_log, ws_grad, H, n_rows)
         # (the forward records the event right after the launch that writes the key mask: xfmr_encoder_cfg.embed_event)
-        tok, key_mask = m._encode_tokens(hist, embed_event=self._ev_embed.cuda_event if overlap else None)
+        tok, key_mask = m._encode_tokens(None if packed else hist, embed_event=self._ev_embed.cuda_event if overlap else None,
+                                         packed=packed)
         if m.config.is_normalized:  # models.py:393-394: the queries are the L2-normalised token embeddings
             tok = ops.l2_normalize(tok)
-        assert tok.shape[1] == L
+        assert packed is not None or tok.shape[1] == L
         if overlap:
             # The six logging heads + statistics do not feed the gradient: evaluate them on a side stream so the
             # (VALU-bound) logging pass runs underneath the (latency-bound) encoder backward. The caller joins
@@ -275,8 +296,8 @@ class RecommenderLightningModule(_Base):
         if overlap:  # raw device vectors: the side-stream pass (train head entries = 0) and the gradient call (train head only)
             out["losses/device"] = losses
             out["losses_train/device"] = losses_train
-        batch_size, seq_len = key_mask.shape
-        numel = key_mask.numel()
+        batch_size, seq_len = hist.shape[0], L  # (the padded shape, also when the rows were packed)
+        numel = batch_size * seq_len
         # trainer.py:241-244: known without a device sync, logged on every path
         out |= {"batch/size": batch_size, "batch/seq_len": seq_len, "batch/numel": numel}
         if sync_metrics and not overlap:
@@ -403,6 +424,15 @@ class RecommenderLightningModule(_Base):
         self.logged = {}
         self.log_dict({key: out[key].detach()})
         return out[key]
+
+    def backward(self, loss: torch.Tensor, *args, **kwargs) -> None:
+        """Lightning's ``LightningModule.backward`` hook (called by its automatic optimisation; ``Trainer.fit_step`` and
+        ``bench.py`` call it too): ``loss.backward()`` with the persistent unit gradient -- no ones-fill launch, and the fused
+        loss skips its multiply by 1 (ops.unit_grad)."""
+        if loss.dim() == 0 and loss.is_cuda and not args and not kwargs:
+            loss.backward(gradient=ops.unit_grad(loss))
+        else:
+            loss.backward(*args, **kwargs)
 
     def on_train_batch_end(self, outputs=None, batch=None, batch_idx: int = 0) -> None:
         """Lightning hook (after ``optimizer.step``): join the logging stream and log the step's remaining values."""
@@ -567,7 +597,7 @@ class Trainer:
             self.default_stream_steps += 1  # (a later hipGraph capture refuses: GraphedStep)
         self.optimizer.zero_grad(set_to_none=True)
         loss = m.training_step(batch, 0)
-        loss.backward()
+        m.backward(loss)
         self.allreduce_(m.model.flat.grad)
         self.optimizer.step()
         m.on_train_batch_end(loss, batch, 0)  # joins the logging stream (leaving the pass to finish underneath the next
