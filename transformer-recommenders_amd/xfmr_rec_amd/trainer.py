@@ -672,6 +672,10 @@ class Trainer:
                     if ring.pending == 0:
                         ring.stage(b)
                     dev_b = ring.take()
+                    if graph != "off":
+                        # a captured step has fixed launch sizes: it runs the padded layout, and so do the eager steps around
+                        # it (one sequence of steps, one layout) -- the rows' lengths are not passed on
+                        dev_b = {k: dev_b[k] for k in SEQ_BATCH_KEYS}
                 else:
                     dev_b = b
                 nxt = next(it, None)
