@@ -73,6 +73,8 @@ def parse(argv=None):
     ap.add_argument("--lean", action="store_true", help="only the train head (not the reference's 7 + stats)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ragged", action="store_true",
+                    help="skip the `ragged` figures (profiling runs: rocprofv3 --pmc serialises every launch)")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="logging heads on a side stream under the encoder backward: pays off once the logging pass is "
                          "long enough (B*L >= 102400: +0.6 %% at B=512, -1.4 %% at B=256, -2 %% at B=128); auto decides by that")
@@ -554,7 +556,7 @@ def main():
     # len ~ clip(round(exp(N(4.35, 1))), 16, L), right-padded with 0 as the reference's collate does (data.py:799-805). The
     # same timed region on ragged batches of the same (B, L) shape, beside the dense figure.
     ragged = None
-    if args.lengths == "dense":
+    if args.lengths == "dense" and not args.no_ragged:
         while ring.pending:
             ring.take()
         ring.release()

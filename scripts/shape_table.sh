@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG/shapes
 mkdir -p "$OUT"
 cd "$ROOT"
-run() { name=$1; shift; timeout -k 10 240 python bench.py --no-cpu-baseline "$@" > "$OUT/$name.json" 2> "$OUT/$name.err" || echo "FAILED $name"; echo "$name done"; }
+run() { name=$1; shift; timeout -k 10 240 python bench.py --no-cpu-baseline --no-ragged "$@" > "$OUT/$name.json" 2> "$OUT/$name.err" || echo "FAILED $name"; echo "$name done"; }
 run b32 --batch 32
 run b128 --batch 128
 run b256 --batch 256

@@ -103,7 +103,8 @@ def main():
                             ("attn_fwd_seq_bf16_kernel", "attn_fwd_seq_bf16_kernel"),
                             ("attn_bwd_fused_bf16_kernel", "attn_bwd_fused_bf16_kernel"),
                             ("loss_logging_pass", "loss_main_dma_kernel<128, -3>"),
-                            ("loss_gradient_pass", "loss_main_dma_kernel<128, 7>")):
+                            ("loss_gradient_pass", "loss_main_dma_kernel<128, 7>"),
+                            ("gemm_group_kernel", "gemm_group_kernel"), ("multi_rowsum_kernel", "multi_rowsum_kernel")):
             fk, wk = pmc_mean(sf, "FETCH_SIZE", needle), pmc_mean(sw, "WRITE_SIZE", needle)
             if fk is not None and wk is not None:
                 per[key] = (2 * fk + wk) * 1024
