@@ -922,7 +922,10 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
   // and re-read (105 + 105 MB at the benchmark shape), no gradient work in the combine kernel. Measured at 800 query
   // blocks: the pass itself takes the same time with 1, 2 or 3 splits (387 us). XFMR_LOSS_NSPLIT_GRAD overrides (experiments).
   int ns_grad = p.nsplit;
-  if (grid.x >= 512) ns_grad = 1;
+  // (round 4: from 257 blocks on. n splits of b blocks take ceil(n b / 512) rounds of 1/n of the columns each: with more than
+  //  256 blocks two splits are two rounds of half a walk -- one split's time -- plus the partial dQ and the combine launch.
+  //  Measured on MovieLens-like batches of 512 in the packed layout, ~390 blocks: 2.00-2.01 against 2.03 ms per step.)
+  if (grid.x >= 512 || (H <= 128 && grid.x > 256)) ns_grad = 1;  // (H > 128: one workgroup per CU, planned by rounds below)
   static const int ns_grad_env = [] { const char* e = getenv("XFMR_LOSS_NSPLIT_GRAD"); return e ? atoi(e) : 0; }();
   if (ns_grad_env > 0) ns_grad = ns_grad_env;
   const int ns_grad_flag = (int)XFMR_LOSS_NSPLIT_GRAD_OF(cfg->flags);  // (tests: several plans in one process)
