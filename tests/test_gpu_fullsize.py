@@ -476,7 +476,7 @@ def _oracle_sums(key, tok, mask, pos, neg, table, **cfg):
     return _ORACLE_SUMS[key]
 
 
-def _check_against_oracle(ops, prec, lengths, H, V, B, L, heads, plans, seed):
+def _check_against_oracle(ops, prec, lengths, H, V, B, L, heads, plans, seed, blocks=(512, 10**9)):
     from oracle import lean
     from oracle import losses as OL
     from xfmr_rec_amd import _native as N
@@ -486,7 +486,7 @@ def _check_against_oracle(ops, prec, lengths, H, V, B, L, heads, plans, seed):
     rn, tb = ops.table_prepare(tdev)
     dev = dict(tok=tok.to(DEV), mask=mask.to(torch.uint8).to(DEV), pos=pos.to(DEV), neg=neg.to(DEV))
     qsel = mask & (pos != 0)
-    assert (int(tok.shape[0]) + 127) // 128 >= 512  # the plan under test: >= 512 query blocks
+    assert blocks[0] <= (int(tok.shape[0]) + 127) // 128 <= blocks[1]  # the plan under test
     g = torch.Generator().manual_seed(3)
     qidx = qsel.nonzero().flatten()
     rows = qidx[torch.randperm(qidx.numel(), generator=g)[:512]]
@@ -540,3 +540,11 @@ def test_h256_loss_with_512_query_blocks_vs_oracle(ops, prec):
     _check_against_oracle(ops, prec, "ragged", H=256, V=1500, B=330, L=200,
                           heads=("InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"),
                           plans=((1, 1), (5, 5)), seed=67)
+
+
+def test_config2_loss_plan_between_257_and_511_query_blocks_vs_oracle(ops):
+    """257 ... 511 query blocks (batch 256 dense; MovieLens-like batches of 512 in the packed layout: ~50 000 rows = ~390
+    blocks): the H <= 128 gradient pass runs ONE split there too (round 4) while the logging pass keeps the plan's splits."""
+    _check_against_oracle(ops, "bf16", "dense", H=128, V=3883, B=250, L=200,
+                          heads=("InfoNCELoss", "PairwiseLogisticLoss", "AlignmentContrastiveLoss"),
+                          plans=((3, 3), (2, 1)), seed=71, blocks=(257, 511))
