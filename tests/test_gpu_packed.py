@@ -68,7 +68,8 @@ def test_pack_rows_kernel(ops):
     (6, 200, 128, 4, 512, 2, [200, 131, 17, 0, 1, 64]),          # config 2's layer shape; an empty and a one-row sequence
     (5, 40, 64, 2, 128, 2, [40, 23, 3, 40, 8]),
     (120, 200, 128, 4, 512, 2, None),                            # 24 000 padded rows: the LayerNorm-fused / fused-FFN kernels
-    (3, 256, 256, 8, 1024, 1, [256, 100, 31]),                   # H = 256, the longest sequence the packed kernels take
+    (3, 256, 256, 8, 1024, 1, [256, 100, 31]),                   # H = 256, the lock-step backward's longest sequence
+    (3, 512, 128, 4, 512, 1, [512, 300, 31]),                    # 256 < L <= 512: four-tile forward deal, two-role backward
 ])
 def test_packed_encoder_equals_the_padded_layout_on_valid_rows(ops, B, L, H, A, I, nL, lengths):
     from xfmr_rec_amd import _native as N

@@ -773,7 +773,8 @@ __constant__ uint8_t kBwdSched[8][4][9] = {
   {{0,1,2,3,4,5,6,7,119}, {102,103,23,22,21,20,19,18,17}, {34,35,36,37,38,39,87,86,85}, {68,69,70,71,55,54,53,52,51}},
 };
 __constant__ uint8_t kBwdSteps[8] = {1, 2, 3, 4, 5, 6, 7, 9};
-constexpr int kFusedMaxL = 256;
+constexpr int kFusedMaxL = 256;  // the lock-step backward (its schedule table: <= 8 tiles)
+constexpr int kSeqMaxL = 512;    // the one-workgroup forward and the two-role backward (<= 16 tiles: four per wave)
 
 __device__ __forceinline__ AttnBlock attn_seq_block(const AttnArgs& a) {  // as attn_block with one block per (b, h)
   const int d = blockIdx.x, xcd = d & 7, slot = d >> 3;
@@ -810,8 +811,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(const AttnArg
   uint32_t* sBits = reinterpret_cast<uint32_t*>(sV + Lp * DH);  // key mask, one bit per key
 
   const int lane = xf_lane(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5;
-  // the wave's (at most two) query tiles; their query rows are in flight while K / V are staged
-  const int qt[2] = {nt - 1 - wid, nt - 8 + wid};
+  // the wave's query tiles (at most two up to 8 tiles, four up to 16): tile t walks t + 1 key blocks, the deal pairs long
+  // with short (nt-1-w, nt-8+w | nt-9-w, nt-16+w). The first two tiles' query rows are in flight while K / V are staged.
+  const int qt[4] = {nt - 1 - wid, nt - 8 + wid, nt - 9 - wid, nt - 16 + wid};
+  const int ntile = nt > 8 ? 4 : 2;
   RegRows<PrecBF16, DH> qreg[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -825,8 +828,12 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(const AttnArg
 
   const float sc = 0.17677669529663687f * kLog2e;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (qt[i] < 0) continue;
+  for (int i = 0; i < 4; ++i) {  // (unrolled: qt[i] / qreg[i & 1] are registers, not indexed arrays)
+    if (i >= ntile || qt[i] < 0) continue;
+    if (i >= 2) {  // (sequences longer than 256: the third / fourth tile's query rows are fetched when their turn comes)
+      const int qq = qt[i] * 32 + (lane & 31);
+      qreg[i & 1].template load_at<S16>(a.qkv, (tok0 + qq) * 3 * H + h * DH, qq < L);
+    }
     const int q0 = qt[i] * 32, q = q0 + (lane & 31);
     float m = -INFINITY, lsum = 0.f;
     f32x16 o;
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seq_bf16_kernel(const AttnArg
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
-      AI::tile_nreg(s, sK, kb * 32, qreg[i].regs());
+      AI::tile_nreg(s, sK, kb * 32, qreg[i & 1].regs());
       float bmax = -INFINITY;
       const uint32_t kword = sBits[kb];
       // interior tile: every key is before the wave's first query and none is padding -- no per-score masking
@@ -1151,8 +1158,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_bf16_kernel(const AttnA
 // Tiles are dealt so that the waves of a role walk the same number of tile pairs (key tile t has nt - t query tiles, query
 // tile t has t + 1 key tiles): even nt: {w, nt-1-w}; odd nt: {0}, {w, nt-w}. Results: the same sums in a fixed order,
 // bit-reproducible; dQ differs from the lock-step form in summation order only (its key tiles are added in ascending order).
-__device__ __forceinline__ void roles_deal(int nt, int w, int out[2]) {  // key-tile indices of dK/dV wave w (-1: none)
+__device__ __forceinline__ void roles_deal(int nt, int w, int nw, int out[2]) {  // key-tile indices of dK/dV wave w (-1: none)
   out[0] = out[1] = -1;
+  if (nw == 8) {  // 9 ... 16 tiles (256 < L <= 512), eight waves per role: {w, nt - 1 - w} with the partner among tiles 8 ...
+    out[0] = w;
+    if (nt - 1 - w >= 8) out[1] = nt - 1 - w;
+    return;
+  }
   if (nt & 1) {
     if (w == 0) out[0] = 0;
     else if (w <= (nt - 1) / 2) { out[0] = w; out[1] = nt - w; }
@@ -1161,8 +1173,10 @@ __device__ __forceinline__ void roles_deal(int nt, int w, int out[2]) {  // key-
   }
 }
 
-template <bool S16>
-__global__ __launch_bounds__(512, 4) void attn_bwd_roles_bf16_kernel(const AttnArgs a_in) {
+// NW = waves per role: 4 (up to 8 tiles: two workgroups of 8 waves per CU) or 8 (9 ... 16 tiles: the four images of a
+// 512-row sequence are 128 KB of LDS -- one workgroup per CU, which then brings all 16 waves itself)
+template <bool S16, int NW>
+__global__ __launch_bounds__(128 * NW, 4) void attn_bwd_roles_bf16_kernel(const AttnArgs a_in) {
   AttnArgs a = a_in;  // (device-side step counter -> dropout key: xf_drop_resolve)
   XF_CHAIN_PRIO();
   a.drop = xf_drop_resolve(a.drop);
@@ -1257,8 +1271,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_roles_bf16_kernel(const AttnA
   const int lane = xf_lane(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5;
   const float sc = 0.17677669529663687f * kLog2e, ks = 0.17677669529663687f;
   int mine[2];
-  roles_deal(nt, wid & 3, mine);
-  if (wid < 4) {
+  roles_deal(nt, wid % NW, NW, mine);
+  if (wid < NW) {
     // ---- role 1: this wave's KEY tiles; walks the query tiles at or after each (attn_bwd_dkv_bf16_kernel's loop)
 #pragma unroll 1
     for (int ti = 0; ti < 2; ++ti) {
@@ -1429,8 +1443,8 @@ constexpr size_t kLdsLimit = 160 * 1024;
 template <bool S16>
 int launch_fwd_bf16(const AttnArgs& a, hipStream_t st) {
   static const int two_blocks = [] { const char* e = getenv("XFMR_ATTN_FWD_SPLIT"); return e ? atoi(e) : 0; }();
-  if (a.offs && !(a.causal && a.L <= kFusedMaxL)) return XFMR_EUNSUPPORTED;  // packed rows: the one-workgroup forms only
-  if ((!two_blocks || a.offs) && a.causal && a.L <= kFusedMaxL) {  // the one-workgroup forms walk the causal triangle only
+  if (a.offs && !(a.causal && a.L <= kSeqMaxL)) return XFMR_EUNSUPPORTED;  // packed rows: the one-workgroup forms only
+  if ((!two_blocks || a.offs) && a.causal && a.L <= kSeqMaxL) {  // the one-workgroup forms walk the causal triangle only
     const size_t sf = bf16_smem_fwd_seq(a.L);
     if (hipFuncSetAttribute((const void*)attn_fwd_seq_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sf) != hipSuccess)
@@ -1460,13 +1474,23 @@ int launch_bwd_bf16(const AttnArgs& a, hipStream_t st) {
   // pairs x ~2 800 issue cycles per (batch, head) against 28 x ~2 000) -- not the default. DESIGN.md section 4.
   const char* form = getenv("XFMR_ATTN_BWD_FORM");
   const bool roles = form && form[0] == 'r';
-  if (a.offs && !(a.causal && a.L <= kFusedMaxL)) return XFMR_EUNSUPPORTED;  // packed rows: the one-workgroup forms only
-  if ((!two_kernels || a.offs) && roles && a.causal && a.L <= kFusedMaxL) {
+  if (a.offs && !(a.causal && a.L <= kSeqMaxL)) return XFMR_EUNSUPPORTED;  // packed rows: the one-workgroup forms only
+  // 256 < L <= 512 (BASELINE config 5): the two-role form is the one-workgroup backward there (the lock-step form's schedule
+  // table stops at eight tiles): Q, K, V, dO of 512 rows are 128 KB of LDS -- one workgroup of eight waves per CU
+  if ((!two_kernels || a.offs) && (roles || a.L > kFusedMaxL) && a.causal && a.L <= kSeqMaxL) {
     const size_t sr = bf16_smem_roles(a.L);
-    if (hipFuncSetAttribute((const void*)attn_bwd_roles_bf16_kernel<S16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sr) != hipSuccess)
-      return XFMR_EHIP;
-    hipLaunchKernelGGL((attn_bwd_roles_bf16_kernel<S16>), dim3((unsigned)(a.A * ((a.B + 7) / 8) * 8)), dim3(512), sr, st, a);
+    const dim3 grid((unsigned)(a.A * ((a.B + 7) / 8) * 8));
+    if (a.L > kFusedMaxL) {
+      if (hipFuncSetAttribute((const void*)attn_bwd_roles_bf16_kernel<S16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sr) != hipSuccess)
+        return XFMR_EHIP;
+      hipLaunchKernelGGL((attn_bwd_roles_bf16_kernel<S16, 8>), grid, dim3(1024), sr, st, a);
+    } else {
+      if (hipFuncSetAttribute((const void*)attn_bwd_roles_bf16_kernel<S16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sr) != hipSuccess)
+        return XFMR_EHIP;
+      hipLaunchKernelGGL((attn_bwd_roles_bf16_kernel<S16, 4>), grid, dim3(512), sr, st, a);
+    }
     XF_LAUNCH_CHECK();
     return XFMR_OK;
   }

@@ -216,8 +216,8 @@ int check_cfg(const xfmr_encoder_cfg* c) {
   if (c->seq_offsets) {  // packed rows (ABI 3)
     if (!c->row_pos || c->packed_rows <= 0 || c->packed_rows > (int64_t)c->batch * c->seq_len) return XFMR_EINVAL;
     // the kernels that walk a sequence by its offsets: the bf16 policy's one-workgroup attention forms (head size 32, causal,
-    // seq_len <= 256); everything else is row-wise and does not care
-    if (!mixed_storage(c) || c->hidden != c->heads * 32 || c->seq_len > 256 || (c->flags & XFMR_ENC_BIDIRECTIONAL))
+    // seq_len <= 512); everything else is row-wise and does not care
+    if (!mixed_storage(c) || c->hidden != c->heads * 32 || c->seq_len > 512 || (c->flags & XFMR_ENC_BIDIRECTIONAL))
       return XFMR_EUNSUPPORTED;
   } else if (c->row_pos || c->packed_rows) {
     return XFMR_EINVAL;
