@@ -1675,6 +1675,9 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
   g.s16 = s16 & (XF_S16_A | XF_S16_B); g.bias_part = bias_part;
   g.drop = xf_make_dropout(0.f, 0, 0);
   *splits_out = splits;
+  // XFMR_EXP_SKIP_DW=1 (experiments only: upper bound of what a faster dW GEMM can give the step; gradients are garbage)
+  static const bool skip = [] { const char* e = getenv("XFMR_EXP_SKIP_DW"); return e && *e == '1'; }();
+  if (skip) return XFMR_OK;
   return dispatch_gemm<true, true, EPI_SPLITK, XF_S16_A, (XF_S16_A | XF_S16_B)>(g, splits, precision, st);
 }
 
