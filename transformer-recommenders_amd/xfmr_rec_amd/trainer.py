@@ -203,6 +203,8 @@ class RecommenderLightningModule(_Base):
         packed = None
         padded_positions = 0
         lens = batch.get("lengths")
+        if torch.is_tensor(lens) and lens.is_cuda:
+            lens = None  # (the launch sizes need the row count on the HOST: device-side lengths would cost a sync per step)
         if (lens is not None and hist.shape[1] == L and m.supports_packed_rows(L) and not torch.compiler.is_compiling()
                 and not torch.cuda.is_current_stream_capturing()):
             rows = int(batch["packed_rows"]) if "packed_rows" in batch else int(lens.sum())
