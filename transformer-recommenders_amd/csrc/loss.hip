@@ -972,7 +972,8 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
     const bool pinned = grad_pass && cfg->all_heads == 1 && cfg->train_head == XFMR_LOSS_INFONCE &&
                         !cfg->mask_false_negatives;
     // the online-maximum InfoNCE at H > 128 runs as dQ column parts (loss_dma.inc): it keeps the split form
-    const bool col_parts = H > 128 && cfg->train_head == XFMR_LOSS_INFONCE && !cfg->mask_false_negatives && !pinned;
+    const bool col_parts = (H > 128 && cfg->train_head == XFMR_LOSS_INFONCE && !cfg->mask_false_negatives && !pinned) ||
+                           (H == 256 && grad_pass && !pinned && xf_loss_dma_256_hparts(a, cfg->train_head) > 1);
     // H > 128 below 512 query blocks: these gradient kernels run ONE workgroup per CU (loss_dma.inc), all of them equally
     // long, so the pass takes ceil(blocks * n / CUs) rounds of 1 / n of the columns each. The fewest splits among the best
     // such n: config 5 (256 blocks on 256 CUs) runs 1 split -- one full round, the rows finished in the kernel, no 134 MB
@@ -992,11 +993,15 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       }
       ns_grad = best;
     }
-    if (!grad_pass || col_parts) ns_grad = p.nsplit;
+    if (!grad_pass || col_parts) {  // column parts keep the split form (no in-kernel finish); overrides still apply
+      ns_grad = p.nsplit;
+      if (col_parts && ns_grad_env > 0) ns_grad = ns_grad_env < p.nsplit ? ns_grad_env : p.nsplit;
+      if (col_parts && ns_grad_flag > 0) ns_grad = ns_grad_flag < p.nsplit ? ns_grad_flag : p.nsplit;
+    }
     dim3 ggrid(grid.x, (unsigned)ns_grad);
     if (grad_pass) {
       a.nsplit = ns_part = ns_grad;
-      if (ns_grad == 1) { a.d_tok = d_tok; fused_finish = true; }
+      if (ns_grad == 1 && !col_parts) { a.d_tok = d_tok; fused_finish = true; }
     }
     if (pinned) {
       LossArgs b = a;

@@ -546,4 +546,5 @@ using namespace xfl;
 int xf_launch_loss_dma_64(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st);
 int xf_launch_loss_dma_128(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st);
 int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st);
+int xf_loss_dma_256_hparts(const LossArgs& a, int head);  // dQ column parts of the H = 256 gradient pass (loss_dma_h256.hip)
 int xf_launch_loss_dma_384(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st);

@@ -10,10 +10,20 @@ static bool logm256() {
   return on;
 }
 
+// dQ column parts of the gradient pass this launcher would start for `head` (loss.hip plans its splits with it)
+int xf_loss_dma_256_hparts(const LossArgs& a, int head) {
+  if (head == XFMR_LOSS_INFONCE && !a.mask_fn && !a.pin_part) return 2;  // the online-maximum InfoNCE (loss_dma.inc)
+  if (!XFL_H256_LEAN_HALVES || !a.mask_fn) return 1;
+  if (head == XFMR_LOSS_INFONCE) return 2;
+  if (a.mode != XFMR_NEG_SHARED) return 1;
+  if (head == XFMR_LOSS_ALIGNMENT_CONTRASTIVE || head == XFMR_LOSS_CONTRASTIVE) return 2;
+  return (head == XFMR_LOSS_PAIRWISE_LOGISTIC && !a.tau) ? 2 : 1;
+}
+
 int xf_launch_loss_dma_256(const LossArgs& a, const void* table_bf16, int head, dim3 grid, hipStream_t st) {
   const __bf16* tbf = (const __bf16*)table_bf16;
   dim3 block(256);
-  if (head == XFMR_LOSS_INFONCE && !a.mask_fn && !a.pin_part) grid.z = 2;  // two dQ column halves (loss_dma.inc)
+  if (head >= 0) grid.z = (unsigned)xf_loss_dma_256_hparts(a, head);  // dQ column halves (loss_dma.inc)
   switch (head) {
     // logging pass: masking on + in-batch negatives take the fast epilogue (loss_epilogue_logging_masked), as at H = 128.
     // (Round 2 measured it 26 % SLOWER than the general epilogue at ONE wave per SIMD -- 2.21 against 1.75 ms at BASELINE
