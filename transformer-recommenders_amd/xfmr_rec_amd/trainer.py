@@ -422,7 +422,7 @@ class RecommenderLightningModule(_Base):
         # only DETACHED tensors outlive the step: a retained train loss would keep the step's autograd graph -- the saved
         # activations and `flat`'s AccumulateGrad node with the stream it was created on -- alive into the next step (and
         # into a later hipGraph capture on another stream: ADVICE r3)
-        self._pending_out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+        self._pending_out = {k: (v.detach() if (torch.is_tensor(v) and v.requires_grad) else v) for k, v in out.items()}
         self.logged = {}
         self.log_dict({key: out[key].detach()})
         return out[key]
