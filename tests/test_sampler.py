@@ -61,6 +61,9 @@ def test_device_sampler_invariants_and_reproducibility(lookahead):
     for seed in range(12):
         b = {k: v.cpu().numpy() for k, v in ds.sample_batch(rows, seed).items()}
         assert b["history_item_idx"].shape == (len(hs), 32)
+        # the rows' lengths, known on the host before the launch (the packed layout of the training step needs them there)
+        assert (b["lengths"] == (b["history_item_idx"] != 0).sum(1)).all()
+        assert ((b["history_item_idx"] != 0) == (np.arange(32)[None, :] < b["lengths"][:, None])).all()  # right-padded
         for r, (h, l) in enumerate(zip(hs, ls)):
             OS.check_example(h, l, b["history_item_idx"][r], b["pos_item_idx"][r], b["neg_item_idx"][r],
                              max_seq_length=32, pos_lookahead=lookahead, n_items=V)

@@ -69,7 +69,9 @@ class DeviceSeqDataset:
 
     def sample_batch(self, rows, seed: int) -> dict[str, torch.Tensor]:
         """``collate([dataset[r] for r in rows])`` (``data.py:749-805``) in one launch; returns the three index tensors
-        of ``SeqBatch`` on the device, shape ``(len(rows), width)``."""
+        of ``SeqBatch`` on the device, shape ``(len(rows), width)`` -- and the rows' lengths on the HOST (a history of n
+        events gives min(n - 1, max_seq_length) sampled positions, ``data.py:669-688``: known before the launch), with which
+        the training step runs the packed layout."""
         rows_np = np.asarray(rows, dtype=np.int64)
         lens = self.lengths[rows_np]
         width = int(max(1, min(self.config.max_seq_length, int(lens.max()) - 1)))
@@ -86,7 +88,8 @@ class DeviceSeqDataset:
                                 N.stream()),
             "xfmr_seq_sample",
         )
-        return {"history_item_idx": out[0], "pos_item_idx": out[1], "neg_item_idx": out[2]}
+        return {"history_item_idx": out[0], "pos_item_idx": out[1], "neg_item_idx": out[2],
+                "lengths": torch.from_numpy(np.minimum(lens - 1, width).astype(np.int64))}
 
 
 SEQ_BATCH_KEYS = ("history_item_idx", "pos_item_idx", "neg_item_idx")  # the index tensors of SeqBatch (data.py:534-540)
