@@ -70,13 +70,17 @@ def test_pack_rows_kernel(ops):
     (120, 200, 128, 4, 512, 2, None),                            # 24 000 padded rows: the LayerNorm-fused / fused-FFN kernels
     (3, 256, 256, 8, 1024, 1, [256, 100, 31]),                   # H = 256, the lock-step backward's longest sequence
     (3, 512, 128, 4, 512, 1, [512, 300, 31]),                    # 256 < L <= 512: four-tile forward deal, two-role backward
+    (128, 32, 64, 2, 128, 2, "short"),                           # the e2e shape: 4 096 padded rows of H = 64, short sequences
+    (64, 32, 64, 2, 128, 2, "short"),
 ])
 def test_packed_encoder_equals_the_padded_layout_on_valid_rows(ops, B, L, H, A, I, nL, lengths):
     from xfmr_rec_amd import _native as N
 
     V = 300
     g = torch.Generator().manual_seed(11)
-    if lengths is None:
+    if lengths == "short":
+        lengths = torch.randint(11, L + 1, (B,), generator=g).tolist()
+    elif lengths is None:
         lengths = torch.exp(4.35 + torch.randn(B, generator=g)).round().clamp(16, L).long().tolist()
     table = unit_table(V, H).to(DEV)
     batch = _ragged(B, L, V, lengths, seed=5)

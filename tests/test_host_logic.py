@@ -72,6 +72,17 @@ def test_unsupported_shapes_are_rejected_on_the_host(native):
     assert lib.xfmr_linear_bwd_dw_workspace(25600, 128, 128) >= 128 * 128 * 4
 
 
+def test_weight_gradient_slab_room_covers_every_smaller_token_count(native):
+    """The packed layout (ABI 3) carves the slab buffers for batch x seq_len tokens and launches with the real row count;
+    the slab plan is not monotone in the token count (4 095 tokens: 32 slabs, 4 096: 16) -- round 4's e2e NaN. The size
+    query must hold for every token count up to the one asked for."""
+    lib = native.load()
+    for n, k in ((192, 64), (128, 64), (64, 128), (384, 128), (512, 128), (768, 256), (1024, 256)):
+        sizes = [lib.xfmr_linear_bwd_dw_workspace(m, n, k) for m in range(1, 9000, 37)]
+        assert all(a <= b for a, b in zip(sizes, sizes[1:])), (n, k)
+    assert lib.xfmr_linear_bwd_dw_workspace(4096, 192, 64) >= 32 * 192 * 64 * 4
+
+
 def test_no_cpu_fallback():
     from xfmr_rec_amd import ops
 

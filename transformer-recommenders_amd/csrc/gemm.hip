@@ -1443,6 +1443,20 @@ int dw_split_plan(int64_t M, int N, int K, int* k_chunk) {
   *k_chunk = (int)chunk;
   return (int)((M + chunk - 1) / chunk);
 }
+// The most slabs dw_split_plan gives for ANY token count <= M. The plan is not monotone in M (4 095 tokens: 32 slabs of
+// 128; 4 096: 16 of 256), and the packed layout (xfmr_encoder_cfg.seq_offsets) carves its slab buffers for batch x seq_len
+// tokens and then launches with the real row count -- round 4: a 128 x 32 batch of 2 750 real rows wrote 22 slabs into room
+// for 16. chunk >= max(128, M / want)  =>  slabs <= min(ceil(M / 128), want).
+int dw_split_bound(int64_t M, int N, int K) {
+  int k_chunk;
+  const int64_t tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  int64_t want = (1024 + tiles - 1) / tiles;
+  if (want > 256) want = 256;
+  const int64_t by_rows = (M + 127) / 128;
+  const int64_t bound = by_rows < want ? by_rows : want;
+  const int plan = dw_split_plan(M, N, K, &k_chunk);
+  return bound > plan ? (int)bound : plan;
+}
 
 }  // namespace
 
@@ -1630,10 +1644,8 @@ int xfmr_linear_bwd_dx(const float* dy, const float* w, float* dx, int64_t M, in
   return xf_linear_bwd_dx_ex(dy, w, dx, M, N, K, residual_grad, gelu_pre, precision, 0, (hipStream_t)stream);
 }
 
-size_t xfmr_linear_bwd_dw_workspace(int64_t M, int32_t N, int32_t K) {
-  int k_chunk;
-  int splits = dw_split_plan(M, N, K, &k_chunk);
-  return (size_t)splits * (size_t)N * (size_t)K * sizeof(float);
+size_t xfmr_linear_bwd_dw_workspace(int64_t M, int32_t N, int32_t K) {  // enough for every token count <= M
+  return (size_t)dw_split_bound(M, N, K) * (size_t)N * (size_t)K * sizeof(float);
 }
 
 int xf_linear_bwd_dw_ex(const void* dy, const void* x, float* dw, int64_t M, int32_t N, int32_t K, int32_t precision,
