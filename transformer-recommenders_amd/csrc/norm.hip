@@ -513,16 +513,27 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
   return XFMR_OK;
 }
 
-int ln_bwd_blocks(int64_t rows, int* rows_per_block) {
+int ln_bwd_blocks(int64_t rows, int H, int* rows_per_block) {
   // 32 rows per workgroup, <= 1024 workgroups (measured at T = 25 600: 1.859 ms/step; 64 rows / 512: 1.877;
-  // 16 rows / 2048: 1.891 -- the partial records the final reduction reads grow with the workgroup count)
-  int64_t blocks = (rows + 31) / 32;
+  // 16 rows / 2048: 1.891 -- the partial records the final reduction reads grow with the workgroup count).
+  // Small steps (round 4): 32 rows per workgroup are 8 dependent row round trips per wave on rows / 32 CUs -- 1 024 tokens
+  // of H = 384 (the reference's default model) took 33 us per LayerNorm backward, a quarter of that step. Below 16 384 rows:
+  // 16 per workgroup; below 4 096: one wave-iteration (4 waves x 64 / lanes-per-row rows).
+  const int iter_rows = H == 64 ? 16 : H == 128 ? 8 : 4;  // rows of one workgroup iteration (ln_bwd_v4_kernel / ln_bwd_kernel)
+  const int64_t per = rows >= 16384 ? 32 : rows >= 4096 ? 16 : iter_rows;
+  int64_t blocks = (rows + per - 1) / per;
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   int64_t rpb = (rows + blocks - 1) / blocks;
-  rpb = ((rpb + 15) / 16) * 16;  // whole wave-iterations of the vectorised kernel (4 waves x up to 4 rows)
+  rpb = ((rpb + iter_rows - 1) / iter_rows) * iter_rows;  // whole workgroup iterations
   *rows_per_block = (int)rpb;
   return (int)((rows + rpb - 1) / rpb);
+}
+// The most partial records ln_bwd_blocks gives for ANY row count <= rows (the plan is not monotone in the row count; the
+// packed layout carves for batch x seq_len rows and launches with the real ones).
+int ln_bwd_blocks_bound(int64_t rows) {
+  const int64_t b = (rows + 3) / 4;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
 }
 
 
@@ -651,8 +662,7 @@ int xf_layernorm_fwd_ex(const float* x, const float* gamma, const float* beta, f
 }
 
 size_t xfmr_layernorm_bwd_workspace(int64_t rows, int32_t H) {
-  int rpb;
-  return (size_t)ln_bwd_blocks(rows, &rpb) * 3 * (size_t)H * sizeof(float);
+  return (size_t)ln_bwd_blocks_bound(rows) * 3 * (size_t)H * sizeof(float);  // enough for every row count <= rows
 }
 
 // Internal variant that also takes the dropout applied to the LayerNorm OUTPUT (embedding site).
@@ -665,7 +675,7 @@ int xf_layernorm_bwd_impl(const float* dy, const float* x, const float* mean, co
   LnBwdArgs a{};
   a.dy = dy; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.dx = dx; a.d_lin = d_lin;
   a.partials = (float*)partials; a.rows = rows; a.H = H; a.lin16 = lin16 ? 1 : 0;
-  const int blocks = ln_bwd_blocks(rows, &a.rows_per_block);
+  const int blocks = ln_bwd_blocks(rows, H, &a.rows_per_block);
   a.drop_out = drop_out; a.drop_lin = drop_lin;
   const size_t shmem = (size_t)12 * H * sizeof(float);
   const int npl = npl_of(H);
