@@ -58,7 +58,8 @@ enum {
   XFMR_EUNSUPPORTED = -2, /* shape outside what the kernels are built for              */
   XFMR_EWORKSPACE = -3,  /* workspace too small                                        */
   XFMR_EHIP = -4,        /* a HIP launch failed (hipGetLastError)                      */
-  XFMR_EALIGN = -5       /* pointer / leading dimension not 16-byte aligned            */
+  XFMR_EALIGN = -5,      /* pointer / leading dimension not 16-byte aligned            */
+  XFMR_ECOMM = -6        /* RCCL not loadable, or an RCCL call failed (xfmr_comm_*)    */
 };
 
 enum { XFMR_PREC_F32 = 0, XFMR_PREC_BF16 = 1 };
@@ -541,6 +542,26 @@ int xfmr_adamw_dev(float* params, const float* grads, float* exp_avg, float* exp
                    float beta1, float beta2, float eps, float weight_decay, const uint32_t* step_device,
                    int32_t step_offset, float grad_scale, void* stream);
 int xfmr_step_advance(uint32_t* step_device, void* stream); /* *step_device += 1 (one thread) */
+
+/* ------------------------------------------------------------------------------------------------
+ * K19: the data-parallel exchange (SURVEY section 8b `allreduce_flat`, 8e): what torch DDP does for the reference
+ * (config.yaml:5-6,35 -- Lightning `strategy: auto`): g <- SUM over ranks of the flat gradient buffer, in place, fp32, on
+ * the caller's stream; the 1 / world factor is xfmr_adamw's grad_scale. RCCL does the transport (rings over xGMI); it is
+ * loaded at RUN time from the process (dlopen of librccl.so.1: the copy already mapped -- torch's -- or the ROCm one), so
+ * nothing here links against it and a single-GPU user never loads it.
+ *   rank 0:        xfmr_comm_unique_id(id)            ... ship the 128 bytes to every rank by any channel ...
+ *   every rank:    xfmr_comm_create(&comm, id, world, rank)   (collective; binds the CURRENT device)
+ *   every step:    xfmr_allreduce_flat(comm, grads, n, stream)
+ *   at the end:    xfmr_comm_destroy(comm)
+ * The communicator is the one object these calls create; the caller owns it. XFMR_ECOMM: RCCL missing or an RCCL error
+ * (xfmr_comm_last_error(): RCCL's own text for the last failure of this thread).
+ * ---------------------------------------------------------------------------------------------- */
+#define XFMR_COMM_ID_BYTES 128
+int xfmr_comm_unique_id(unsigned char id[XFMR_COMM_ID_BYTES]);
+int xfmr_comm_create(void** comm, const unsigned char id[XFMR_COMM_ID_BYTES], int32_t world, int32_t rank);
+int xfmr_comm_destroy(void* comm);
+int xfmr_allreduce_flat(void* comm, float* grads, int64_t n, void* stream);
+const char* xfmr_comm_last_error(void);
 
 /* Elementwise helpers used by the autograd wrappers. */
 int xfmr_scale_by_device_scalar(float* x, int64_t n, const float* scalar, void* stream);

@@ -150,3 +150,29 @@ def test_grads_half_event_releases_a_finished_upper_half(B, nL, form):
     lib.xfmr_event_destroy(ev.value)
     if ctx:
         ctx.close()
+
+
+def test_allreduce_flat_through_the_c_abi_on_a_one_rank_communicator():
+    """`xfmr_allreduce_flat` (include/xfmr_hip.h K19: RCCL resolved at run time): a world of ONE rank is what one GPU can
+    run -- RCCL initialises, the call is enqueued on the caller's stream and a SUM over one rank returns the buffer bit for
+    bit. More ranks need more devices (RCCL refuses two ranks on one): the driver's multi-GPU bench is where that runs."""
+    for p in (ROOT, ROOT / "transformer-recommenders_amd"):
+        sys.path.insert(0, str(p))
+    from xfmr_rec_amd import distributed as D
+
+    torch.cuda.set_device(0)
+    ex = D.AbiAllReduce(torch.device("cuda:0"))
+    try:
+        assert ex.world == 1 and ex.comm
+        g = torch.randn(819200, device="cuda:0")  # config 2's flat gradient: 3.1 MiB
+        want = g.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # the caller's CURRENT stream is the one it is enqueued on
+            out = ex.reduce_(g)
+        side.synchronize()
+        assert out is g and torch.equal(g, want)
+        with pytest.raises(RuntimeError, match="fp32"):
+            ex.reduce_(g.double())
+    finally:
+        ex.close()

@@ -83,6 +83,21 @@ def test_weight_gradient_slab_room_covers_every_smaller_token_count(native):
     assert lib.xfmr_linear_bwd_dw_workspace(4096, 192, 64) >= 32 * 192 * 64 * 4
 
 
+def test_comm_entry_points_validate_on_the_host(native):
+    """xfmr_comm_* / xfmr_allreduce_flat (K19): argument checks return codes, never touch a device; RCCL is resolved at run
+    time (the library does not link against it)."""
+    import subprocess
+
+    lib = native.load()
+    assert lib.xfmr_allreduce_flat(None, None, 0, None) == -1
+    assert lib.xfmr_comm_create(None, None, 1, 0) == -1
+    assert lib.xfmr_comm_destroy(None) == -1
+    assert lib.xfmr_comm_unique_id(None) == -1
+    assert b"RCCL" in lib.xfmr_strerror(native.ECOMM)
+    needed = subprocess.run(["readelf", "-d", str(native.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
+
+
 def test_no_cpu_fallback():
     from xfmr_rec_amd import ops
 

@@ -251,6 +251,7 @@ const char* xfmr_strerror(int code) {
     case XFMR_EWORKSPACE: return "workspace too small";
     case XFMR_EHIP: return "HIP launch failed";
     case XFMR_EALIGN: return "pointer or leading dimension not 16-byte aligned";
+    case XFMR_ECOMM: return "RCCL not loadable or an RCCL call failed (xfmr_comm_last_error)";
     default: return "unknown error";
   }
 }

@@ -27,6 +27,7 @@ ENC_BIDIRECTIONAL, ENC_LN_UNFUSED, ENC_FFN_UNFUSED, ENC_FFN_BWD_UNFUSED, ENC_DW_
 ENC_DW_UNPAIRED, ENC_REDUCE_HALF_EARLY = 64, 128
 LOSS_DTOK_ZEROED = 1  # xfmr_loss_cfg.flags
 ABI_VERSION = 3
+ECOMM = -6  # XFMR_ECOMM: RCCL not loadable / an RCCL call failed (xfmr_comm_last_error has RCCL's text)
 NUM_LOSSES, NUM_STATS = 7, 16
 LOSS_IDS = {
     "AlignmentLoss": 0,
@@ -168,7 +169,13 @@ _SIGNATURES = {
     "xfmr_step_advance": (C.c_int, [_P, _P]),
     "xfmr_scale_by_device_scalar": (C.c_int, [_P, C.c_int64, _P, _P]),
     "xfmr_selftest_mfma": (C.c_int, [_P, _P]),
+    "xfmr_comm_unique_id": (C.c_int, [_P]),
+    "xfmr_comm_create": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "xfmr_comm_destroy": (C.c_int, [_P]),
+    "xfmr_allreduce_flat": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "xfmr_comm_last_error": (C.c_char_p, []),
 }
+COMM_ID_BYTES = 128
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
@@ -211,6 +218,8 @@ def load() -> C.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().xfmr_strerror(rc).decode()
+        if rc == ECOMM:
+            msg += ": " + load().xfmr_comm_last_error().decode()
         raise RuntimeError(f"{what} failed: {msg} (code {rc})")
 
 

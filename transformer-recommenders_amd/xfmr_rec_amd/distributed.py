@@ -54,6 +54,50 @@ def allreduce_flat_grad_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
     return flat_grad
 
 
+class AbiAllReduce:
+    """The exchange through the C ABI (``xfmr_allreduce_flat``, ``include/xfmr_hip.h`` K19) instead of ``torch.distributed``:
+    what a host that is not PyTorch binds. The RCCL communicator is created from a 128-byte id that rank 0 makes
+    (``xfmr_comm_unique_id``) and the already initialised process group ships (any backend: it is 128 bytes, once);
+    afterwards a step's exchange is ONE call on the compute stream -- no Python collective, no work object.
+    ``XFMR_ALLREDUCE=abi`` selects it in :class:`~xfmr_rec_amd.trainer.Trainer`; the default stays ``torch.distributed``
+    (the same RCCL underneath, and the driver's multi-GPU runs have only ever exercised that one)."""
+
+    def __init__(self, device, group=None):
+        import ctypes
+
+        from . import _native as N
+
+        self._lib, self._N = N.load(), N
+        self.comm = None
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = world
+        ident = (ctypes.c_ubyte * N.COMM_ID_BYTES)()
+        if rank == 0:
+            N.check(self._lib.xfmr_comm_unique_id(ident), "xfmr_comm_unique_id")
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (ctypes.c_ubyte * N.COMM_ID_BYTES).from_buffer_copy(box[0])
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            N.check(self._lib.xfmr_comm_create(ctypes.byref(comm), ident, world, rank), "xfmr_comm_create")
+        self.comm = comm.value
+
+    def reduce_(self, flat_grad: torch.Tensor) -> torch.Tensor:
+        N = self._N
+        if not flat_grad.is_cuda or not flat_grad.is_contiguous() or flat_grad.dtype != torch.float32:
+            raise RuntimeError("xfmr_allreduce_flat takes a contiguous fp32 buffer in HBM")
+        N.check(self._lib.xfmr_allreduce_flat(self.comm, flat_grad.data_ptr(), flat_grad.numel(), N.stream()),
+                "xfmr_allreduce_flat")
+        return flat_grad
+
+    def close(self):
+        if self.comm is not None:
+            self._lib.xfmr_comm_destroy(self.comm)
+            self.comm = None
+
+
 class HalvedAllReduce:
     """The gradient exchange of a step in TWO messages, the first one overlapped with the backward (SURVEY section 8e:
     "overlapped with the last layers' backward"; the reference gets the same from torch DDP's buckets, ``config.yaml:5-6``).

@@ -575,6 +575,11 @@ class Trainer:
                 from .distributed import HalvedAllReduce
 
                 self.exchange = HalvedAllReduce(module.model, process_group)
+            elif os.environ.get("XFMR_ALLREDUCE", "") == "abi" and module.model.flat.is_cuda:
+                # the exchange through the C ABI (xfmr_allreduce_flat: RCCL underneath, no torch collective in the step)
+                from .distributed import AbiAllReduce
+
+                self.exchange = AbiAllReduce(module.model.device, process_group)
 
     def allreduce_(self, flat_grad: torch.Tensor) -> None:
         """The step's one exchange: SUM of the flat gradient over the ranks (1 / W is folded into AdamW); with
