@@ -1463,6 +1463,8 @@ int dw_split_bound(int64_t M, int N, int K) {
 
 extern "C" {
 
+int xf_dw_split_plan(int64_t M, int32_t N, int32_t K, int* k_chunk) { return dw_split_plan(M, N, K, k_chunk); }
+
 // internal (norm.hip): dst[c] = sum over all rows
 int xf_rowsum(float* dst, const float* src, int64_t rows, int64_t cols, hipStream_t st) {
   return launch_rowsum(dst, src, rows, cols, rows, st);
@@ -1679,6 +1681,12 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
   if (!xf_aligned16(dy) || !xf_aligned16(x) || !xf_aligned16(slabs)) return XFMR_EALIGN;
   if ((s16 & ~XF_AUX_GELU_GRAD) && precision != XFMR_PREC_BF16) return XFMR_EINVAL;
   if ((s16 & (XF_S16_A | XF_S16_B | XF_S16_C | XF_S16_P)) && ((K & 7) || (N & 7))) return XFMR_EUNSUPPORTED;  // 16-byte bf16 pieces
+  // XFMR_EXP_SKIP_DW=1 (experiments only: upper bound of what a faster dW GEMM can give the step; gradients are garbage)
+  static const bool skip_ring = [] { const char* e = getenv("XFMR_EXP_SKIP_DW"); return e && *e == '1'; }();
+  {
+    const XfDwItem one{dy, x, N, K, slabs, bias_part, splits_out};
+    if (!skip_ring && xf_dw_ring_takes(&one, 1, M, precision, s16)) return xf_dw_ring_launch(&one, 1, M, st);  // dw_ring.hip
+  }
   int k_chunk;
   const int splits = dw_split_plan(M, N, K, &k_chunk);
   GemmArgs g{};
@@ -1699,6 +1707,7 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
 int xf_linear_bwd_dw_group(const XfDwItem* items, int n, int64_t M, int32_t precision, uint32_t s16, hipStream_t st) {
   constexpr uint32_t SAB = XF_S16_A | XF_S16_B;
   if (!items || n < 1 || n > 4) return XFMR_EINVAL;
+  if (xf_dw_ring_takes(items, n, M, precision, s16)) return xf_dw_ring_launch(items, n, M, st);  // dw_ring.hip
   static const bool env_tiles = getenv("XFMR_DW_TILE") || getenv("XFMR_GEMM_TILE");
   bool groupable = n > 1 && precision == XFMR_PREC_BF16 && (s16 & SAB) == SAB && !env_tiles && M > 0;
   for (int i = 0; i < n && groupable; ++i) {

@@ -47,6 +47,11 @@ int xf_linear_bwd_dw_deferred(const void* dy, const void* x, int64_t M, int32_t 
 // up to four of them over the same M tokens in one launch (gemm.hip: gemm_group_kernel)
 struct XfDwItem { const void* dy; const void* x; int32_t N, K; float* slabs; float* bias_part; int* splits; };
 int xf_linear_bwd_dw_group(const XfDwItem* items, int n, int64_t M, int32_t precision, uint32_t s16, hipStream_t st);
+// the slab plan of one weight-gradient GEMM over M tokens (gemm.hip): token chunk per slab, returns the slab count
+int xf_dw_split_plan(int64_t M, int32_t N, int32_t K, int* k_chunk);
+// dw_ring.hip: the LDS-DMA ring form of the same GEMMs (same plan, same slab layout) for the shapes it takes
+bool xf_dw_ring_takes(const XfDwItem* items, int n, int64_t M, int32_t precision, uint32_t s16);
+int xf_dw_ring_launch(const XfDwItem* items, int n, int64_t M, hipStream_t st);
 // dst[c] = sum_r src[r * ld + c], r < rows, c < cols, for every segment, in one launch (deterministic order)
 struct XfReduceSeg { const float* src; float* dst; int rows; int cols; int ld; int pad; };
 int xf_multi_rowsum(const XfReduceSeg* segs, int nseg, hipStream_t st);
