@@ -600,9 +600,9 @@ def main():
     # sits on a lowest-priority stream underneath the encoder backward, so its duration there includes the time it is held
     # back -- what a one-stream rocprofv3 trace (profiles/*_kernel_stats.md) sees is this figure.
     alone_ms, alone_grad_ms = [], []
-    # in line the layer's four weight-gradient GEMMs are ONE launch (gemm_group_kernel) and can be bracketed too, and so can
+    # in line the layer's four weight-gradient GEMMs are ONE launch (dw_ring_kernel) and can be bracketed too, and so can
     # the backward's final reduction launch
-    ALONE_PARTS = ENC_PARTS + ((N.PROF_DW, "gemm_group_kernel"), (N.PROF_REDUCE, "multi_rowsum_kernel"))
+    ALONE_PARTS = ENC_PARTS + ((N.PROF_DW, "dw_ring_kernel"), (N.PROF_REDUCE, "multi_rowsum_kernel"))
     alone_enc = {k: [] for k, _ in ALONE_PARTS}
     if (overlap or gstep is not None) and not args.lean:
         n_alone = 18
@@ -676,7 +676,7 @@ def main():
         N.PROF_ATTN_BWD: ("attn_bwd_fused_bf16_kernel (one workgroup per (batch, head): dQ, dK, dV)",
                           2 * 3 * TH * 2 + 2 * TH * 2, 10.0 * B * A_heads * L * (L + 1) / 2 * 32),
         # operands only: dy + g, dI + x1, d_lin + ctx, dQKV + x (all bf16); the split-K slabs it also writes are overhead
-        N.PROF_DW: ("gemm_group_kernel (the layer's four weight-gradient GEMMs, split-K, in one launch: the in-line form)",
+        N.PROF_DW: ("dw_ring_kernel (the layer's four weight-gradient GEMMs, token slabs through an LDS-DMA ring, in one launch: the in-line form)",
                     (TH + TI) * 2 * 2 + 2 * TH * 2 + (3 * TH + TH) * 2, 2.0 * Tt * (2 * H * args.inter + H * H + 3 * H * H)),
     }
     enc_entries = []

@@ -34,7 +34,7 @@ K = [
     ("gemm_kernel<PrecBF16, 64, 64, 64, false, true, 0, 3u", "QKV dX + residual grad (layer 0)", T3H * b16 + 2 * TH * f32, 2 * T * H * 3 * H),
     ("gemm_kernel<PrecBF16, 128, 64, 128, true, true, 4,", "dW split-K (avg of the 4 weights; operands only, + 14 MB of slabs)",
      ((TH + TI) * b16 * 2 + (TH + TH) * b16 + (T3H + TH) * b16) / 4, (2 * 2 * T * H * I + 2 * T * H * H + 2 * T * 3 * H * H) / 4),
-    ("gemm_group_kernel<PrecBF16, 128, 64, 128, true, true, 4,", "dW split-K, the four weights of a layer in one launch (in-line form; operands only, + 55 MB of slabs)",
+    ("dw_ring_kernel", "dW in token slabs (LDS-DMA ring), the four weights of a layer in one launch (in-line form; operands only, + 38 MB of slabs)",
      (TH + TI) * b16 * 2 + (TH + TH) * b16 + (T3H + TH) * b16, 2 * 2 * T * H * I + 2 * T * H * H + 2 * T * 3 * H * H),
     ("attn_fwd_seq_bf16_kernel", "attention fwd (per layer)", T3H * b16 + TH * b16 + B * A * L * f32, 4 * B * A * L * (L + 1) / 2 * 32),
     ("attn_bwd_fused_bf16_kernel", "attention bwd (per layer)", 2 * T3H * b16 + 2 * TH * b16, 10 * B * A * L * (L + 1) / 2 * 32),
@@ -72,7 +72,7 @@ for frag, desc, nbytes, flops in K:
     tb = f"{nbytes / (avg * 1e-6) / 1e12:.2f}" if nbytes else "—"
     tf = f"{flops / (avg * 1e-6) / 1e12:.0f}" if flops else "—"
     lines.append(f"| {desc} (`{frag.strip(', ')}`) | {calls / steps:.1f} | {avg:.1f} | {nbytes / MB:.0f} | {tb} | {tf} |")
-    if frag.startswith(("gemm_kernel", "gemm_group_kernel", "ffn_")):
+    if frag.startswith(("gemm_kernel", "gemm_group_kernel", "dw_ring_kernel", "ffn_")):
         gemm_bytes += nbytes * calls / steps
         gemm_ns += tot / steps
 if args.json:

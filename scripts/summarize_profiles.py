@@ -104,7 +104,7 @@ def main():
                             ("attn_bwd_fused_bf16_kernel", "attn_bwd_fused_bf16_kernel"),
                             ("loss_logging_pass", "loss_main_dma_kernel<128, -3>"),
                             ("loss_gradient_pass", "loss_main_dma_kernel<128, 7>"),
-                            ("gemm_group_kernel", "gemm_group_kernel"), ("multi_rowsum_kernel", "multi_rowsum_kernel")):
+                            ("dw_ring_kernel", "dw_ring_kernel"), ("multi_rowsum_kernel", "multi_rowsum_kernel")):
             fk, wk = pmc_mean(sf, "FETCH_SIZE", needle), pmc_mean(sw, "WRITE_SIZE", needle)
             if fk is not None and wk is not None:
                 per[key] = (2 * fk + wk) * 1024
