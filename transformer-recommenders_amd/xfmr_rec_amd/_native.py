@@ -237,7 +237,13 @@ def ptr(t: torch.Tensor | None) -> int | None:
 
 
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device. Called once per launch sequence: the raw accessor
+    (no ``torch.cuda.Stream`` object, no ``is_available()`` / device-count probe per call: ~10 us each on the host of a
+    host-bound small step) where this torch has it."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:  # pragma: no cover - older / newer torch without the private accessors
+        return torch.cuda.current_stream().cuda_stream
 
 
 def precision_id(p) -> int:
