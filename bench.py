@@ -661,6 +661,12 @@ def main():
                   "frac_overlapped": k["frac"]}
             k |= {"avg_launch_ms": round(a, 4), "achieved": round(tf, 2), "frac": round(tf / peak, 5), "note": note}
     k_log["launches_per_step"] = k_grad["launches_per_step"] = 1
+    if args.loss in ("AlignmentContrastiveLoss", "ContrastiveLoss", "PairwiseHingeLoss"):
+        # hinge-type gradient weights are exactly 0 inside the margin: the gradient pass skips the dQ MFMAs of every 32 x 32
+        # block without an active pair (csrc/loss_dma.inc). The algorithmic flops above still count the dQ product, so on
+        # batches with few active pairs (random-init weights, a random table: none) `achieved` is up to 2 x the executed rate.
+        k_grad["dq_product"] = ("skipped per 32x32 block when every gradient weight of the block is 0 (hinge-type head); "
+                                "algorithmic_flops_per_launch counts it in full")
     # The encoder's four big kernels (one launch per layer each), against HBM: ALGORITHMIC bytes per launch = what the kernel
     # must read and write once (scripts/kernel_roofline.py holds the same table) / the launch duration.
     Tt = B * L

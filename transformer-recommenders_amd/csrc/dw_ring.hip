@@ -240,8 +240,16 @@ int xf_dw_ring_launch(const XfDwItem* items, int n, int64_t M, hipStream_t st) {
   }
   for (int i = n; i <= 4; ++i) p.start[i] = (int)total;
   constexpr size_t smem = (size_t)2 * NST * IMG_ELEMS * sizeof(__bf16);  // 128 KB
-  if (hipFuncSetAttribute((const void*)dw_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return XFMR_EHIP;
+  {  // the dynamic-LDS limit is a per-device attribute of the function: set once per device of this process
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return XFMR_EHIP;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      if (hipFuncSetAttribute((const void*)dw_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return XFMR_EHIP;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+  }
   hipLaunchKernelGGL(dw_ring_kernel, dim3((unsigned)total), dim3(512), smem, st, p);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
