@@ -222,6 +222,36 @@ bool xf_dw_ring_takes(const XfDwItem* items, int n, int64_t M, int32_t precision
   return true;
 }
 
+// The ring kernel's own slab plan. The generic plan (xf_dw_split_plan: ~1024 workgroups of 128 x 64 tiles, three per CU) cuts
+// the tokens into 62-115 slabs per weight at the benchmark shape and 25-50 at small batches; this kernel runs ONE workgroup
+// per CU on 128 x 128 tiles, and a slab costs it a ring fill, a 64 KB tile store and later a row of the reduction launch:
+// ~3 000 tokens per slab, but at least 64 workgroups per weight (128 x 128 tiles x slabs), never more slabs than the generic plan
+// (the slab room is carved for that: xfmr_linear_bwd_dw_workspace). MEASURED (round 4, scripts/probe/dwr_plan_sweep.sh, one
+// box, two rounds, ms per step against the generic plan): batch 128 1.166-1.170 against 1.210; batch 32 0.656-0.670 against
+// 0.690-0.692; MovieLens-like packed batches of 512 (~50 k tokens) 1.94-1.95 against 1.96-1.97; batch 512 dense 3.20-3.22 against
+// 3.19-3.22 (there the plan changes little: 34 / 34 / 64 / 34 slabs instead of 62 / 62 / 115 / 80). 4 096 tokens per slab or
+// fewer than 64 workgroups per weight lose at batch 512 (3.30-3.38 / 3.24-3.25): its four launches per layer run one after the
+// other on the side stream and need the chip's width each.
+static int dw_ring_plan(int64_t M, int N, int K, int* k_chunk) {
+  static const int tokens = [] { const char* e = getenv("XFMR_DWR_TOKENS"); const int v = e ? atoi(e) : 3072; return v < 128 ? 128 : v; }();
+  // (a function of the weight alone -- not of how many weights share the launch -- so that the grouped in-line launch and the
+  //  four side-stream launches of a layer write the same slabs, bit for bit: tests/test_gpu_fullsize.py)
+  static const int min_wg = [] { const char* e = getenv("XFMR_DWR_MINWG"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }();
+  const int launch_tiles = (N / TW) * (K / TW);
+  int generic_chunk;
+  const int generic = xf_dw_split_plan(M, N, K, &generic_chunk);
+  int64_t want = (M + tokens - 1) / tokens;
+  const int64_t lo = (min_wg + launch_tiles - 1) / launch_tiles;
+  if (want < lo) want = lo;
+  if (want > generic) want = generic;
+  if (want < 1) want = 1;
+  int64_t chunk = (M + want - 1) / want;
+  chunk = ((chunk + 127) / 128) * 128;
+  if (chunk < generic_chunk) chunk = generic_chunk;  // (never finer than the generic plan: its slab count is the room's bound)
+  *k_chunk = (int)chunk;
+  return (int)((M + chunk - 1) / chunk);
+}
+
 int xf_dw_ring_launch(const XfDwItem* items, int n, int64_t M, hipStream_t st) {
   DwRingArgs p{};
   p.T = M;
@@ -229,7 +259,7 @@ int xf_dw_ring_launch(const XfDwItem* items, int n, int64_t M, hipStream_t st) {
   for (int i = 0; i < n; ++i) {
     const XfDwItem& t = items[i];
     int k_chunk;
-    const int splits = xf_dw_split_plan(M, t.N, t.K, &k_chunk);
+    const int splits = dw_ring_plan(M, t.N, t.K, &k_chunk);
     DwRingItem& d = p.it[i];
     d.dy = reinterpret_cast<const __bf16*>(t.dy); d.x = reinterpret_cast<const __bf16*>(t.x);
     d.slabs = t.slabs; d.bias_part = t.bias_part; d.N = t.N; d.K = t.K; d.k_chunk = k_chunk; d.splits = splits;
