@@ -101,7 +101,7 @@ def test_grads_half_event_releases_a_finished_upper_half(B, nL, form):
     """The only invariant HalvedAllReduce adds: when xfmr_encoder_cfg.grads_half_event fires, the tail of the flat
     gradient (layers >= L/2, from xfmr_param_half_offset on) is COMPLETE -- although the rest of the backward is still
     running. A second stream that waits for the event ONLY copies the tail; it must equal the finished buffer bit for
-    bit. Both forms of the backward: weight-gradient GEMMs on the context's side stream (>= 65 536 tokens: the early
+    bit. Both forms of the backward: weight-gradient GEMMs on the context's side stream (>= 40 960 tokens: the early
     reduction launch is enqueued there, behind that layer's GEMMs) and everything in line; an odd layer count and a
     single layer (boundary = 0: the whole buffer is the "tail", released by the backward's last reduction)."""
     import ctypes

@@ -293,7 +293,7 @@ def test_ffn_backward_dx_chain_in_one_kernel_is_bit_identical_to_the_two_gemm_fo
 
 @pytest.mark.parametrize("B,nL", [(512, 4), (330, 3)])
 def test_weight_gradient_gemms_on_the_side_stream_give_the_same_bits(ops, B, nL):
-    """At T >= 65 536 (H = 128) the encoder backward enqueues its 4 x layers weight-gradient GEMMs on the low-priority side
+    """At T >= 40 960 (H = 128; 65 536 until round 4) the encoder backward enqueues its 4 x layers weight-gradient GEMMs on the low-priority side
     stream of the caller's xfmr_context (they fill the last, partly empty rounds of the dX chain's 64-row-tile kernels);
     the gradient buffers the chain reuses exist once per layer in that mode. XFMR_ENC_DW_INLINE (or no context) keeps
     everything on one stream: the same kernels on the same data, so every gradient must be equal bit for bit -- over repeated runs (a missed

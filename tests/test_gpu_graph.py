@@ -35,8 +35,39 @@ def X():
     return X
 
 
+def _isolated(train_loss):
+    """Child process of the cross-stream cases below (spawned: its own HIP context)."""
+    import pathlib
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    for p in (root, root / "transformer-recommenders_amd", root / "tests"):
+        sys.path.insert(0, str(p))
+    import xfmr_rec_amd as X
+
+    _replay_equals_eager(X, train_loss, True)
+
+
 @pytest.mark.parametrize("train_loss,overlap", [("InfoNCELoss", True), ("PairwiseLogisticLoss", True), ("InfoNCELoss", False)])
 def test_graph_replay_equals_eager_steps_bit_for_bit_with_dropout(X, train_loss, overlap):
+    """overlap=True captures the step WITH its two forks (weight-gradient GEMMs and logging heads on side streams: graph
+    branches) -- not what the product replays (GraphedStep's default is the single-stream capture: cross-stream graphs replay
+    2-3x slower on this runtime). Those two cases run in a spawned child: round 4 saw ONE segmentation fault inside
+    hipGraphLaunch of such a graph, at its first replay, in a process that had run ~110 other GPU tests before it in an unusual
+    order (full-size, two-rank, packed, then this file); not reproduced by any pair of files nor by the suite in its own
+    order (three runs). A child keeps a runtime fault of the experimental form from taking the whole suite with it."""
+    if not overlap:
+        return _replay_equals_eager(X, train_loss, overlap)
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    proc = ctx.Process(target=_isolated, args=(train_loss,))
+    proc.start()
+    proc.join(300)
+    assert proc.exitcode == 0, f"cross-stream capture / replay child exited with {proc.exitcode}"
+
+
+def _replay_equals_eager(X, train_loss, overlap):
     # eager: the same device-side step counter drives dropout and AdamW
     eager, batches = _setup(X, train_loss)
     eager.model.use_device_step(True)

@@ -121,11 +121,15 @@ bool ffn_fused(const xfmr_encoder_cfg* c, int64_t T) {
 
 // Shapes whose backward runs the weight-gradient GEMMs on the side stream (xfmr_encoder_bwd): those of the LayerNorm-fused
 // dX GEMMs. The workspace holds one set of the gradient buffers per layer for them.
+constexpr int64_t kDwSideTokens = 40960;
 bool dw_side_shape(const xfmr_encoder_cfg* c, int64_t T) {
-  // (T >= 65 536: at batch 128 x 200 tokens the step is 1.36 ms of ~70 launches from one host thread and the 32 extra event
+  // (round 2 set T >= 65 536: at batch 128 x 200 tokens the step is 1.36 ms of ~70 launches from one host thread and the 32 extra event
   //  calls cost more than the overlap gives -- 1.40 vs 1.355 ms; batch 256: even; batch 512: -2.4 %)
   if (!mixed_storage(c) || c->layers > 64) return false;
-  return (c->flags & XFMR_ENC_DW_SIDE_ANY) || (c->hidden == 128 && T >= 65536);
+  // (round 4, with the ring weight-gradient kernel: from 40 960 tokens -- batch 256 x 200 dense 1.925-1.927 against 1.941-1.943 ms,
+  //  MovieLens-like packed batches of 512 (~50 k rows) 1.912 against 1.942; packed batches of 256 (~25 k rows) 1.265 against
+  //  1.237: in line below)
+  return (c->flags & XFMR_ENC_DW_SIDE_ANY) || (c->hidden == 128 && T >= kDwSideTokens);
 }
 
 // Carves `base` (may be null: size query). Layer i's activations are returned in *la when i >= 0.
@@ -479,7 +483,7 @@ int xfmr_encoder_bwd(const xfmr_encoder_cfg* cfg, const float* params, float* gr
   //  is a question of the rows actually run -- ~50 000 packed rows of a MovieLens-like batch of 512: 1.915 in line against
   //  1.95 ms on the side stream, like a dense batch of 256)
   const bool dw_side = ctx && dw_side_shape(cfg, Tplan) && !(cfg->flags & XFMR_ENC_DW_INLINE) &&
-                       ((cfg->flags & XFMR_ENC_DW_SIDE_ANY) || T >= 65536 || !offs);
+                       ((cfg->flags & XFMR_ENC_DW_SIDE_ANY) || T >= kDwSideTokens || !offs);
   hipStream_t const side = dw_side ? ctx->side : nullptr;
   hipEvent_t const ev_in = dw_side ? ctx->ev_in : nullptr, ev_done = dw_side ? ctx->ev_done : nullptr;
   bool side_used = false;

@@ -394,6 +394,8 @@ def encoder_flags_from_env() -> int:
         f |= N.ENC_FFN_BWD_UNFUSED
     if os.environ.get("XFMR_DW_SIDE", "") == "0":
         f |= N.ENC_DW_INLINE
+    if os.environ.get("XFMR_DW_SIDE", "") == "any":  # (experiments: the side stream below its token threshold too)
+        f |= N.ENC_DW_SIDE_ANY
     if os.environ.get("XFMR_DW_PAIR", "") == "0":
         f |= N.ENC_DW_UNPAIRED
     if _env_on("XFMR_REDUCE_HALF_EARLY"):
