@@ -77,7 +77,7 @@ def parse(argv=None):
                     help="skip the `ragged` figures (profiling runs: rocprofv3 --pmc serialises every launch)")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="logging heads on a side stream under the encoder backward: pays off once the logging pass is "
-                         "long enough (B*L >= 102400: +0.6 %% at B=512, -1.4 %% at B=256, -2 %% at B=128); auto decides by that")
+                         "long enough (B*L >= 51200: round 4 measured +1..2 %% at B=256, -1.3 %% at B=128); auto decides by that")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)  # former default switch; no effect
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step as one hipGraph (GraphedStep): auto = when the eager step would be bound by the "
@@ -422,7 +422,7 @@ def main():
         batches.append({k: v.to(dev) for k, v in b.items()})
     tokens_per_seq = sum(lens) / len(lens)
 
-    overlap = args.overlap == "on" or (args.overlap == "auto" and B * L >= 102400)
+    overlap = args.overlap == "on" or (args.overlap == "auto" and B * L >= 51200)  # (= the module's own "auto" rule)
 
     # Host -> HBM hand-over inside the step ("H2D of the 3 index tensors -> ..."): persistent device slots,
     # pre-created events, one hipMemcpyAsync per batch on a copy stream, the copy of batch i + 1 underneath step i -- the

@@ -412,10 +412,11 @@ class RecommenderLightningModule(_Base):
         prof = getattr(self, "profile_events", None) or (None, None)  # bench.py: hipEvent pairs around the two loss passes
         defer = getattr(self, "defer_logging", "auto")
         if defer == "auto":
-            # the side-stream logging pass pays once it is long enough to be worth hiding: B x L >= 102 400 tokens
-            # (+0.6 % at batch 512 x 200, -1.4 % at 256, -2 % at 128: measured in round 1, bench.py --overlap)
+            # the side-stream logging pass pays once it is long enough to be worth hiding: B x L >= 51 200 tokens
+            # (round 4, bench.py --overlap on / off, one box: batch 256 x 200 1.918-1.947 against 1.958-1.962 ms, batch 128
+            #  1.193 against 1.178; round 1 had measured -1.4 % at 256 and set 102 400)
             h = batch["history_item_idx"]
-            defer = h.shape[0] * min(h.shape[1], self.model.max_seq_length) >= 102400
+            defer = h.shape[0] * min(h.shape[1], self.model.max_seq_length) >= 51200
         out = self.compute_losses(batch, sync_metrics=False, defer_logging=bool(defer),
                                   profile_grad=prof[0], profile_log=prof[1])
         key = f"loss/{self.config.train_loss}"
