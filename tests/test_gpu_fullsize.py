@@ -211,7 +211,7 @@ def test_h256_gradient_pass_split_plans_agree_with_the_fp32_path(ops, T, head):
 # operand images are smaller than the fused epilogues' LDS scratch + exchange records
 @pytest.mark.parametrize("B,nL,reps,I", [(512, 2, 8, 512), (97, 1, 2, 512), (97, 2, 1, 96)])
 def test_config2_encoder_with_layernorm_in_the_gemm_epilogues_equals_the_separate_kernels(ops, B, nL, reps, I):
-    """At T >= 16 384 tokens (H = 128) the encoder applies the LayerNorms inside GEMM epilogues: forward in the
+    """At T >= 12 288 tokens (H = 128; 16 384 until round 4) the encoder applies the LayerNorms inside GEMM epilogues: forward in the
     out-proj / FFN2 Linears, backward in the dX GEMMs that produce the LayerNorm output gradients. XFMR_LN_UNFUSED=1
     (read per call) keeps the separate LayerNorm launches: same token embeddings and the same parameter gradients, to
     fp32 rounding of the row statistics / bf16 rounding of the copies (dropout on: the masks are shared)."""

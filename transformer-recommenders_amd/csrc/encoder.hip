@@ -113,10 +113,14 @@ int prof(const xfmr_encoder_cfg* c, int kind, int layer, int which, hipStream_t 
 bool ln_fused(const xfmr_encoder_cfg* c, int64_t T) {
   // out-proj / FFN2 GEMM + LayerNorm as one kernel: its 64 x 128 tiles are T / 64 workgroups -- below one per CU
   // (T < 16 384) the two-kernel form with 64 x 64 tiles is faster (batch 32: -1.5 % fused; batch 128: +0.9 %; 512: +1.8 %)
-  return mixed_storage(c) && c->hidden == 128 && T >= 16384 && !(c->flags & XFMR_ENC_LN_UNFUSED);
+  // (round 4: from 12 288 tokens -- batch 64 x 200: 0.876 against 0.889 ms with the two LayerNorm-fused GEMMs and the FFN as
+  //  separate GEMMs; at batch 32 nothing in it, 0.662 against 0.661-0.672. XFMR_LN_FUSED_MIN_TOKENS for experiments.)
+  static const int64_t min_tokens = [] { const char* e = getenv("XFMR_LN_FUSED_MIN_TOKENS"); return e ? (int64_t)atoll(e) : (int64_t)12288; }();
+  return mixed_storage(c) && c->hidden == 128 && T >= min_tokens && !(c->flags & XFMR_ENC_LN_UNFUSED);
 }
 bool ffn_fused(const xfmr_encoder_cfg* c, int64_t T) {
-  return ln_fused(c, T) && (c->inter % 128) == 0 && c->inter <= 1024 && !(c->flags & XFMR_ENC_FFN_UNFUSED);
+  // (the fused FFN pair keeps its 16 384 tokens: at 12 800 it measured 0.887 against 0.876 ms for the separate GEMMs)
+  return ln_fused(c, T) && T >= 16384 && (c->inter % 128) == 0 && c->inter <= 1024 && !(c->flags & XFMR_ENC_FFN_UNFUSED);
 }
 
 // Shapes whose backward runs the weight-gradient GEMMs on the side stream (xfmr_encoder_bwd): those of the LayerNorm-fused
