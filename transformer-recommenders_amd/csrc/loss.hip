@@ -988,7 +988,10 @@ static int run_loss(const xfmr_loss_cfg* cfg, const float* tok, const float* tab
       int best = p.nsplit;
       double best_cost = 1e30;
       for (int n = 1; n <= p.nsplit; ++n) {
-        const double cost = (double)(((int64_t)grid.x * n + cus - 1) / cus) / n;
+        // (+ 0.01 per split: every split writes and the combine kernel re-reads a (queries x H) fp32 partial dQ -- at 8 query
+        //  blocks (the reference's default model: 32 x 32 tokens, H = 384) 8 splits measured 0.303 ms per step against 0.313
+        //  for 16 and 0.306 for 4; configs 4 / 5 keep their 5 / 1)
+        const double cost = (double)(((int64_t)grid.x * n + cus - 1) / cus) / n + 0.01 * n;
         if (cost < best_cost - 1e-9) { best_cost = cost; best = n; }
       }
       ns_grad = best;
