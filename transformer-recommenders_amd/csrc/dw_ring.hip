@@ -32,7 +32,9 @@ namespace {
 // workgroup per CU) 3.20-3.21; 64 x 2 (64 KB, two per CU) 3.25-3.29; 32 x 4 (64 KB, two per CU) 3.24-3.28. In isolation a
 // weight takes the same time with 2, 3 or 4 stages of 64 tokens, and the same with three quarters of the operand reads
 // compiled out: at 4.7-5.1 TB/s of operands (7 TB/s out of L2 with the tiles' re-reads) the launch sits at the memory
-// system, not at the ring depth or the LDS port.
+// system, not at the ring depth or the LDS port. (Also measured: even / odd 16-token steps on separate accumulators -- four
+// independent MFMA chains per wave instead of two -- 36.7 against 36.7 us on a 102-workgroup launch: the SQ counters' 45 %
+// "issue stalled" of this kernel, profiles/r04_step_pmc.md, is not the accumulate chain.)
 #ifndef XF_DWR_RT
 #define XF_DWR_RT 64
 #endif
