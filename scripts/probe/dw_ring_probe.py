@@ -31,7 +31,7 @@ for name, (n, k, bias) in shapes.items():
     slab_bytes = lib.xf_linear_bwd_dw_slab_bytes(T, n, k)
     slabs = [torch.zeros(slab_bytes // 4, device=dev) for _ in range(2)]
     bparts = [torch.zeros(256 * n, device=dev) if bias else None for _ in range(2)]
-    splits = (C.c_int * 1)()
+    splits = [(C.c_int * 1)(), (C.c_int * 1)()]  # (the two kernels have their own slab plans)
     ops[name] = (dy, x, n, k, slabs, bparts, splits)
 
 def items(names, which):
@@ -39,7 +39,7 @@ def items(names, which):
     for i, nm in enumerate(names):
         dy, x, n, k, slabs, bparts, splits = ops[nm]
         arr[i] = Item(dy.data_ptr(), x.data_ptr(), n, k, slabs[which].data_ptr(),
-                      bparts[which].data_ptr() if bparts[which] is not None else None, C.addressof(splits))
+                      bparts[which].data_ptr() if bparts[which] is not None else None, C.addressof(splits[which]))
     return arr
 
 def run(names, ring):
@@ -62,13 +62,13 @@ for names in (["qkv"], ["out"], ["ffn1"], ["ffn2"], ["ffn2", "ffn1", "out", "qkv
     print(f"{'+'.join(names):22s} generic {tg:7.1f} us {byts / tg / 1e6:5.2f} TB/s   ring {tr:7.1f} us {byts / tr / 1e6:5.2f} TB/s")
 torch.cuda.synchronize()
 for nm, (dy, x, n, k, slabs, bparts, splits) in ops.items():
-    s = splits[0]
-    a = slabs[0][: s * n * k].view(s, n, k).sum(0)
+    sg, s = splits[0][0], splits[1][0]
+    a = slabs[0][: sg * n * k].view(sg, n, k).sum(0)
     b = slabs[1][: s * n * k].view(s, n, k).sum(0)
     ref = dy.float().t() @ x.float()
     rel = lambda u, v: float((u - v).norm() / v.norm())
-    msg = f"{nm}: splits {s} generic-vs-torch {rel(a, ref):.2e} ring-vs-torch {rel(b, ref):.2e}"
+    msg = f"{nm}: slabs {sg} / {s} generic-vs-torch {rel(a, ref):.2e} ring-vs-torch {rel(b, ref):.2e}"
     if bparts[0] is not None:
-        ba, bb = bparts[0][: s * n].view(s, n).sum(0), bparts[1][: s * n].view(s, n).sum(0)
+        ba, bb = bparts[0][: sg * n].view(sg, n).sum(0), bparts[1][: s * n].view(s, n).sum(0)
         msg += f"  bias: generic {rel(ba, dy.float().sum(0)):.2e} ring {rel(bb, dy.float().sum(0)):.2e}"
     print(msg)
