@@ -62,6 +62,15 @@ def test_pack_rows_kernel(ops):
     assert torch.equal(pk["row_pos"].cpu().long(), torch.arange(L)[None, :].expand(B, L)[valid])
     pk2 = ops.pack_rows(batch["history_item_idx"].to(DEV), batch["pos_item_idx"].to(DEV), None, off.to(DEV), rows)
     assert pk2["neg"] is None and torch.equal(pk2["hist"], pk["hist"])
+    # in another order (xfmr_pack_rows_ordered): slot b holds batch row order[b] -- the same as packing the reordered batch
+    order, off_o = ops.length_order(lengths)
+    assert [lengths[i] for i in order.tolist()] == sorted(lengths, reverse=True)
+    pk_o = ops.pack_rows(*(batch[k].to(DEV) for k in ("history_item_idx", "pos_item_idx", "neg_item_idx")), off_o.to(DEV), rows,
+                         order=order.to(DEV))
+    pk_r = ops.pack_rows(*(batch[k][order].contiguous().to(DEV) for k in ("history_item_idx", "pos_item_idx", "neg_item_idx")),
+                         off_o.to(DEV), rows)
+    for k in ("hist", "pos", "neg", "seq_offsets", "row_pos"):
+        assert torch.equal(pk_o[k], pk_r[k]), k
 
 
 @pytest.mark.parametrize("B,L,H,A,I,nL,lengths", [
@@ -192,7 +201,11 @@ def test_packed_step_through_the_ring_trainer_and_the_registered_ops(X, monkeypa
     got = ring.take()
     assert got["lengths"].tolist() == lengths and got["packed_rows"] == sum(lengths)
     torch.cuda.synchronize()
-    assert got["offsets"].cpu().tolist() == _offsets(lengths).tolist()
+    # the packed layout takes the rows longest first (ops.length_order): the ring ships that order and the offsets in it
+    order = got["order"].cpu().tolist()
+    assert sorted(order) == list(range(B)) and [lengths[i] for i in order] == sorted(lengths, reverse=True)
+    assert order == [0, 3, 6, 2, 5, 1, 7, 4]  # (stable: equal lengths keep their batch order)
+    assert got["offsets"].cpu().tolist() == _offsets([lengths[i] for i in order]).tolist()
     ring.release()
     ring.close()
     calls = []

@@ -539,9 +539,12 @@ int ln_bwd_blocks_bound(int64_t rows) {
 
 // ---- packed rows (xfmr_encoder_cfg.seq_offsets) ----------------------------------------------------------------------
 // one block row per sequence: rows [0, len_b) of the three (B, L) index tensors -> their packed places
+// `order` (optional): packed slot b holds batch row order[b] -- the caller sorts the sequences by length, longest first, so
+// that the one-workgroup-per-(sequence, head) attention kernels start their longest workgroups first (xfmr_pack_rows_ordered)
 __global__ __launch_bounds__(256) void pack_rows_kernel(const int64_t* hist, const int64_t* pos, const int64_t* neg,
-                                                        const int64_t* offs64, int L, int64_t packed_rows, int64_t* hist_p,
-                                                        int64_t* pos_p, int64_t* neg_p, int32_t* offs32, int32_t* row_pos) {
+                                                        const int64_t* offs64, const int64_t* order, int B, int L,
+                                                        int64_t packed_rows, int64_t* hist_p, int64_t* pos_p, int64_t* neg_p,
+                                                        int32_t* offs32, int32_t* row_pos) {
   const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
   const int64_t o0 = offs64[b], o1 = offs64[b + 1];
   if (l == 0) {
@@ -550,7 +553,12 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const int64_t* hist, con
   }
   const int64_t len = o1 - o0;
   if (l >= len || len > L || o0 + l >= packed_rows) return;  // (a malformed offset table writes nothing out of range)
-  const int64_t src = (int64_t)b * L + l, dst = o0 + l;
+  int64_t brow = b;
+  if (order) {
+    brow = order[b];
+    if (brow < 0 || brow >= B) return;  // (a malformed order reads nothing out of range)
+  }
+  const int64_t src = brow * L + l, dst = o0 + l;
   hist_p[dst] = hist[src];
   pos_p[dst] = pos[src];
   if (neg) neg_p[dst] = neg[src];
@@ -735,17 +743,23 @@ int xf_embed_param_grads_packed(const float* d_pre, float* d_pos, float* d_type,
   return XFMR_OK;
 }
 
-int xfmr_pack_rows(const int64_t* hist, const int64_t* pos, const int64_t* neg, const int64_t* offsets64, int32_t batch,
-                   int32_t seq_len, int64_t packed_rows, int64_t* hist_p, int64_t* pos_p, int64_t* neg_p,
-                   int32_t* offsets32, int32_t* row_pos, void* stream) {
+int xfmr_pack_rows_ordered(const int64_t* hist, const int64_t* pos, const int64_t* neg, const int64_t* offsets64,
+                           const int64_t* order, int32_t batch, int32_t seq_len, int64_t packed_rows, int64_t* hist_p,
+                           int64_t* pos_p, int64_t* neg_p, int32_t* offsets32, int32_t* row_pos, void* stream) {
   if (!hist || !pos || !offsets64 || !hist_p || !pos_p || !offsets32 || !row_pos) return XFMR_EINVAL;
   if ((neg == nullptr) != (neg_p == nullptr)) return XFMR_EINVAL;
   if (batch <= 0 || seq_len <= 0 || packed_rows < 0 || packed_rows > (int64_t)batch * seq_len) return XFMR_EINVAL;
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((seq_len + 255) / 256), (unsigned)batch), dim3(256), 0,
-                     (hipStream_t)stream, hist, pos, neg, offsets64, seq_len, packed_rows, hist_p, pos_p, neg_p, offsets32,
-                     row_pos);
+                     (hipStream_t)stream, hist, pos, neg, offsets64, order, batch, seq_len, packed_rows, hist_p, pos_p, neg_p,
+                     offsets32, row_pos);
   XF_LAUNCH_CHECK();
   return XFMR_OK;
+}
+int xfmr_pack_rows(const int64_t* hist, const int64_t* pos, const int64_t* neg, const int64_t* offsets64, int32_t batch,
+                   int32_t seq_len, int64_t packed_rows, int64_t* hist_p, int64_t* pos_p, int64_t* neg_p,
+                   int32_t* offsets32, int32_t* row_pos, void* stream) {
+  return xfmr_pack_rows_ordered(hist, pos, neg, offsets64, nullptr, batch, seq_len, packed_rows, hist_p, pos_p, neg_p,
+                                offsets32, row_pos, stream);
 }
 
 int xfmr_pool(const float* tok, const uint8_t* key_mask, float* out, int32_t B, int32_t L, int32_t H, int32_t mode,

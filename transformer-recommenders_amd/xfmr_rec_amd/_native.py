@@ -108,6 +108,7 @@ _SIGNATURES = {
     "xfmr_embed_ln_fwd": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_uint32, _P]),
     "xfmr_pack_rows": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "xfmr_pack_rows_ordered": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "xfmr_embed_param_grads": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "xfmr_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "xfmr_layernorm_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int32]),

@@ -142,8 +142,10 @@ class PinnedBatchRing:
             self.host = [torch.zeros(self.shape, dtype=torch.int64).pin_memory() for _ in range(self.slots)]
             # the rows' cumulative lengths (batch + 1 int64): what the PACKED layout of the encoder needs from the host
             # (xfmr_encoder_cfg.seq_offsets); a second small copy on the same stream, in front of the batch's
-            self.dev_off = [torch.zeros(int(batch) + 1, dtype=torch.int64, device=self.device) for _ in range(self.slots)]
-            self.host_off = [torch.zeros(int(batch) + 1, dtype=torch.int64).pin_memory() for _ in range(self.slots)]
+            # ... and the ORDER the packed layout takes the rows in (longest first: ops.length_order), behind the offsets:
+            # [0, b] cumulative lengths in that order, [b + 1, 2 b] the order (b = the staged batch's rows)
+            self.dev_off = [torch.zeros(2 * int(batch) + 1, dtype=torch.int64, device=self.device) for _ in range(self.slots)]
+            self.host_off = [torch.zeros(2 * int(batch) + 1, dtype=torch.int64).pin_memory() for _ in range(self.slots)]
             h = ctypes.c_void_p()
             N.check(self.lib.xfmr_stream_create(ctypes.byref(h)), "xfmr_stream_create")
             self.copy_stream = h.value
@@ -201,11 +203,14 @@ class PinnedBatchRing:
         lens = row_lengths(blk[0]) if lengths is None else torch.as_tensor(lengths, dtype=torch.int64).cpu()
         b = shape[1]
         off = self.host_off[s]
-        off[0] = 0
-        torch.cumsum(lens, 0, out=off[1 : b + 1])
+        from .ops import length_order
+
+        order, cum = length_order(lens)  # longest first (XFMR_PACK_ORDER=0: the batch's own order)
+        off[: b + 1] = cum
+        off[b + 1 : 2 * b + 1] = order
         self.lengths[s], self.rows[s] = lens, int(off[b])
         nbytes = 8 * shape[0] * shape[1] * shape[2]
-        N.check(self.lib.xfmr_batch_upload(self.dev_off[s].data_ptr(), off.data_ptr(), 8 * (b + 1), self.copy_stream,
+        N.check(self.lib.xfmr_batch_upload(self.dev_off[s].data_ptr(), off.data_ptr(), 8 * (2 * b + 1), self.copy_stream,
                                            self.free[s] if self.used[s] else None, self.ready[s]), "xfmr_batch_upload")
         N.check(self.lib.xfmr_batch_upload(self.dev[s].data_ptr(), blk.data_ptr(), nbytes, self.copy_stream, None,
                                            self.ready[s]), "xfmr_batch_upload")
@@ -231,7 +236,10 @@ class PinnedBatchRing:
         v = self.dev[s].view(-1)[: shape[0] * shape[1] * shape[2]].view(shape)
         out = {k: v[i] for i, k in enumerate(SEQ_BATCH_KEYS)}
         # what the packed layout needs: the lengths (host), their cumulative offsets (device) and their sum (host)
-        out |= {"lengths": self.lengths[s], "offsets": self.dev_off[s][: shape[1] + 1], "packed_rows": self.rows[s]}
+        # (offsets = the cumulative lengths in the ORDER the packed layout takes the rows in: longest first)
+        b = shape[1]
+        out |= {"lengths": self.lengths[s], "offsets": self.dev_off[s][: b + 1], "order": self.dev_off[s][b + 1 : 2 * b + 1],
+                "packed_rows": self.rows[s]}
         return out
 
     def release(self) -> None:

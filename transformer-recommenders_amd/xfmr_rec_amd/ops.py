@@ -454,21 +454,37 @@ class Context:
             pass
 
 
-def pack_rows(hist, pos, neg, offsets64, rows: int):
+def pack_rows(hist, pos, neg, offsets64, rows: int, order=None):
     """The PACKED layout of a collated batch (xfmr_pack_rows): hist / pos / neg (B, L) int64 device tensors (neg may be
     None), offsets64 (B + 1) int64 on the device = the cumulative row lengths, ``rows`` = offsets64[-1] as the HOST knows
-    it (the collate padded the rows: it knows their lengths). Returns the packed (rows,) index tensors, ``seq_offsets``
-    (B + 1) int32 and ``row_pos`` (rows,) int32 for make_encoder_cfg."""
+    it (the collate padded the rows: it knows their lengths). ``order`` (B,) int64 on the device: packed slot b holds batch row
+    order[b] and offsets64 are the cumulative lengths in THAT order (:func:`length_order`: longest first). Returns the packed
+    (rows,) index tensors, ``seq_offsets`` (B + 1) int32 and ``row_pos`` (rows,) int32 for make_encoder_cfg."""
     B, L = hist.shape
     dev = hist.device
     out = {k: torch.empty((rows,), dtype=torch.int64, device=dev) for k in ("hist", "pos")}
     out["neg"] = torch.empty((rows,), dtype=torch.int64, device=dev) if neg is not None else None
     out["seq_offsets"] = torch.empty((B + 1,), dtype=torch.int32, device=dev)
     out["row_pos"] = torch.empty((rows,), dtype=torch.int32, device=dev)
-    N.check(N.load().xfmr_pack_rows(N.ptr(hist), N.ptr(pos), N.ptr(neg), N.ptr(offsets64), B, L, rows, N.ptr(out["hist"]),
-                                    N.ptr(out["pos"]), N.ptr(out["neg"]), N.ptr(out["seq_offsets"]), N.ptr(out["row_pos"]),
-                                    N.stream()), "xfmr_pack_rows")
+    N.check(N.load().xfmr_pack_rows_ordered(N.ptr(hist), N.ptr(pos), N.ptr(neg), N.ptr(offsets64), N.ptr(order), B, L, rows,
+                                            N.ptr(out["hist"]), N.ptr(out["pos"]), N.ptr(out["neg"]), N.ptr(out["seq_offsets"]),
+                                            N.ptr(out["row_pos"]), N.stream()), "xfmr_pack_rows_ordered")
     return out
+
+
+def length_order(lengths):
+    """(order, offsets) of a batch's row lengths (CPU int64 tensor) for the packed layout: the rows by length, LONGEST first
+    (stable), and the cumulative lengths in that order (B + 1). The attention kernels run one workgroup per (sequence, head)
+    in slot order; a 200-token sequence that starts last is a 28 us tail on a launch whose balanced time is ~45 (MovieLens-like
+    batches of 512, one-stream trace: attention backward 72.6 -> 58.2 us per layer, forward 26.2 -> 20.2; step 1.867 -> 1.853 ms)."""
+    lens = torch.as_tensor(lengths, dtype=torch.int64).cpu()
+    if os.environ.get("XFMR_PACK_ORDER", "") == "0":  # (A/B runs: the batch's own order)
+        order = torch.arange(lens.numel(), dtype=torch.int64)
+    else:
+        order = torch.argsort(lens, descending=True, stable=True)
+    off = torch.zeros(lens.numel() + 1, dtype=torch.int64)
+    torch.cumsum(lens[order], 0, out=off[1:])
+    return order, off
 
 
 def encoder_fwd(cfg: N.EncoderCfg, flat_params, item_idx, table):

@@ -209,12 +209,14 @@ class RecommenderLightningModule(_Base):
                 and not torch.cuda.is_current_stream_capturing()):
             rows = int(batch["packed_rows"]) if "packed_rows" in batch else int(lens.sum())
             if 0 < rows <= 0.97 * hist.shape[0] * L:  # (a nearly full batch gains nothing)
-                offs64 = batch.get("offsets")
+                # the sequences go into the packed layout by length, LONGEST first (ops.length_order: nothing depends on the order
+                # of a batch's rows -- every loss is a sum over them -- and the attention kernels start their longest workgroups
+                # first); PinnedBatchRing ships the order and the offsets in that order with the batch
+                offs64, order = batch.get("offsets"), batch.get("order")
                 if offs64 is None:
-                    offs64 = torch.zeros(hist.shape[0] + 1, dtype=torch.int64)
-                    offs64[1:] = torch.cumsum(torch.as_tensor(lens, dtype=torch.int64), 0)
-                    offs64 = offs64.to(dev)
-                packed = ops.pack_rows(hist.to(dev, torch.int64).contiguous(), pos, neg, offs64, rows)
+                    order, offs64 = ops.length_order(lens)
+                    order, offs64 = order.to(dev), offs64.to(dev)
+                packed = ops.pack_rows(hist.to(dev, torch.int64).contiguous(), pos, neg, offs64, rows, order=order)
                 packed |= {"batch": hist.shape[0], "seq_len": L}
                 pos, neg = packed["pos"], packed["neg"]
                 padded_positions = hist.shape[0] * L
