@@ -609,6 +609,19 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
       float dotp = 0.f;
       constexpr int NSW = 8;  // 128-column sweeps: H <= 1024
       float4 gk[NSW];         // the row's gradient pieces of this lane
+      // the splits' rescaling factors, once per row (InfoNCE: exp2(m_s - M); 1 otherwise; 0 past the plan's split count).
+      // Up to 16 splits (every plan's count) the partial rows of a sweep are then loaded EIGHT at a time: one dependent
+      // round trip per split and sweep was 13 us of this kernel's 25 on the small steps (round 4, parts compiled out).
+      constexpr int FS = 16;
+      float fs[FS];
+      const int ns = a.nsplit;
+#pragma unroll
+      for (int u = 0; u < FS; ++u) {
+        const int sidx = u < ns ? u : (ns > 0 ? ns - 1 : 0);
+        float f = 1.f;
+        if (head == XFMR_LOSS_INFONCE) f = exp2f(a.part[((int64_t)sidx * a.T + qi) * REC + R_M] - M);
+        fs[u] = u < ns ? f : 0.f;
+      }
 #pragma unroll
       for (int sw = 0; sw < NSW; ++sw) {
         const int c = sw * 128 + 4 * hl;
@@ -616,11 +629,29 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(CombineArgs a) {
         if (c >= H) continue;
         float4 O = make_float4(0, 0, 0, 0);
         if (head != XFMR_LOSS_ALIGNMENT) {
-          for (int s = 0; s < a.nsplit; ++s) {
-            float4 v = *reinterpret_cast<const float4*>(&a.partO[((int64_t)s * a.T + qi) * H + c]);
-            float f = 1.f;
-            if (head == XFMR_LOSS_INFONCE) f = exp2f(a.part[((int64_t)s * a.T + qi) * REC + R_M] - M);
-            O.x += v.x * f; O.y += v.y * f; O.z += v.z * f; O.w += v.w * f;
+          if (ns <= FS) {
+#pragma unroll
+            for (int s0 = 0; s0 < FS; s0 += 8) {
+              if (s0 >= ns) break;
+              float4 v[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {  // (past the count: the last split's row again, weighted 0)
+                const int sidx = s0 + u < ns ? s0 + u : ns - 1;
+                v[u] = *reinterpret_cast<const float4*>(&a.partO[((int64_t)sidx * a.T + qi) * H + c]);
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const float f = fs[s0 + u];
+                O.x += v[u].x * f; O.y += v[u].y * f; O.z += v[u].z * f; O.w += v[u].w * f;
+              }
+            }
+          } else {
+            for (int s = 0; s < ns; ++s) {
+              float4 v = *reinterpret_cast<const float4*>(&a.partO[((int64_t)s * a.T + qi) * H + c]);
+              float f = 1.f;
+              if (head == XFMR_LOSS_INFONCE) f = exp2f(a.part[((int64_t)s * a.T + qi) * REC + R_M] - M);
+              O.x += v.x * f; O.y += v.y * f; O.z += v.z * f; O.w += v.w * f;
+            }
           }
         }
         const float4 e4 = *reinterpret_cast<const float4*>(ep + c);
